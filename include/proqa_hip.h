@@ -1,0 +1,169 @@
+/*
+ * proqa_hip.h — C ABI of libproqa_hip.so, the MI355X (gfx950) implementation of
+ * ProQA's dense-retrieval hot path: corpus/query encode -> .npy index -> exhaustive
+ * inner-product top-k search.
+ *
+ * The reference (xwhan/ProQA, pure Python) has no FFI of its own: its hot path calls
+ * third-party libraries (faiss-cpu, transformers/torch).  Every entry point below
+ * names the reference call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative PROQA_E* code on failure;
+ *     proqa_last_error() gives a thread-local message for the last failure.
+ *   - plain pointers and sizes only; no torch / numpy types.  Pointers named *_dev are
+ *     device (HBM) addresses valid on the current HIP device; all others are host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ *   - the caller allocates every output; the library never frees caller memory.
+ *   - handles are not re-entrant: one host thread per handle at a time.
+ *   - one process drives one GPU (the current HIP device at handle creation).
+ */
+#ifndef PROQA_HIP_H
+#define PROQA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PROQA_ABI_VERSION 1
+
+/* element types of embedding matrices (the .npy index is '<f2' under --fp16, else '<f4':
+ * retrieval/get_embed.py:139) */
+#define PROQA_F16 0
+#define PROQA_F32 1
+
+/* error codes */
+#define PROQA_OK 0
+#define PROQA_EINVAL (-1)   /* bad argument */
+#define PROQA_EHIP (-2)     /* HIP runtime error (message carries hipGetErrorString) */
+#define PROQA_ENOMEM (-3)   /* allocation failed */
+#define PROQA_EIO (-4)      /* file error */
+#define PROQA_EFORMAT (-5)  /* malformed .npy */
+#define PROQA_ENOGPU (-6)   /* no usable gfx950 device */
+
+/* embedding width is hard-coded to 128 at every consumer in the reference
+ * (retrieval/retriever.py:19-20, retrieval/eval_retrieval.py:98) */
+#define PROQA_EMBED_DIM 128
+
+const char* proqa_last_error(void);
+int proqa_abi_version(void);
+/* number of visible HIP devices, and the gcnArchName of the current one (e.g. "gfx950:...") */
+int proqa_device_info(int* n_devices, char* arch_name, size_t arch_name_len);
+
+/* ------------------------------------------------------------------------------------
+ * Exact inner-product index.  Replaces
+ *     index = faiss.IndexFlatIP(d); index.add(xb); D, I = index.search(xq, k)
+ * at retrieval/eval_retrieval.py:102-104 (also retrieval/trec_process.py:74-76).
+ * Results: scores descending; exact ties ordered by ascending row index (FAISS leaves the
+ * tie order unspecified); if fewer than k rows exist the tail is I = -1, D = -FLT_MAX.
+ * Rows are stored in HBM as fp16 (the --fp16 index format); scores accumulate in fp32.
+ * ---------------------------------------------------------------------------------- */
+typedef struct proqa_index proqa_index;
+
+/* d must be 128.  capacity_rows > 0 preallocates HBM for that many rows (avoids regrowth). */
+int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out);
+/* append n rows from host memory (row-major [n, d], dtype PROQA_F16 or PROQA_F32; F32 is
+ * rounded to fp16 on upload, exact for indexes that were written as '<f2').  May be called
+ * repeatedly, e.g. once per mmap chunk of para_embed.npy. */
+int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype);
+/* same, source already in HBM (used by the synthetic benchmark and the sharded path) */
+int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int dtype, void* stream);
+/* adopt caller-owned fp16 rows already in HBM without copying; the caller keeps them alive
+ * until proqa_index_free/reset */
+int proqa_index_adopt_device(proqa_index* idx, const void* xb_dev_f16, int64_t n);
+int proqa_index_ntotal(const proqa_index* idx, int64_t* n);
+int proqa_index_reset(proqa_index* idx);
+int proqa_index_free(proqa_index* idx);
+
+/* host-pointer search: xq row-major [nq, d]; D float32 [nq, k]; I int64 [nq, k] */
+int proqa_index_search(proqa_index* idx, const void* xq, int64_t nq, int dtype, int k,
+                       float* D, int64_t* I);
+/* device-pointer search; row indices are reported as idx_offset + local row so that a
+ * row-sharded corpus yields global ids.  Synchronises `stream` before returning. */
+int proqa_index_search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k,
+                              int64_t idx_offset, float* D_dev, int64_t* I_dev, void* stream);
+
+/* statistics of the last search on this handle (for tests and the benchmark) */
+typedef struct proqa_search_stats {
+  int32_t rounds;            /* filter+merge rounds launched */
+  int32_t fallback_rounds;   /* rounds re-run on the overflow-safe path */
+  int64_t candidates;        /* (score,id) pairs that passed the running threshold */
+  float filter_ms;           /* HIP-event time of the mips_filter launches, summed over the
+                                rounds (0 unless profiling is enabled on the handle) */
+  float total_ms;            /* HIP-event time of the whole search on the stream */
+} proqa_search_stats;
+int proqa_index_last_stats(const proqa_index* idx, proqa_search_stats* out);
+/* bracket every mips_filter launch with HIP events on the search stream (bench.py roofline) */
+int proqa_index_set_profiling(proqa_index* idx, int enable);
+/* tuning knobs (0 keeps the default): candidate capacity per query per round, slab growth */
+int proqa_index_configure(proqa_index* idx, int cand_capacity, int first_slab_rows, int growth);
+
+/* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
+ * (the layout an RCCL all-gather of per-rank [nq, k] produces).  Same ordering rule. */
+int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts,
+                            int64_t nq, int k, float* D_dev, int64_t* I_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Encoder kernels.  Replace the non-GEMM arithmetic of
+ *     BertForRetriever.get_embed (retrieval/retriever.py:33-43)
+ * i.e. transformers' BertModel forward; the 768x768 / 768x3072 GEMMs stay on
+ * PyTorch-ROCm (hipBLASLt).  All tensors fp16 row-major in HBM, fp32 statistics.
+ * ---------------------------------------------------------------------------------- */
+
+/* out[b,s,:] = LayerNorm(word[ids[b,s]] + pos[s] + type[0]) , eps = 1e-12
+ * (BertEmbeddings; token_type_ids are never passed by the reference => row 0) */
+int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_len, int hidden,
+                              const void* word_emb, int64_t vocab, const void* pos_emb,
+                              const void* type_emb, const void* ln_gamma, const void* ln_beta,
+                              float eps, void* out, void* stream);
+
+/* fused multi-head self-attention for one layer:
+ *   ctx = softmax(Q K^T / sqrt(64) + key_mask) V,   head_dim 64
+ * qkv is the fused projection output [B*S, 3*hidden] (Q | K | V, each head-major);
+ * seq_lens[b] = number of valid (unpadded) keys of sequence b — the reference pads on the
+ * right with mask False (retrieval/datasets.py:29-45,298-305). */
+int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
+                        int n_heads, void* ctx_out, void* stream);
+
+/* x = gelu_erf(x + bias) in place, x [rows, cols] (BertIntermediate, hidden_act='gelu') */
+int proqa_bias_gelu_f16(void* x, const void* bias, int64_t rows, int cols, void* stream);
+
+/* out = LayerNorm(x + bias + residual) (BertSelfOutput / BertOutput), eps = 1e-12 */
+int proqa_bias_residual_layernorm_f16(const void* x, const void* bias, const void* residual,
+                                      const void* gamma, const void* beta, float eps,
+                                      int64_t rows, int cols, void* out, void* stream);
+
+/* embed[b,:] = (tanh(h[b,0,:] Wp^T + bp)) Wproj^T + bproj
+ * (BertPooler + proj_{q,c}: retrieval/retriever.py:19-20,37-42).  h is [B, S, hidden];
+ * out is [B, 128] in out_dtype. */
+int proqa_pool_project_f16(const void* h, int batch, int seq_len, int hidden, const void* w_pool,
+                           const void* b_pool, const void* w_proj, const void* b_proj,
+                           void* out, int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * .npy index files.  Replace np.save (retrieval/get_embed.py:139) and np.load
+ * (retrieval/eval_retrieval.py:99-100) for 2-D C-order '<f2' / '<f4' arrays, format v1.0,
+ * header padded so that data starts at a multiple of 64 bytes.
+ * ---------------------------------------------------------------------------------- */
+typedef struct proqa_npy_info {
+  int64_t rows;
+  int64_t cols;
+  int32_t dtype;        /* PROQA_F16 / PROQA_F32 */
+  int64_t data_offset;  /* byte offset of element [0,0] */
+} proqa_npy_info;
+
+int proqa_npy_stat(const char* path, proqa_npy_info* info);
+/* read rows [row0, row0+n) into dst (host), element type as stored */
+int proqa_npy_read_rows(const char* path, int64_t row0, int64_t n, void* dst, size_t dst_bytes);
+/* write a whole array */
+int proqa_npy_write(const char* path, const void* data, int64_t rows, int64_t cols, int dtype);
+/* create a pre-sized file (header + zero-filled data) that ranks later fill by row range */
+int proqa_npy_create(const char* path, int64_t rows, int64_t cols, int dtype);
+int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* src);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROQA_HIP_H */

@@ -1,0 +1,157 @@
+"""ctypes binding of libproqa_hip.so (C ABI declared in include/proqa_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is visible the
+calls raise.  PyTorch is used only as the owner of device memory and streams; raw device
+pointers (tensor.data_ptr()) and the current stream handle cross the boundary.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libproqa_hip.so")
+
+PROQA_F16 = 0
+PROQA_F32 = 1
+EMBED_DIM = 128
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_int64 = ctypes.c_int64
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+c_char_p = ctypes.c_char_p
+
+
+class ProqaError(RuntimeError):
+    """A libproqa_hip call returned a negative status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"libproqa_hip error {code}: {message}")
+        self.code = code
+
+
+class SearchStats(ctypes.Structure):
+    _fields_ = [("rounds", ctypes.c_int32), ("fallback_rounds", ctypes.c_int32),
+                ("candidates", ctypes.c_int64), ("filter_ms", c_float), ("total_ms", c_float)]
+
+
+class NpyInfo(ctypes.Structure):
+    _fields_ = [("rows", c_int64), ("cols", c_int64), ("dtype", ctypes.c_int32),
+                ("data_offset", c_int64)]
+
+
+# name -> (restype, argtypes); mirrors include/proqa_hip.h one to one
+SIGNATURES = {
+    "proqa_last_error": (c_char_p, []),
+    "proqa_abi_version": (c_int, []),
+    "proqa_device_info": (c_int, [ctypes.POINTER(c_int), c_char_p, c_size_t]),
+    "proqa_index_create": (c_int, [c_int, c_int64, ctypes.POINTER(c_void_p)]),
+    "proqa_index_add": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "proqa_index_add_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "proqa_index_adopt_device": (c_int, [c_void_p, c_void_p, c_int64]),
+    "proqa_index_ntotal": (c_int, [c_void_p, ctypes.POINTER(c_int64)]),
+    "proqa_index_reset": (c_int, [c_void_p]),
+    "proqa_index_free": (c_int, [c_void_p]),
+    "proqa_index_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "proqa_index_search_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
+                                          c_void_p, c_void_p, c_void_p]),
+    "proqa_index_last_stats": (c_int, [c_void_p, ctypes.POINTER(SearchStats)]),
+    "proqa_index_set_profiling": (c_int, [c_void_p, c_int]),
+    "proqa_index_configure": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
+                                        c_void_p, c_void_p]),
+    "proqa_embed_layernorm_f16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                          c_void_p, c_void_p]),
+    "proqa_attention_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "proqa_bias_gelu_f16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "proqa_bias_residual_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_float, c_int64, c_int, c_void_p, c_void_p]),
+    "proqa_pool_project_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int, c_void_p]),
+    "proqa_npy_stat": (c_int, [c_char_p, ctypes.POINTER(NpyInfo)]),
+    "proqa_npy_read_rows": (c_int, [c_char_p, c_int64, c_int64, c_void_p, c_size_t]),
+    "proqa_npy_write": (c_int, [c_char_p, c_void_p, c_int64, c_int64, c_int]),
+    "proqa_npy_create": (c_int, [c_char_p, c_int64, c_int64, c_int]),
+    "proqa_npy_write_rows": (c_int, [c_char_p, c_int64, c_int64, c_void_p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _promote_hip_runtime():
+    """Make ONE HIP runtime's symbols global before libproqa_hip.so is opened.
+
+    libproqa_hip.so carries no DT_NEEDED on libamdhip64 (see proqa_amd/build.py).  When torch is
+    importable its bundled runtime is the one that owns every tensor we are handed, so that copy
+    is promoted; otherwise the system ROCm runtime is used.
+    """
+    candidates = []
+    try:
+        import torch  # noqa: F401  (loads its libamdhip64.so)
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    candidates += ["libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"]
+    errors = []
+    for cand in candidates:
+        if os.path.isabs(cand) and not os.path.exists(cand):
+            continue
+        try:
+            return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError as e:  # pragma: no cover - depends on the machine
+            errors.append(f"{cand}: {e}")
+    raise RuntimeError("no HIP runtime (libamdhip64.so) could be loaded: " + "; ".join(errors))
+
+
+def load():
+    """Return the bound library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m proqa_amd.build` "
+                "(or __graft_entry__.build()); proqa_amd has no CPU fallback")
+        _promote_hip_runtime()
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI drifted
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.proqa_abi_version() != 1:
+            raise RuntimeError("libproqa_hip.so ABI version mismatch; rebuild it")
+        _lib = lib
+        return lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().proqa_last_error()
+        raise ProqaError(status, msg.decode("utf-8", "replace") if msg else "")
+    return status
+
+
+def current_stream_ptr():
+    """hipStream_t of torch's current stream on the current device, as an int."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_info():
+    lib = load()
+    n = c_int(0)
+    buf = ctypes.create_string_buffer(256)
+    check(lib.proqa_device_info(ctypes.byref(n), buf, 256))
+    return n.value, buf.value.decode()
+
+
+def require_gpu():
+    """Raise unless a gfx950 device is visible; called by every product entry point."""
+    n, arch = device_info()
+    if not arch.startswith("gfx950"):
+        raise RuntimeError(f"proqa_amd targets MI355X (gfx950); found '{arch}'")
+    return n, arch

@@ -1,0 +1,67 @@
+"""Build libproqa_hip.so in-tree with hipcc for gfx950.
+
+The library is linked WITHOUT a DT_NEEDED entry on libamdhip64: the process that loads it
+decides which HIP runtime is live (PyTorch-ROCm ships its own copy; loading a second one next
+to it would give the kernels a different runtime than the tensors they are handed).
+proqa_amd._lib makes the runtime's symbols global before dlopen()ing the library.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libproqa_hip.so")
+ARCH = "gfx950"
+
+SOURCES = [
+    "common.cpp",
+    "npy_io.cpp",
+    "mips_index.cpp",
+    "mips_kernels.hip",
+    "encoder_kernels.hip",
+    "attention_kernel.hip",
+]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libproqa_hip.so cannot be built")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every source for gfx950 and link csrc/libproqa_hip.so. Returns its path."""
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "proqa_hip.h"))
+    objs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers):
+            cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+                   "-Wall", "-Wno-unused-function", "-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True)
+    if force or _stale(LIB_PATH, objs):
+        cmd = ["g++", "-shared", "-o", LIB_PATH] + objs + ["-Wl,--no-as-needed", "-lpthread", "-lm"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,172 @@
+// Fused BERT self-attention for one layer (proqa_attention_f16 in proqa_hip.h):
+//   ctx[b, q, h*64:(h+1)*64] = softmax(Q K^T / 8 + key_mask) V      (head_dim 64)
+// Replaces BertSelfAttention inside BertForRetriever.get_embed
+// (/root/reference/retrieval/retriever.py:37,41 -> transformers BertModel); the additive key
+// mask comes from the right-padding of em_collate (retrieval/datasets.py:29-45,298-305).
+//
+// One 256-thread workgroup per (sequence, head).  K and V of that head (S x 64 fp16 each) are
+// staged once in LDS with full-line coalesced loads; each wave then owns 32-query blocks.
+// Both products run on v_mfma_f32_32x32x16_f16 in the "swapped" orientation so that every lane
+// owns ONE query column of the accumulator:
+//   S^T = K Q^T   : lane (q = lane&31) holds 16 keys of its query per 32-key tile, so the row max
+//                   / row sum of the online softmax are lane-local (+ one xor-32 shuffle);
+//   O^T = V^T P^T : P^T is consumed straight from those registers as the MFMA B operand, and the
+//                   rescale by exp(m_old - m_new) and the final 1/l are per-lane scalars.
+// The k-order of an MFMA step is free as long as both operands agree, so V^T fragments gather
+// exactly the keys a lane's P registers hold (rows {0-3, 8-11} + 4*half + 16*step of the tile).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace proqa {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kHeadDim = 64;
+constexpr int kKStride = kHeadDim + 8;  // fp16 elements per K row in LDS (144 B: conflict-free b128)
+constexpr int kVStride = kHeadDim;      // V is read 2 bytes at a time: 128 B rows are conflict-free
+
+__global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict__ qkv,
+                                                     const int* __restrict__ seq_lens, int seq_len,
+                                                     int n_heads, _Float16* __restrict__ ctx) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  const int s_pad = (seq_len + 31) & ~31;
+  _Float16* k_lds = smem;                       // [s_pad][kKStride]
+  _Float16* v_lds = smem + s_pad * kKStride;    // [s_pad][kVStride]
+
+  const int b = blockIdx.x / n_heads;
+  const int head = blockIdx.x - b * n_heads;
+  const int hidden = n_heads * kHeadDim;
+  const long long row_stride = 3ll * hidden;
+  const _Float16* base = qkv + (long long)b * seq_len * row_stride + head * kHeadDim;
+  int len = seq_lens ? seq_lens[b] : seq_len;
+  len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
+  const int n_ktiles = (len + 31) >> 5;
+
+  const int tid = threadIdx.x;
+  // stage K and V rows [0, n_ktiles*32): 8 lanes cover one 128-byte row
+  for (int i = tid; i < n_ktiles * 32 * 8; i += 256) {
+    const int row = i >> 3, c = i & 7;
+    f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+    if (row < seq_len) {
+      const _Float16* src = base + row * row_stride + c * 8;
+      kv = *(const f16x8*)(src + hidden);
+      vv = *(const f16x8*)(src + 2 * hidden);
+    }
+    *(f16x8*)(k_lds + row * kKStride + c * 8) = kv;
+    *(f16x8*)(v_lds + row * kVStride + c * 8) = vv;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int half = lane >> 5;
+  const int n_qblocks = s_pad >> 5;
+
+  for (int qb = wave; qb < n_qblocks; qb += 4) {
+    const int q = qb * 32 + li;
+    // Q fragments (MFMA B operand): 16-byte pieces 2j+half of the lane's query row
+    f16x8 qf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      qf[j] = q < seq_len ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) : z;
+    }
+    float m = -__builtin_inff();
+    float l = 0.f;
+    f32x16 o0 = {0}, o1 = {0};
+
+    for (int kt = 0; kt < n_ktiles; ++kt) {
+      // S^T tile: rows = 32 keys, columns = 32 queries
+      f32x16 st = {0};
+      const _Float16* krow = k_lds + (kt * 32 + li) * kKStride + half * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x8 kf = *(const f16x8*)(krow + j * 16);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j], st, 0, 0, 0);
+      }
+      float mt = -__builtin_inff();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        st[r] = key < len ? st[r] * 0.125f : -__builtin_inff();
+        mt = __builtin_fmaxf(mt, st[r]);
+      }
+      mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = __builtin_fmaxf(m, mt);  // finite: key 0 is always valid
+      const float alpha = __expf(m - m_new);
+      float rs = 0.f;
+      f16x8 pf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(st[r] - m_new);
+        rs += p;
+        pf[r >> 3][r & 7] = (_Float16)p;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
+      // O^T += V^T P^T : A operand = V^T gathered for the keys this lane's P registers hold
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        f16x8 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = kt * 32 + 16 * jj + (e & 3) + 8 * (e >> 2) + 4 * half;
+          v0[e] = v_lds[key * kVStride + li];
+          v1[e] = v_lds[key * kVStride + 32 + li];
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[jj], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[jj], o1, 0, 0, 0);
+      }
+    }
+
+    if (q < seq_len) {
+      const float inv = 1.0f / l;
+      _Float16* dst = ctx + ((long long)b * seq_len + q) * hidden + head * kHeadDim;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[e] = (_Float16)(o0[g * 4 + e] * inv);
+          c[e] = (_Float16)(o1[g * 4 + e] * inv);
+        }
+        *(f16x4*)(dst + g * 8 + 4 * half) = a;
+        *(f16x4*)(dst + 32 + g * 8 + 4 * half) = c;
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace proqa
+
+using namespace proqa;
+
+extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
+                                   int n_heads, void* ctx_out, void* stream) {
+  if (!qkv || !ctx_out) return fail(PROQA_EINVAL, "attention: NULL argument");
+  if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention: bad sizes");
+  const int s_pad = (seq_len + 31) & ~31;
+  const size_t lds = (size_t)s_pad * (kKStride + kVStride) * sizeof(_Float16);
+  if (lds > 160 * 1024) return fail(PROQA_EINVAL, "attention: seq_len=%d needs %zu B of LDS (> 160 KiB)", seq_len, lds);
+  if (batch == 0) return PROQA_OK;
+  if (lds > 64 * 1024) {
+    PROQA_HIP(hipFuncSetAttribute((const void*)attention_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(attention_fwd, dim3((unsigned)batch * n_heads), dim3(256), lds, as_stream(stream),
+                     (const _Float16*)qkv, (const int*)seq_lens_dev, seq_len, n_heads, (_Float16*)ctx_out);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}

@@ -1,0 +1,47 @@
+// Shared host-side helpers for libproqa_hip.so (error plumbing, HIP checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/proqa_hip.h"
+
+namespace proqa {
+
+// thread-local last-error message, surfaced through proqa_last_error()
+char* error_buffer();
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+inline int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  return fail(PROQA_EHIP, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+}
+
+#define PROQA_HIP(call)                                                          \
+  do {                                                                           \
+    hipError_t _e = (call);                                                      \
+    if (_e != hipSuccess) return ::proqa::hip_fail(_e, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define PROQA_LAUNCH_CHECK()                                                              \
+  do {                                                                                    \
+    hipError_t _e = hipGetLastError();                                                    \
+    if (_e != hipSuccess) return ::proqa::hip_fail(_e, "kernel launch", __FILE__, __LINE__); \
+  } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T>
+inline T ceil_div(T a, T b) {
+  return (a + b - 1) / b;
+}
+template <typename T>
+inline T round_up(T a, T b) {
+  return ceil_div(a, b) * b;
+}
+
+// number of compute units of the current device (256 on MI355X); cached
+int device_cu_count();
+
+}  // namespace proqa

@@ -1,0 +1,282 @@
+// Non-GEMM kernels of the BERT tower behind BertForRetriever.get_embed
+// (/root/reference/retrieval/retriever.py:33-43; the arithmetic is transformers' BertModel:
+// embeddings -> 12 x {self-attention, output dense+LN, FFN} -> pooler, then proj_{q,c}).
+// The dense 768x768 / 768x3072 projections stay on PyTorch-ROCm (hipBLASLt); everything
+// between them is here.  Activations are fp16 in HBM, statistics fp32.
+//
+// All row-wise kernels use one wave64 per row with 16-byte (8 x fp16) accesses per lane: at
+// hidden=768 a row is 96 such chunks, so lanes 0-31 hold two chunks and lanes 32-63 one; the
+// row never leaves registers between the load and the normalised store.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace proqa {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kMaxChunksPerLane = 2;  // hidden <= 64 lanes * 2 chunks * 8 = 1024
+constexpr int kRowsPerBlock = 4;      // 4 waves per 256-thread block
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// LayerNorm over the register-resident row (two-pass in registers: mean, then variance of the
+// deviations — matches torch.nn.LayerNorm's biased variance) and 16-byte stores.
+__device__ __forceinline__ void layernorm_store(float (&x)[kMaxChunksPerLane][8], int lane, int n_chunks,
+                                                int hidden, const _Float16* __restrict__ gamma,
+                                                const _Float16* __restrict__ beta, float eps,
+                                                _Float16* __restrict__ out_row) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunksPerLane; ++c)
+    if (lane + 64 * c < n_chunks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += x[c][i];
+    }
+  const float mean = wave_sum(s) / (float)hidden;
+  float v = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunksPerLane; ++c)
+    if (lane + 64 * c < n_chunks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = x[c][i] - mean;
+        v += d * d;
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(v) / (float)hidden + eps);
+#pragma unroll
+  for (int c = 0; c < kMaxChunksPerLane; ++c) {
+    const int chunk = lane + 64 * c;
+    if (chunk < n_chunks) {
+      const f16x8 g = *(const f16x8*)(gamma + chunk * 8);
+      const f16x8 b = *(const f16x8*)(beta + chunk * 8);
+      f16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = (_Float16)((x[c][i] - mean) * rstd * (float)g[i] + (float)b[i]);
+      *(f16x8*)(out_row + chunk * 8) = o;
+    }
+  }
+}
+
+// BertEmbeddings: LN(word[id] + pos[s] + type[0])
+__global__ __launch_bounds__(256) void embed_layernorm(const long long* __restrict__ ids, long long n_tokens,
+                                                       int seq_len, int hidden,
+                                                       const _Float16* __restrict__ word, long long vocab,
+                                                       const _Float16* __restrict__ pos,
+                                                       const _Float16* __restrict__ type0,
+                                                       const _Float16* __restrict__ gamma,
+                                                       const _Float16* __restrict__ beta, float eps,
+                                                       _Float16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long tok = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (tok >= n_tokens) return;
+  long long id = ids[tok];
+  if (id < 0 || id >= vocab) id = 0;  // never index outside the table
+  const int s = (int)(tok % seq_len);
+  const int n_chunks = hidden >> 3;
+  const _Float16* w = word + id * hidden;
+  const _Float16* p = pos + (long long)s * hidden;
+  float x[kMaxChunksPerLane][8];
+#pragma unroll
+  for (int c = 0; c < kMaxChunksPerLane; ++c) {
+    const int chunk = lane + 64 * c;
+    if (chunk < n_chunks) {
+      const f16x8 a = *(const f16x8*)(w + chunk * 8);
+      const f16x8 b = *(const f16x8*)(p + chunk * 8);
+      const f16x8 t = *(const f16x8*)(type0 + chunk * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[c][i] = (float)a[i] + (float)b[i] + (float)t[i];
+    }
+  }
+  layernorm_store(x, lane, n_chunks, hidden, gamma, beta, eps, out + tok * hidden);
+}
+
+// BertSelfOutput / BertOutput: LN(dense_out + bias + residual)
+__global__ __launch_bounds__(256) void bias_residual_layernorm(const _Float16* __restrict__ xin,
+                                                               const _Float16* __restrict__ bias,
+                                                               const _Float16* __restrict__ residual,
+                                                               const _Float16* __restrict__ gamma,
+                                                               const _Float16* __restrict__ beta, float eps,
+                                                               long long rows, int cols,
+                                                               _Float16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int n_chunks = cols >> 3;
+  const _Float16* xr = xin + row * cols;
+  const _Float16* rr = residual + row * cols;
+  float x[kMaxChunksPerLane][8];
+#pragma unroll
+  for (int c = 0; c < kMaxChunksPerLane; ++c) {
+    const int chunk = lane + 64 * c;
+    if (chunk < n_chunks) {
+      const f16x8 a = *(const f16x8*)(xr + chunk * 8);
+      const f16x8 r = *(const f16x8*)(rr + chunk * 8);
+      const f16x8 b = *(const f16x8*)(bias + chunk * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[c][i] = (float)a[i] + (float)b[i] + (float)r[i];
+    }
+  }
+  layernorm_store(x, lane, n_chunks, cols, gamma, beta, eps, out + row * cols);
+}
+
+// BertIntermediate: x = gelu(x + bias), exact erf form (hidden_act = 'gelu')
+__global__ __launch_bounds__(256) void bias_gelu(_Float16* __restrict__ x, const _Float16* __restrict__ bias,
+                                                 long long n_chunks_total, int chunks_per_row) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks_total; c += stride) {
+    const int col_chunk = (int)(c % chunks_per_row);
+    f16x8 v = *(f16x8*)(x + c * 8);
+    const f16x8 b = *(const f16x8*)(bias + col_chunk * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t = (float)v[i] + (float)b[i];
+      v[i] = (_Float16)(0.5f * t * (1.0f + erff(t * 0.70710678118654752440f)));
+    }
+    *(f16x8*)(x + c * 8) = v;
+  }
+}
+
+// BertPooler + projection head: out[b] = Wproj . tanh(Wp . h[b,0] + bp) + bproj
+// One 256-thread block per kPoolRows sequences; each wave owns output features round-robin and
+// the 64 lanes split the 768-long dot product (16-byte weight loads, shuffle reduction).
+constexpr int kPoolRows = 4;
+
+__global__ __launch_bounds__(256) void pool_project(const _Float16* __restrict__ h, int batch, int seq_len,
+                                                    int hidden, const _Float16* __restrict__ w_pool,
+                                                    const _Float16* __restrict__ b_pool,
+                                                    const _Float16* __restrict__ w_proj,
+                                                    const _Float16* __restrict__ b_proj, void* __restrict__ out,
+                                                    int out_dtype, int out_dim) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [kPoolRows][hidden] x2
+  float* xs = smem;                          // CLS rows
+  float* ps = smem + kPoolRows * hidden;     // pooled rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * kPoolRows;
+  for (int i = tid; i < kPoolRows * hidden; i += 256) {
+    const int r = i / hidden, c = i - r * hidden;
+    const int b = b0 + r;
+    xs[i] = b < batch ? (float)h[((long long)b * seq_len) * hidden + c] : 0.f;
+  }
+  __syncthreads();
+  const int n_chunks = hidden >> 3;
+  for (int o = wave; o < hidden; o += 4) {
+    float acc[kPoolRows] = {0.f, 0.f, 0.f, 0.f};
+    for (int chunk = lane; chunk < n_chunks; chunk += 64) {
+      const f16x8 w = *(const f16x8*)(w_pool + (long long)o * hidden + chunk * 8);
+#pragma unroll
+      for (int r = 0; r < kPoolRows; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r] += (float)w[i] * xs[r * hidden + chunk * 8 + i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kPoolRows; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane < kPoolRows) ps[lane * hidden + o] = tanhf(acc[lane] + (float)b_pool[o]);
+  }
+  __syncthreads();
+  for (int o = wave; o < out_dim; o += 4) {
+    float acc[kPoolRows] = {0.f, 0.f, 0.f, 0.f};
+    for (int chunk = lane; chunk < n_chunks; chunk += 64) {
+      const f16x8 w = *(const f16x8*)(w_proj + (long long)o * hidden + chunk * 8);
+#pragma unroll
+      for (int r = 0; r < kPoolRows; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r] += (float)w[i] * ps[r * hidden + chunk * 8 + i];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kPoolRows; ++r) acc[r] = wave_sum(acc[r]);
+    if (lane < kPoolRows && b0 + lane < batch) {
+      const float v = acc[lane] + (float)b_proj[o];
+      const long long dst = (long long)(b0 + lane) * out_dim + o;
+      if (out_dtype == PROQA_F16)
+        ((_Float16*)out)[dst] = (_Float16)v;
+      else
+        ((float*)out)[dst] = v;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace proqa
+
+using namespace proqa;
+
+extern "C" {
+
+int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_len, int hidden,
+                              const void* word_emb, int64_t vocab, const void* pos_emb, const void* type_emb,
+                              const void* ln_gamma, const void* ln_beta, float eps, void* out, void* stream) {
+  if (!ids_dev || !word_emb || !pos_emb || !type_emb || !ln_gamma || !ln_beta || !out)
+    return fail(PROQA_EINVAL, "embed_layernorm: NULL argument");
+  if (n_tokens < 0 || seq_len <= 0 || vocab <= 0) return fail(PROQA_EINVAL, "embed_layernorm: bad sizes");
+  if (hidden <= 0 || hidden % 8 || hidden > 64 * kMaxChunksPerLane * 8)
+    return fail(PROQA_EINVAL, "embed_layernorm: hidden=%d must be a multiple of 8 and <= %d", hidden,
+                64 * kMaxChunksPerLane * 8);
+  if (n_tokens == 0) return PROQA_OK;
+  const unsigned grid = (unsigned)ceil_div<int64_t>(n_tokens, kRowsPerBlock);
+  hipLaunchKernelGGL(embed_layernorm, dim3(grid), dim3(256), 0, as_stream(stream), (const long long*)ids_dev,
+                     (long long)n_tokens, seq_len, hidden, (const _Float16*)word_emb, (long long)vocab,
+                     (const _Float16*)pos_emb, (const _Float16*)type_emb, (const _Float16*)ln_gamma,
+                     (const _Float16*)ln_beta, eps, (_Float16*)out);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+int proqa_bias_residual_layernorm_f16(const void* x, const void* bias, const void* residual, const void* gamma,
+                                      const void* beta, float eps, int64_t rows, int cols, void* out,
+                                      void* stream) {
+  if (!x || !bias || !residual || !gamma || !beta || !out)
+    return fail(PROQA_EINVAL, "bias_residual_layernorm: NULL argument");
+  if (rows < 0 || cols <= 0 || cols % 8 || cols > 64 * kMaxChunksPerLane * 8)
+    return fail(PROQA_EINVAL, "bias_residual_layernorm: cols=%d must be a multiple of 8 and <= %d", cols,
+                64 * kMaxChunksPerLane * 8);
+  if (rows == 0) return PROQA_OK;
+  const unsigned grid = (unsigned)ceil_div<int64_t>(rows, kRowsPerBlock);
+  hipLaunchKernelGGL(bias_residual_layernorm, dim3(grid), dim3(256), 0, as_stream(stream), (const _Float16*)x,
+                     (const _Float16*)bias, (const _Float16*)residual, (const _Float16*)gamma,
+                     (const _Float16*)beta, eps, (long long)rows, cols, (_Float16*)out);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+int proqa_bias_gelu_f16(void* x, const void* bias, int64_t rows, int cols, void* stream) {
+  if (!x || !bias) return fail(PROQA_EINVAL, "bias_gelu: NULL argument");
+  if (rows < 0 || cols <= 0 || cols % 8) return fail(PROQA_EINVAL, "bias_gelu: cols=%d must be a multiple of 8", cols);
+  if (rows == 0) return PROQA_OK;
+  const long long n_chunks = rows * (long long)(cols / 8);
+  const long long want = ceil_div<long long>(n_chunks, 256);
+  const unsigned grid = (unsigned)std::min<long long>(want, (long long)device_cu_count() * 8);
+  hipLaunchKernelGGL(bias_gelu, dim3(grid), dim3(256), 0, as_stream(stream), (_Float16*)x, (const _Float16*)bias,
+                     n_chunks, cols / 8);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+int proqa_pool_project_f16(const void* h, int batch, int seq_len, int hidden, const void* w_pool,
+                           const void* b_pool, const void* w_proj, const void* b_proj, void* out, int out_dtype,
+                           void* stream) {
+  if (!h || !w_pool || !b_pool || !w_proj || !b_proj || !out) return fail(PROQA_EINVAL, "pool_project: NULL argument");
+  if (batch < 0 || seq_len <= 0 || hidden <= 0 || hidden % 8) return fail(PROQA_EINVAL, "pool_project: bad sizes");
+  if (out_dtype != PROQA_F16 && out_dtype != PROQA_F32) return fail(PROQA_EINVAL, "pool_project: bad out dtype");
+  const size_t lds = (size_t)2 * kPoolRows * hidden * sizeof(float);
+  if (lds > 64 * 1024) return fail(PROQA_EINVAL, "pool_project: hidden=%d too large", hidden);
+  if (batch == 0) return PROQA_OK;
+  const unsigned grid = (unsigned)ceil_div<int>(batch, kPoolRows);
+  hipLaunchKernelGGL(pool_project, dim3(grid), dim3(256), lds, as_stream(stream), (const _Float16*)h, batch,
+                     seq_len, hidden, (const _Float16*)w_pool, (const _Float16*)b_pool, (const _Float16*)w_proj,
+                     (const _Float16*)b_proj, out, out_dtype, PROQA_EMBED_DIM);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,464 @@
+// Host orchestration of the exact inner-product index (proqa_index_* in proqa_hip.h).
+//
+// Replaces faiss.IndexFlatIP at /root/reference/retrieval/eval_retrieval.py:102-104:
+//   add()    -> rows live in HBM as fp16 [N,128] (the --fp16 .npy format, get_embed.py:139)
+//   search() -> rounds of {mips_filter_f16 over a corpus slab, topk_merge per query}; slabs grow
+//               geometrically so the per-query threshold (running k-th best score) tightens
+//               fast and the big late slabs emit only a handful of candidates per query.
+//   If a round overflows a query's candidate list (adversarially ordered corpus), its slab is
+//   re-scanned on the overflow-safe path: sub-slabs of <= capacity rows, inclusive threshold,
+//   duplicate removal in the merge.  The result is exact either way.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+#include "mips_kernels.h"
+
+namespace proqa {
+
+struct Slab {
+  long long r0, r1;
+};
+
+}  // namespace proqa
+
+struct proqa_index {
+  int device = 0;
+  // corpus
+  char* xb = nullptr;       // fp16 rows
+  bool owns_xb = true;
+  int64_t n = 0;
+  int64_t capacity = 0;
+  // search workspace (grown on demand)
+  int64_t ws_nq_pad = 0;
+  int ws_k = 0;
+  unsigned ws_cap = 0;
+  void* xq_pad = nullptr;
+  float* tau = nullptr;
+  unsigned* cand_cnt = nullptr;
+  unsigned* run_n = nullptr;
+  uint2* cand = nullptr;
+  unsigned long long* run_keys = nullptr;
+  unsigned* overflow = nullptr;            // [kMaxRounds] device
+  unsigned* overflow_host = nullptr;       // pinned mirror
+  unsigned long long* stat_dev = nullptr;  // candidate counter
+  unsigned long long* stat_host = nullptr; // pinned
+  void* stage_dev = nullptr;               // staging for host-pointer add/search
+  size_t stage_bytes = 0;
+  void* stage_pinned = nullptr;
+  size_t stage_pinned_bytes = 0;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipEvent_t ev_filter[2 * 64] = {};       // per-round brackets, created when profiling is on
+  bool profile = false;
+  // tuning
+  unsigned cand_capacity = 2048;
+  int first_slab_rows = 256;
+  int growth = 4;
+  proqa_search_stats stats = {};
+};
+
+namespace proqa {
+namespace {
+
+constexpr int kMaxRounds = 64;
+
+int ensure_device(proqa_index* idx) {
+  int dev = 0;
+  PROQA_HIP(hipGetDevice(&dev));
+  if (dev != idx->device) PROQA_HIP(hipSetDevice(idx->device));
+  return PROQA_OK;
+}
+
+int reserve_rows(proqa_index* idx, int64_t rows) {
+  if (rows <= idx->capacity) return PROQA_OK;
+  if (!idx->owns_xb) return fail(PROQA_EINVAL, "index adopted caller memory; cannot grow it");
+  int64_t cap = std::max<int64_t>(rows, idx->capacity + idx->capacity / 2);
+  cap = round_up<int64_t>(cap, kStageRows);
+  char* p = nullptr;
+  hipError_t e = hipMalloc((void**)&p, (size_t)cap * kDim * 2);
+  if (e != hipSuccess) return fail(PROQA_ENOMEM, "hipMalloc of %lld index rows failed: %s", (long long)cap,
+                                   hipGetErrorString(e));
+  if (idx->n > 0) PROQA_HIP(hipMemcpy(p, idx->xb, (size_t)idx->n * kDim * 2, hipMemcpyDeviceToDevice));
+  if (idx->xb) PROQA_HIP(hipFree(idx->xb));
+  idx->xb = p;
+  idx->capacity = cap;
+  return PROQA_OK;
+}
+
+int ensure_stage(proqa_index* idx, size_t bytes) {
+  if (bytes > idx->stage_bytes) {
+    if (idx->stage_dev) PROQA_HIP(hipFree(idx->stage_dev));
+    idx->stage_dev = nullptr;
+    idx->stage_bytes = 0;
+    hipError_t e = hipMalloc(&idx->stage_dev, bytes);
+    if (e != hipSuccess) return fail(PROQA_ENOMEM, "hipMalloc staging %zu B: %s", bytes, hipGetErrorString(e));
+    idx->stage_bytes = bytes;
+  }
+  return PROQA_OK;
+}
+
+void free_workspace(proqa_index* idx) {
+  void* ptrs[] = {idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n, idx->cand, idx->run_keys};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  idx->xq_pad = nullptr;
+  idx->tau = nullptr;
+  idx->cand_cnt = nullptr;
+  idx->run_n = nullptr;
+  idx->cand = nullptr;
+  idx->run_keys = nullptr;
+  idx->ws_nq_pad = 0;
+  idx->ws_k = 0;
+  idx->ws_cap = 0;
+}
+
+int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k, unsigned cap) {
+  if (nq_pad <= idx->ws_nq_pad && k <= idx->ws_k && cap == idx->ws_cap) return PROQA_OK;
+  free_workspace(idx);
+  const int64_t q = std::max(nq_pad, idx->ws_nq_pad);
+  PROQA_HIP(hipMalloc(&idx->xq_pad, (size_t)q * kDim * 2));
+  PROQA_HIP(hipMalloc((void**)&idx->tau, (size_t)q * sizeof(float)));
+  PROQA_HIP(hipMalloc((void**)&idx->cand_cnt, (size_t)q * sizeof(unsigned)));
+  PROQA_HIP(hipMalloc((void**)&idx->run_n, (size_t)q * sizeof(unsigned)));
+  PROQA_HIP(hipMalloc((void**)&idx->cand, (size_t)q * cap * sizeof(uint2)));
+  PROQA_HIP(hipMalloc((void**)&idx->run_keys, (size_t)q * k * sizeof(unsigned long long)));
+  idx->ws_nq_pad = q;
+  idx->ws_k = k;
+  idx->ws_cap = cap;
+  return PROQA_OK;
+}
+
+// geometric slab schedule over [0, n)
+std::vector<Slab> plan_slabs(long long n, int first, int growth) {
+  std::vector<Slab> out;
+  long long seen = 0;
+  long long next = std::min<long long>(n, round_up<long long>(first, kStageRows));
+  while (seen < n) {
+    long long r1 = std::min(n, seen + next);
+    // do not leave a tiny tail for an extra round
+    if (n - r1 < next / 4) r1 = n;
+    out.push_back({seen, r1});
+    seen = r1;
+    next = round_up<long long>(seen * growth, kStageRows);
+  }
+  return out;
+}
+
+struct LaunchGeom {
+  int rows_per_chunk;
+  unsigned grid;
+};
+
+LaunchGeom geometry(long long slab_rows, unsigned n_qtiles) {
+  const int cus = device_cu_count();
+  // one workgroup per CU: target_chunks * n_qtiles ~= #CUs, chunks a multiple of 8 (XCD map)
+  long long target = std::max<long long>(8, (cus / (long long)n_qtiles) / 8 * 8);
+  long long rpc = round_up<long long>(ceil_div<long long>(slab_rows, target), kStageRows);
+  long long chunks = round_up<long long>(ceil_div<long long>(slab_rows, rpc), 8);
+  return {(int)rpc, (unsigned)(chunks * n_qtiles)};
+}
+
+int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
+              bool inclusive, unsigned* overflow_word, hipStream_t st, hipEvent_t f0, hipEvent_t f1) {
+  FilterArgs fa;
+  fa.xq = idx->xq_pad;
+  fa.xb = idx->xb;
+  fa.slab_row0 = slab.r0;
+  fa.slab_row1 = slab.r1;
+  const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles);
+  fa.rows_per_chunk = g.rows_per_chunk;
+  fa.n_qtiles = n_qtiles;
+  fa.tau = idx->tau;
+  fa.cand_cnt = idx->cand_cnt;
+  fa.cand = idx->cand;
+  fa.cap = idx->ws_cap;
+  fa.overflow = overflow_word;
+  if (f0) PROQA_HIP(hipEventRecord(f0, st));
+  PROQA_HIP(launch_filter(fa, qw, inclusive, g.grid, st));
+  if (f1) PROQA_HIP(hipEventRecord(f1, st));
+
+  MergeArgs ma;
+  ma.cand = idx->cand;
+  ma.cand_cnt = idx->cand_cnt;
+  ma.cap = idx->ws_cap;
+  ma.run_keys = idx->run_keys;
+  ma.run_n = idx->run_n;
+  ma.tau = idx->tau;
+  ma.k = k;
+  ma.dedupe = inclusive ? 1 : 0;
+  ma.stat_candidates = idx->stat_dev;
+  PROQA_HIP(launch_merge(ma, nq_pad, st));
+  return PROQA_OK;
+}
+
+int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
+                  float* D_dev, int64_t* I_dev, hipStream_t st) {
+  if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
+  if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "search: bad dtype %d", dtype);
+  const unsigned cap = idx->cand_capacity;
+  if ((long long)k + cap > kMaxSortKeys)
+    return fail(PROQA_EINVAL, "search: k=%d + candidate capacity %u exceeds %d (large-k search not built yet)",
+                k, cap, kMaxSortKeys);
+  if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
+  idx->stats = {};
+  if (nq == 0) return PROQA_OK;
+  if (int rc = ensure_device(idx)) return rc;
+
+  // wave tile: 2 query blocks of 32 per wave (512 queries per workgroup) unless the batch is small
+  const int qw = nq > 256 ? 2 : 1;
+  const unsigned tile_q = kFilterWaves * qw * 32;
+  const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
+  const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
+  if (int rc = ensure_workspace(idx, nq_pad, k, cap)) return rc;
+
+  PROQA_HIP(hipEventRecord(idx->ev[0], st));
+  PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
+  PROQA_HIP(hipMemsetAsync(idx->stat_dev, 0, sizeof(unsigned long long), st));
+  PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, nq_pad, idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n, st));
+
+  std::vector<Slab> slabs = plan_slabs(idx->n, idx->first_slab_rows, idx->growth);
+  if ((int)slabs.size() > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
+  for (size_t r = 0; r < slabs.size(); ++r) {
+    hipEvent_t f0 = idx->profile ? idx->ev_filter[2 * r] : nullptr;
+    hipEvent_t f1 = idx->profile ? idx->ev_filter[2 * r + 1] : nullptr;
+    if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, k, false, idx->overflow + r, st, f0, f1))
+      return rc;
+  }
+  PROQA_HIP(hipMemcpyAsync(idx->overflow_host, idx->overflow, kMaxRounds * sizeof(unsigned),
+                           hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipStreamSynchronize(st));
+
+  int fallback = 0;
+  for (size_t r = 0; r < slabs.size(); ++r) {
+    if (!idx->overflow_host[r]) continue;
+    // overflow-safe re-scan: sub-slabs can never overflow (rows <= capacity)
+    const long long step = (long long)(cap / kStageRows) * kStageRows;
+    for (long long r0 = slabs[r].r0; r0 < slabs[r].r1; r0 += step) {
+      Slab sub{r0, std::min(slabs[r].r1, r0 + step)};
+      if (int rc = run_round(idx, sub, qw, n_qtiles, (unsigned)nq_pad, k, true, idx->overflow + kMaxRounds - 1,
+                             st, nullptr, nullptr))
+        return rc;
+      ++fallback;
+    }
+  }
+
+  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, idx_offset, D_dev, (long long*)I_dev, st));
+  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipEventRecord(idx->ev[1], st));
+  PROQA_HIP(hipStreamSynchronize(st));
+
+  idx->stats.rounds = (int)slabs.size();
+  idx->stats.fallback_rounds = fallback;
+  idx->stats.candidates = (int64_t)*idx->stat_host;
+  (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
+  if (idx->profile) {
+    float sum = 0.f;
+    for (size_t r = 0; r < slabs.size(); ++r) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, idx->ev_filter[2 * r], idx->ev_filter[2 * r + 1]);
+      sum += ms;
+    }
+    idx->stats.filter_ms = sum;
+  }
+  return PROQA_OK;
+}
+
+}  // namespace
+}  // namespace proqa
+
+using namespace proqa;
+
+extern "C" {
+
+int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out) {
+  if (!out) return fail(PROQA_EINVAL, "index_create: out is NULL");
+  *out = nullptr;
+  if (d != kDim) return fail(PROQA_EINVAL, "index_create: d=%d, only d=128 is supported (ProQA embeds are 128-d)", d);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PROQA_ENOGPU, "index_create: no HIP device visible");
+  proqa_index* idx = new (std::nothrow) proqa_index();
+  if (!idx) return fail(PROQA_ENOMEM, "index_create: out of host memory");
+  PROQA_HIP(hipGetDevice(&idx->device));
+  for (auto& e : idx->ev) PROQA_HIP(hipEventCreate(&e));
+  PROQA_HIP(hipMalloc((void**)&idx->overflow, kMaxRounds * sizeof(unsigned)));
+  PROQA_HIP(hipMalloc((void**)&idx->stat_dev, sizeof(unsigned long long)));
+  PROQA_HIP(hipHostMalloc((void**)&idx->overflow_host, kMaxRounds * sizeof(unsigned), hipHostMallocDefault));
+  PROQA_HIP(hipHostMalloc((void**)&idx->stat_host, sizeof(unsigned long long), hipHostMallocDefault));
+  if (capacity_rows > 0) {
+    if (int rc = reserve_rows(idx, capacity_rows)) {
+      proqa_index_free(idx);
+      return rc;
+    }
+  }
+  *out = idx;
+  return PROQA_OK;
+}
+
+int proqa_index_free(proqa_index* idx) {
+  if (!idx) return PROQA_OK;
+  free_workspace(idx);
+  if (idx->xb && idx->owns_xb) (void)hipFree(idx->xb);
+  if (idx->overflow) (void)hipFree(idx->overflow);
+  if (idx->stat_dev) (void)hipFree(idx->stat_dev);
+  if (idx->overflow_host) (void)hipHostFree(idx->overflow_host);
+  if (idx->stat_host) (void)hipHostFree(idx->stat_host);
+  if (idx->stage_dev) (void)hipFree(idx->stage_dev);
+  if (idx->stage_pinned) (void)hipHostFree(idx->stage_pinned);
+  for (auto& e : idx->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto& e : idx->ev_filter)
+    if (e) (void)hipEventDestroy(e);
+  delete idx;
+  return PROQA_OK;
+}
+
+int proqa_index_reset(proqa_index* idx) {
+  if (!idx) return fail(PROQA_EINVAL, "index_reset: NULL handle");
+  if (!idx->owns_xb) {
+    idx->xb = nullptr;
+    idx->capacity = 0;
+    idx->owns_xb = true;
+  }
+  idx->n = 0;
+  return PROQA_OK;
+}
+
+int proqa_index_ntotal(const proqa_index* idx, int64_t* n) {
+  if (!idx || !n) return fail(PROQA_EINVAL, "index_ntotal: NULL argument");
+  *n = idx->n;
+  return PROQA_OK;
+}
+
+int proqa_index_configure(proqa_index* idx, int cand_capacity, int first_slab_rows, int growth) {
+  if (!idx) return fail(PROQA_EINVAL, "index_configure: NULL handle");
+  if (cand_capacity) {
+    if (cand_capacity < kStageRows || cand_capacity % kStageRows || cand_capacity >= kMaxSortKeys)
+      return fail(PROQA_EINVAL, "index_configure: capacity must be a multiple of %d below %d", kStageRows, kMaxSortKeys);
+    idx->cand_capacity = (unsigned)cand_capacity;
+  }
+  if (first_slab_rows) {
+    if (first_slab_rows < 0) return fail(PROQA_EINVAL, "index_configure: first_slab_rows < 0");
+    idx->first_slab_rows = first_slab_rows;
+  }
+  if (growth) {
+    if (growth < 1) return fail(PROQA_EINVAL, "index_configure: growth < 1");
+    idx->growth = growth;
+  }
+  // the first slab runs with threshold -inf: every row is a candidate
+  idx->first_slab_rows = std::min<int>(idx->first_slab_rows, (int)idx->cand_capacity);
+  return PROQA_OK;
+}
+
+int proqa_index_set_profiling(proqa_index* idx, int enable) {
+  if (!idx) return fail(PROQA_EINVAL, "index_set_profiling: NULL handle");
+  if (enable && !idx->ev_filter[0]) {
+    for (auto& e : idx->ev_filter) PROQA_HIP(hipEventCreate(&e));
+  }
+  idx->profile = enable != 0;
+  return PROQA_OK;
+}
+
+int proqa_index_last_stats(const proqa_index* idx, proqa_search_stats* out) {
+  if (!idx || !out) return fail(PROQA_EINVAL, "index_last_stats: NULL argument");
+  *out = idx->stats;
+  return PROQA_OK;
+}
+
+int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int dtype, void* stream) {
+  if (!idx || (!xb_dev && n > 0) || n < 0) return fail(PROQA_EINVAL, "index_add_device: bad argument");
+  if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_add_device: bad dtype %d", dtype);
+  if (n == 0) return PROQA_OK;
+  if (int rc = ensure_device(idx)) return rc;
+  if (int rc = reserve_rows(idx, idx->n + n)) return rc;
+  hipStream_t st = as_stream(stream);
+  char* dst = idx->xb + (size_t)idx->n * kDim * 2;
+  if (dtype == PROQA_F16) {
+    PROQA_HIP(hipMemcpyAsync(dst, xb_dev, (size_t)n * kDim * 2, hipMemcpyDeviceToDevice, st));
+  } else {
+    PROQA_HIP(launch_convert_f32_to_f16((const float*)xb_dev, dst, n * kDim, st));
+  }
+  PROQA_HIP(hipStreamSynchronize(st));
+  idx->n += n;
+  return PROQA_OK;
+}
+
+int proqa_index_adopt_device(proqa_index* idx, const void* xb_dev_f16, int64_t n) {
+  if (!idx || !xb_dev_f16 || n <= 0) return fail(PROQA_EINVAL, "index_adopt_device: bad argument");
+  if (idx->n != 0) return fail(PROQA_EINVAL, "index_adopt_device: index is not empty");
+  if (idx->xb && idx->owns_xb) PROQA_HIP(hipFree(idx->xb));
+  idx->xb = (char*)const_cast<void*>(xb_dev_f16);
+  idx->owns_xb = false;
+  idx->n = n;
+  idx->capacity = n;
+  return PROQA_OK;
+}
+
+int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype) {
+  if (!idx || (!xb && n > 0) || n < 0) return fail(PROQA_EINVAL, "index_add: bad argument");
+  if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_add: bad dtype %d", dtype);
+  if (n == 0) return PROQA_OK;
+  if (int rc = ensure_device(idx)) return rc;
+  if (int rc = reserve_rows(idx, idx->n + n)) return rc;
+  const size_t esz = dtype == PROQA_F16 ? 2 : 4;
+  // upload in bounded pieces (the source may be an mmap of a multi-GB .npy)
+  const int64_t piece = 1 << 20;  // rows
+  for (int64_t r0 = 0; r0 < n; r0 += piece) {
+    const int64_t m = std::min(piece, n - r0);
+    const char* src = (const char*)xb + (size_t)r0 * kDim * esz;
+    char* dst = idx->xb + (size_t)(idx->n + r0) * kDim * 2;
+    if (dtype == PROQA_F16) {
+      PROQA_HIP(hipMemcpy(dst, src, (size_t)m * kDim * 2, hipMemcpyHostToDevice));
+    } else {
+      if (int rc = ensure_stage(idx, (size_t)piece * kDim * 4)) return rc;
+      PROQA_HIP(hipMemcpy(idx->stage_dev, src, (size_t)m * kDim * 4, hipMemcpyHostToDevice));
+      PROQA_HIP(launch_convert_f32_to_f16((const float*)idx->stage_dev, dst, m * kDim, nullptr));
+      PROQA_HIP(hipDeviceSynchronize());
+    }
+  }
+  idx->n += n;
+  return PROQA_OK;
+}
+
+int proqa_index_search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k,
+                              int64_t idx_offset, float* D_dev, int64_t* I_dev, void* stream) {
+  if (!idx || (nq > 0 && (!xq_dev || !D_dev || !I_dev))) return fail(PROQA_EINVAL, "index_search_device: NULL argument");
+  return search_device(idx, xq_dev, nq, dtype, k, idx_offset, D_dev, I_dev, as_stream(stream));
+}
+
+int proqa_index_search(proqa_index* idx, const void* xq, int64_t nq, int dtype, int k, float* D, int64_t* I) {
+  if (!idx || (nq > 0 && (!xq || !D || !I))) return fail(PROQA_EINVAL, "index_search: NULL argument");
+  if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_search: bad dtype %d", dtype);
+  if (nq == 0) return PROQA_OK;
+  if (k <= 0) return fail(PROQA_EINVAL, "index_search: k=%d", k);
+  if (int rc = ensure_device(idx)) return rc;
+  const size_t esz = dtype == PROQA_F16 ? 2 : 4;
+  const size_t q_bytes = round_up<size_t>((size_t)nq * kDim * esz, 256);
+  const size_t d_bytes = round_up<size_t>((size_t)nq * k * sizeof(float), 256);
+  const size_t i_bytes = (size_t)nq * k * sizeof(int64_t);
+  if (int rc = ensure_stage(idx, q_bytes + d_bytes + i_bytes)) return rc;
+  char* base = (char*)idx->stage_dev;
+  PROQA_HIP(hipMemcpy(base, xq, (size_t)nq * kDim * esz, hipMemcpyHostToDevice));
+  float* D_dev = (float*)(base + q_bytes);
+  int64_t* I_dev = (int64_t*)(base + q_bytes + d_bytes);
+  if (int rc = search_device(idx, base, nq, dtype, k, 0, D_dev, I_dev, nullptr)) return rc;
+  PROQA_HIP(hipMemcpy(D, D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
+  PROQA_HIP(hipMemcpy(I, I_dev, i_bytes, hipMemcpyDeviceToHost));
+  return PROQA_OK;
+}
+
+int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int64_t nq,
+                            int k, float* D_dev, int64_t* I_dev, void* stream) {
+  if (!D_parts_dev || !I_parts_dev || !D_dev || !I_dev || n_parts <= 0 || nq < 0 || k <= 0)
+    return fail(PROQA_EINVAL, "topk_merge_device: bad argument");
+  if ((long long)n_parts * k > kMaxSortKeys)
+    return fail(PROQA_EINVAL, "topk_merge_device: n_parts*k=%lld exceeds %d", (long long)n_parts * k, kMaxSortKeys);
+  PROQA_HIP(launch_merge_lists(D_parts_dev, (const long long*)I_parts_dev, n_parts, nq, k, D_dev,
+                               (long long*)I_dev, as_stream(stream)));
+  return PROQA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+"""Exact inner-product index on MI355X, with the call shape of faiss.IndexFlatIP.
+
+The reference searches with
+
+    index = faiss.IndexFlatIP(d); index.add(xb); D, I = index.search(xq, k)
+
+(/root/reference/retrieval/eval_retrieval.py:102-104, also retrieval/trec_process.py:74-76).
+`IndexFlatIP` here keeps that shape (numpy in, numpy out) over libproqa_hip.so;
+`ShardedIndexFlatIP` row-shards the corpus over the ranks of a torch.distributed group (one
+process per GPU, RCCL over xGMI), all-gathers the per-shard (score, id) lists once and merges
+them on the GPU.  Neither class has a CPU path.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import PROQA_F16, PROQA_F32, EMBED_DIM
+
+
+def _np_dtype_code(arr):
+    if arr.dtype == np.float16:
+        return PROQA_F16
+    if arr.dtype == np.float32:
+        return PROQA_F32
+    raise TypeError(f"embeddings must be float16 or float32, got {arr.dtype}")
+
+
+def _torch_dtype_code(t):
+    import torch
+    if t.dtype == torch.float16:
+        return PROQA_F16
+    if t.dtype == torch.float32:
+        return PROQA_F32
+    raise TypeError(f"embeddings must be float16 or float32, got {t.dtype}")
+
+
+def _as_matrix(x, d, what):
+    x = np.ascontiguousarray(x)
+    if x.ndim != 2 or x.shape[1] != d:
+        raise ValueError(f"{what} must have shape [n, {d}], got {x.shape}")
+    return x
+
+
+class IndexFlatIP:
+    """Brute-force maximum-inner-product index; rows live in HBM as fp16."""
+
+    def __init__(self, d=EMBED_DIM, capacity=0):
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.d = int(d)
+        handle = ctypes.c_void_p()
+        _lib.check(self._lib.proqa_index_create(self.d, int(capacity), ctypes.byref(handle)))
+        self._h = handle
+        self._adopted = None  # keeps an adopted tensor alive
+
+    # -- faiss-shaped API ---------------------------------------------------------------
+    @property
+    def ntotal(self):
+        n = ctypes.c_int64()
+        _lib.check(self._lib.proqa_index_ntotal(self._h, ctypes.byref(n)))
+        return n.value
+
+    def add(self, xb):
+        """Append rows.  numpy [n,d] float16/float32 (host) or a CUDA torch tensor."""
+        if _is_torch(xb):
+            return self.add_device(xb)
+        xb = _as_matrix(xb, self.d, "xb")
+        _lib.check(self._lib.proqa_index_add(self._h, xb.ctypes.data, xb.shape[0], _np_dtype_code(xb)))
+
+    def search(self, xq, k):
+        """(D float32 [nq,k], I int64 [nq,k]); scores descending, ties by ascending row."""
+        if _is_torch(xq):
+            D, I = self.search_device(xq, k)
+            return D.cpu().numpy(), I.cpu().numpy()
+        xq = _as_matrix(xq, self.d, "xq")
+        nq = xq.shape[0]
+        D = np.empty((nq, k), dtype=np.float32)
+        I = np.empty((nq, k), dtype=np.int64)
+        _lib.check(self._lib.proqa_index_search(self._h, xq.ctypes.data, nq, _np_dtype_code(xq), int(k),
+                                                D.ctypes.data, I.ctypes.data))
+        return D, I
+
+    def reset(self):
+        _lib.check(self._lib.proqa_index_reset(self._h))
+        self._adopted = None
+
+    # -- device-resident variants -------------------------------------------------------
+    def add_device(self, xb):
+        import torch
+        if not xb.is_cuda:
+            raise ValueError("add_device expects a CUDA tensor")
+        xb = xb.contiguous()
+        if xb.dim() != 2 or xb.shape[1] != self.d:
+            raise ValueError(f"xb must have shape [n, {self.d}], got {tuple(xb.shape)}")
+        with torch.cuda.device(xb.device):
+            _lib.check(self._lib.proqa_index_add_device(self._h, xb.data_ptr(), xb.shape[0], _torch_dtype_code(xb),
+                                                        _lib.current_stream_ptr()))
+
+    def adopt_device(self, xb):
+        """Search caller-owned fp16 rows in place (no copy); the tensor is kept alive here."""
+        import torch
+        if not (xb.is_cuda and xb.dtype == torch.float16 and xb.is_contiguous() and xb.dim() == 2
+                and xb.shape[1] == self.d):
+            raise ValueError("adopt_device expects a contiguous CUDA float16 [n, d] tensor")
+        torch.cuda.current_stream().synchronize()
+        _lib.check(self._lib.proqa_index_adopt_device(self._h, xb.data_ptr(), xb.shape[0]))
+        self._adopted = xb
+
+    def search_device(self, xq, k, idx_offset=0):
+        """CUDA tensor in, CUDA tensors out: (D float32 [nq,k], I int64 [nq,k])."""
+        import torch
+        if not xq.is_cuda:
+            raise ValueError("search_device expects a CUDA tensor")
+        xq = xq.contiguous()
+        if xq.dim() != 2 or xq.shape[1] != self.d:
+            raise ValueError(f"xq must have shape [nq, {self.d}], got {tuple(xq.shape)}")
+        nq = xq.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        with torch.cuda.device(xq.device):
+            _lib.check(self._lib.proqa_index_search_device(self._h, xq.data_ptr(), nq, _torch_dtype_code(xq), int(k),
+                                                           int(idx_offset), D.data_ptr(), I.data_ptr(),
+                                                           _lib.current_stream_ptr()))
+        return D, I
+
+    # -- introspection / tuning ---------------------------------------------------------
+    def last_stats(self):
+        st = _lib.SearchStats()
+        _lib.check(self._lib.proqa_index_last_stats(self._h, ctypes.byref(st)))
+        return {"rounds": st.rounds, "fallback_rounds": st.fallback_rounds, "candidates": st.candidates,
+                "filter_ms": st.filter_ms, "total_ms": st.total_ms}
+
+    def set_profiling(self, enable=True):
+        _lib.check(self._lib.proqa_index_set_profiling(self._h, 1 if enable else 0))
+
+    def configure(self, cand_capacity=0, first_slab_rows=0, growth=0):
+        _lib.check(self._lib.proqa_index_configure(self._h, cand_capacity, first_slab_rows, growth))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.proqa_index_free(self._h)
+            self._h = None
+            self._adopted = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def merge_topk_device(D_parts, I_parts):
+    """Merge [n_parts, nq, k] per-shard lists (ascending shard order) into [nq, k] on the GPU."""
+    import torch
+    lib = _lib.load()
+    D_parts = D_parts.contiguous()
+    I_parts = I_parts.contiguous()
+    n_parts, nq, k = D_parts.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=D_parts.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=D_parts.device)
+    with torch.cuda.device(D_parts.device):
+        _lib.check(lib.proqa_topk_merge_device(D_parts.data_ptr(), I_parts.data_ptr(), n_parts, nq, k,
+                                               D.data_ptr(), I.data_ptr(), _lib.current_stream_ptr()))
+    return D, I
+
+
+def shard_bounds(n_rows, world_size, rank):
+    """Contiguous row range of `rank`: rows [r*N/G, (r+1)*N/G)."""
+    lo = (n_rows * rank) // world_size
+    hi = (n_rows * (rank + 1)) // world_size
+    return lo, hi
+
+
+class ShardedIndexFlatIP:
+    """Row-sharded exact index over a torch.distributed process group (one rank per GPU).
+
+    Every rank holds rows [lo, hi) of the corpus and all queries; `search` runs the local exact
+    top-k with global row ids, all-gathers the [nq, k] (score, id) lists of every rank (the only
+    collective on the path) and merges them with the same ordering rule, so the result is
+    bit-identical to the single-GPU search.  `local_search` / `merge` are injectable so the
+    distributed plumbing can be exercised with the gloo backend on CPU in the tests.
+    """
+
+    def __init__(self, n_total, d=EMBED_DIM, group=None, local_search=None, merge=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_total = int(n_total)
+        self.d = d
+        self.lo, self.hi = shard_bounds(self.n_total, self.world_size, self.rank)
+        self._local_search = local_search
+        self._merge = merge or merge_topk_device
+        self._index = None
+        if local_search is None:
+            self._index = IndexFlatIP(d, capacity=self.hi - self.lo)
+
+    def add_local(self, xb_local):
+        """Add this rank's rows (exactly rows [lo, hi) of the corpus, in order)."""
+        if self._index is None:
+            raise RuntimeError("add_local is only available with the built-in HIP searcher")
+        self._index.add(xb_local)
+        if self._index.ntotal > self.hi - self.lo:
+            raise ValueError("more rows added than this rank's shard holds")
+
+    def search(self, xq, k):
+        """All ranks call with the same queries; returns torch tensors (D, I) on xq's device."""
+        import torch
+        if self._local_search is not None:
+            D, I = self._local_search(xq, k, self.lo)
+        else:
+            D, I = self._index.search_device(xq, k, idx_offset=self.lo)
+        if self.world_size == 1:
+            return D, I
+        D_all = torch.empty((self.world_size,) + tuple(D.shape), dtype=D.dtype, device=D.device)
+        I_all = torch.empty((self.world_size,) + tuple(I.shape), dtype=I.dtype, device=I.device)
+        self.dist.all_gather_into_tensor(D_all, D.contiguous(), group=self.group)
+        self.dist.all_gather_into_tensor(I_all, I.contiguous(), group=self.group)
+        return self._merge(D_all, I_all)

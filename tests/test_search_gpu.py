@@ -1,0 +1,182 @@
+"""Parity of the HIP exhaustive top-k search against the NumPy oracle (through the C ABI)."""
+import numpy as np
+import pytest
+
+from oracle import search_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _int_corpus(rng, n, d=128, lo=-4, hi=4):
+    # integer-valued fp16: every partial sum is exact in fp32, so ids must match bit for bit
+    return rng.integers(lo, hi + 1, (n, d)).astype(np.float16)
+
+
+@pytest.mark.parametrize("n,nq,k", [(4096, 64, 80), (10000, 256, 80), (1000, 33, 80), (131, 7, 5),
+                                    (50000, 600, 80), (128, 1, 1), (257, 300, 200)])
+def test_integer_corpus_ids_identical(gpu_device, n, nq, k):
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(n * 7 + nq)
+    xb = _int_corpus(rng, n)
+    xq = _int_corpus(rng, nq)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    assert index.ntotal == n
+    D, I = index.search(xq, k)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    st = index.last_stats()
+    assert st["fallback_rounds"] == 0
+
+
+def test_fewer_rows_than_k(gpu_device):
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(5)
+    xb = _int_corpus(rng, 37)
+    xq = _int_corpus(rng, 9)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    D, I = index.search(xq, 80)
+    Do, Io = search_oracle.topk_ip(xq, xb, 80)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert (I[:, 37:] == -1).all()
+
+
+def test_empty_index_and_empty_queries(gpu_device):
+    from proqa_amd.index import IndexFlatIP
+    index = IndexFlatIP(128)
+    xq = np.zeros((3, 128), np.float16)
+    D, I = index.search(xq, 4)
+    assert (I == -1).all() and (D == search_oracle.NEG_FILL).all()
+    index.add(np.ones((10, 128), np.float16))
+    D, I = index.search(np.zeros((0, 128), np.float16), 4)
+    assert D.shape == (0, 4) and I.shape == (0, 4)
+
+
+def test_all_ties_lowest_index_wins(gpu_device):
+    from proqa_amd.index import IndexFlatIP
+    xb = np.ones((5000, 128), np.float16)
+    xq = np.ones((40, 128), np.float16)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    D, I = index.search(xq, 80)
+    np.testing.assert_array_equal(I, np.tile(np.arange(80), (40, 1)))
+    assert (D == 128.0).all()
+
+
+def test_random_fp16_matches_oracle(gpu_device):
+    """Random normal fp16: scores agree to fp32 round-off, id sets agree except at round-off ties."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(0)
+    xb = rng.standard_normal((10000, 128)).astype(np.float16)   # BASELINE.json configs[0]
+    xq = rng.standard_normal((256, 128)).astype(np.float16)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    D, I = index.search(xq, 80)
+    Do, Io = search_oracle.topk_ip(xq, xb, 80)
+    np.testing.assert_allclose(D, Do, rtol=1e-5, atol=1e-4)
+    agree = np.mean([len(set(a) & set(b)) / 80.0 for a, b in zip(I, Io)])
+    assert agree > 1 - 1e-4          # Recall@80 tolerance of BASELINE.json north_star
+    assert (np.diff(D, axis=1) <= 0).all()
+
+
+def test_adversarial_order_takes_overflow_safe_path(gpu_device):
+    """Rows sorted by ascending score: every row beats the running threshold, candidate lists
+    overflow, and the slab re-scan must still return the exact answer."""
+    from proqa_amd.index import IndexFlatIP
+    n = 40000
+    base = np.zeros((n, 128), np.float16)
+    base[:, 0] = (np.arange(n) // 40).astype(np.float16)      # non-decreasing scores, with ties
+    xq = np.zeros((70, 128), np.float16)
+    xq[:, 0] = 1
+    index = IndexFlatIP(128)
+    index.configure(cand_capacity=256, first_slab_rows=128, growth=4)
+    index.add(base)
+    D, I = index.search(xq, 80)
+    Do, Io = search_oracle.topk_ip(xq, base, 80)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert index.last_stats()["fallback_rounds"] > 0
+
+
+def test_f32_inputs_and_incremental_add(gpu_device):
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(3)
+    xb = _int_corpus(rng, 3000)
+    xq = _int_corpus(rng, 50)
+    index = IndexFlatIP(128)
+    index.add(xb[:1000].astype(np.float32))     # eval_retrieval.py upcasts to float32 before add
+    index.add(xb[1000:])
+    D, I = index.search(xq.astype(np.float32), 10)
+    Do, Io = search_oracle.topk_ip(xq, xb, 10)
+    np.testing.assert_array_equal(I, Io)
+    index.reset()
+    assert index.ntotal == 0
+
+
+def test_device_search_offsets_and_merge(gpu_device):
+    """Two shards searched separately with global ids, merged on the GPU == unsharded search."""
+    import torch
+    from proqa_amd.index import IndexFlatIP, merge_topk_device
+    rng = np.random.default_rng(11)
+    xb = _int_corpus(rng, 9000)
+    xq = _int_corpus(rng, 130)
+    tq = torch.from_numpy(xq).to(gpu_device)
+    parts = []
+    for lo, hi in [(0, 4000), (4000, 9000)]:
+        ix = IndexFlatIP(128)
+        ix.add_device(torch.from_numpy(xb[lo:hi]).to(gpu_device))
+        parts.append(ix.search_device(tq, 80, idx_offset=lo))
+    D, I = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    Do, Io = search_oracle.topk_ip(xq, xb, 80)
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do)
+
+
+def test_full_size_properties(gpu_device):
+    """18M x 128 fp16 (BASELINE.json configs[2] shape) through size-independent properties:
+    planted rows must be found at rank 0, scores sorted, ids unique and in range, and a sharded
+    search of the same tensor must give the identical result."""
+    import torch
+    from proqa_amd.index import IndexFlatIP, merge_topk_device
+    n, nq, k = 18_000_000, 2032, 80
+    g = torch.Generator(device=gpu_device)
+    g.manual_seed(1234)
+    xb = torch.empty((n, 128), dtype=torch.float16, device=gpu_device)
+    step = 2_000_000
+    for r0 in range(0, n, step):
+        xb[r0:r0 + step] = torch.randn((min(step, n - r0), 128), generator=g, device=gpu_device,
+                                       dtype=torch.float32).to(torch.float16)
+    xq = torch.randn((nq, 128), generator=g, device=gpu_device, dtype=torch.float32).to(torch.float16)
+    # plant: row p_j = 8 * xq_j is the unique best match of query j
+    plant = torch.randperm(n, generator=g, device=gpu_device)[:nq]
+    xb[plant] = (xq.float() * 8).to(torch.float16)
+    index = IndexFlatIP(128)
+    index.adopt_device(xb)
+    D, I = index.search_device(xq, k)
+    assert index.last_stats()["fallback_rounds"] == 0
+    assert torch.equal(I[:, 0], plant)
+    assert (D[:, 1:] <= D[:, :-1]).all()
+    assert (I >= 0).all() and (I < n).all()
+    assert all(len(set(row.tolist())) == k for row in I[:64].cpu())
+    # re-score the reported ids in fp32 on the GPU: D must be the true inner products
+    rows = xb[I[:32].reshape(-1)].float().reshape(32, k, 128)
+    ref = torch.einsum("qkd,qd->qk", rows, xq[:32].float())
+    assert torch.allclose(D[:32], ref, rtol=1e-5, atol=1e-3)
+    # no row outside the list may beat the k-th score (checked exhaustively for 8 queries)
+    S = xq[:8].float() @ xb[:6_000_000].float().T
+    kth = D[:8, -1:]
+    n_better = (S > kth).sum(dim=1)
+    in_list = torch.stack([(I[q] < 6_000_000).sum() for q in range(8)])
+    assert (n_better <= in_list).all()
+    del S
+    # sharded == unsharded, bit for bit
+    parts = []
+    for lo, hi in [(0, 7_000_000), (7_000_000, n)]:
+        ix = IndexFlatIP(128)
+        ix.adopt_device(xb[lo:hi])
+        parts.append(ix.search_device(xq, k, idx_offset=lo))
+    Dm, Im = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(Im, I) and torch.equal(Dm, D)
