@@ -1,0 +1,140 @@
+"""Encode a JSON-lines file of questions or passages into a [N,128] .npy index.
+
+Drop-in for /root/reference/retrieval/get_embed.py (load_saved :22-27, main :29-139,
+predict :142-172): same flags (proqa_amd.config), same input files, same output format.
+
+    python get_embed.py --do_predict --predict_batch_size 512 --bert_model_name bert-base-uncased \
+        --fp16 --predict_file F --init_checkpoint CKPT [--is_query_embed] --embed_save_path OUT
+
+Differences that are intended: the model runs on the MI355X kernels of libproqa_hip.so (no
+apex); under torchrun (WORLD_SIZE > 1) or --local_rank the input rows are split into contiguous
+ranges, one per GPU, and every rank writes its slice of a pre-sized .npy — the reference's
+DataParallel/DDP wrappers have no get_embed and cannot do this.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Subset
+
+from . import npy
+from .config import get_args
+from .datasets import EmDataset, em_collate
+from .retriever import BertForRetriever, config_from_dict
+from .utils import move_to_cuda
+
+
+def load_saved(model, path):
+    """torch state_dict checkpoint -> model; tolerates DataParallel's 'module.' prefix."""
+    state_dict = torch.load(path, map_location="cpu")
+    state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+    model.load_state_dict(state_dict)
+    return model
+
+
+def load_bert_config(name_or_dir):
+    """config.json of a local model directory, else transformers' BertConfig.from_pretrained."""
+    cfg_path = os.path.join(name_or_dir, "config.json")
+    if os.path.isfile(cfg_path):
+        with open(cfg_path) as f:
+            return config_from_dict(json.load(f))
+    from transformers import BertConfig
+    return config_from_dict(BertConfig.from_pretrained(name_or_dir).to_dict())
+
+
+def _dist_env(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.local_rank != -1:
+        rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", max(args.local_rank, 0)))
+        return world, rank, local_rank
+    return 1, 0, 0
+
+
+def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=True):
+    """The reference's hot loop: move batch to the GPU, get_embed, keep embeddings on device."""
+    model.eval()
+    if fp16:
+        model.half()
+    chunks = []
+    for batch in eval_dataloader:
+        batch_to_feed = move_to_cuda(batch)
+        with torch.no_grad():
+            chunks.append(model.get_embed(batch_to_feed, is_query_embed)["embed"])
+    if chunks:
+        embeds = torch.cat(chunks)
+    else:
+        embeds = torch.empty((0, 128), dtype=model.out_dtype, device=device)
+    model.train()
+    return embeds
+
+
+def main(argv=None):
+    args = get_args(argv)
+    is_query_embed = args.is_query_embed
+
+    if args.accumulate_gradients < 1:
+        raise ValueError("Invalid accumulate_gradients parameter: {}, should be >= 1".format(
+            args.accumulate_gradients))
+    if not args.do_train and not args.do_predict:
+        raise ValueError("At least one of `do_train` or `do_predict` must be True.")
+    if args.do_train:
+        raise ValueError("proqa_amd.get_embed implements the encode path only; training is out of scope")
+    if not args.predict_file:
+        raise ValueError("If `do_predict` is True, then `predict_file` must be specified.")
+    if args.no_cuda:
+        raise RuntimeError("--no_cuda: proqa_amd has no CPU path (the reference's move_to_cuda is "
+                           "unconditional as well, retrieval/utils.py:11)")
+
+    world, rank, local_rank = _dist_env(args)
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible: the encode path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1 and not torch.distributed.is_initialized():
+        torch.distributed.init_process_group(backend="nccl")  # RCCL on ROCm; used for barriers only
+
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+
+    from transformers import BertTokenizer
+    bert_config = load_bert_config(args.bert_model_name)
+    model = BertForRetriever(bert_config, args, device=device)
+    tokenizer = BertTokenizer.from_pretrained(args.bert_model_name)
+
+    dataset = EmDataset(tokenizer, args.predict_file, args.max_query_length, args.max_seq_length, is_query_embed)
+    n_total = len(dataset)
+    lo, hi = (n_total * rank) // world, (n_total * (rank + 1)) // world
+    part = dataset if world == 1 else Subset(dataset, range(lo, hi))
+    loader = DataLoader(part, batch_size=args.predict_batch_size, collate_fn=em_collate, pin_memory=True,
+                        num_workers=args.eval_workers)
+
+    assert args.init_checkpoint != ""
+    model = load_saved(model, args.init_checkpoint)
+    model.to(device)
+
+    # output dtype: fp16 under --fp16 (apex O1 emits half) or --efficient_eval (.half()), else fp32
+    want_half = args.fp16 or args.efficient_eval
+    if args.embed_dtype != "auto":
+        want_half = args.embed_dtype in ("float16", "fp16", "f2")
+    model.half() if want_half else model.float()
+
+    embeds = predict(args, model, loader, device, fp16=args.efficient_eval, is_query_embed=is_query_embed)
+    local = embeds.cpu().numpy()
+    out_path = npy.save_path(args.embed_save_path)
+    if world == 1:
+        npy.save(out_path, local)
+    else:
+        if rank == 0:
+            npy.create(out_path, n_total, 128, local.dtype)
+        torch.distributed.barrier()
+        npy.write_rows(out_path, lo, local)
+        torch.distributed.barrier()
+    return out_path
+
+
+if __name__ == "__main__":
+    main()

@@ -220,6 +220,7 @@ class ShardedIndexFlatIP:
             return D, I
         D_all = torch.empty((self.world_size,) + tuple(D.shape), dtype=D.dtype, device=D.device)
         I_all = torch.empty((self.world_size,) + tuple(I.shape), dtype=I.dtype, device=I.device)
-        self.dist.all_gather_into_tensor(D_all, D.contiguous(), group=self.group)
-        self.dist.all_gather_into_tensor(I_all, I.contiguous(), group=self.group)
+        # rank-ordered slices of one buffer: exactly the [n_parts, nq, k] layout the merge consumes
+        self.dist.all_gather(list(D_all.unbind(0)), D.contiguous(), group=self.group)
+        self.dist.all_gather(list(I_all.unbind(0)), I.contiguous(), group=self.group)
         return self._merge(D_all, I_all)

@@ -1,0 +1,264 @@
+"""Dual-tower BERT retriever on MI355X.
+
+Mirrors /root/reference/retrieval/retriever.py (BertForRetriever :10-20, get_embed :33-43):
+
+    model.get_embed({'input_ids': LongTensor[B,L], 'input_mask': BoolTensor[B,L]}, is_query_embed)
+        -> {'embed': Tensor[B,128]}
+
+Each tower is BertModel (embeddings, N x BertLayer, pooler) followed by Linear(hidden, 128) on
+the pooled [CLS] vector.  Here the dense projections run as PyTorch-ROCm fp16 GEMMs (hipBLASLt)
+and everything between them is a hand-written HIP kernel called through the C ABI of
+libproqa_hip.so: embedding gather+LayerNorm, MFMA attention with the key-padding mask,
+bias+GELU(erf), bias+residual+LayerNorm, and the fused pooler(tanh)+projection head.
+Weights are held in fp16 (the reference runs apex AMP O1 / .half() for --fp16); accumulation,
+softmax and LayerNorm statistics are fp32.  There is no CPU path.
+"""
+import re
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib
+from ._lib import PROQA_F16, PROQA_F32, EMBED_DIM
+
+
+def config_from_dict(d):
+    """BertConfig-like namespace from a plain dict (config.json of a HF model directory)."""
+    return SimpleNamespace(
+        vocab_size=d["vocab_size"], hidden_size=d["hidden_size"],
+        num_hidden_layers=d["num_hidden_layers"], num_attention_heads=d["num_attention_heads"],
+        intermediate_size=d["intermediate_size"], max_position_embeddings=d["max_position_embeddings"],
+        type_vocab_size=d.get("type_vocab_size", 2), layer_norm_eps=d.get("layer_norm_eps", 1e-12),
+        hidden_act=d.get("hidden_act", "gelu"))
+
+
+BERT_BASE = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                 intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
+                 layer_norm_eps=1e-12, hidden_act="gelu")
+
+
+def tower_keys(prefix, n_layers):
+    """state_dict keys of one BertModel tower, in the reference's (HF) naming."""
+    keys = [f"{prefix}.embeddings.{n}" for n in (
+        "word_embeddings.weight", "position_embeddings.weight", "token_type_embeddings.weight",
+        "LayerNorm.weight", "LayerNorm.bias")]
+    for i in range(n_layers):
+        p = f"{prefix}.encoder.layer.{i}"
+        for m in ("attention.self.query", "attention.self.key", "attention.self.value",
+                  "attention.output.dense", "attention.output.LayerNorm", "intermediate.dense",
+                  "output.dense", "output.LayerNorm"):
+            keys += [f"{p}.{m}.weight", f"{p}.{m}.bias"]
+    keys += [f"{prefix}.pooler.dense.weight", f"{prefix}.pooler.dense.bias"]
+    return keys
+
+
+class _Tower:
+    """fp16 device weights of one BERT tower, laid out for the kernels (fused QKV, [in,out] GEMM operands)."""
+
+    def __init__(self, sd, prefix, proj_prefix, cfg, device):
+        def w(name):
+            return sd[name].detach().to(device=device, dtype=torch.float16).contiguous()
+
+        e = f"{prefix}.embeddings"
+        self.word = w(f"{e}.word_embeddings.weight")
+        self.pos = w(f"{e}.position_embeddings.weight")
+        self.type0 = w(f"{e}.token_type_embeddings.weight")[0].contiguous()
+        self.emb_g = w(f"{e}.LayerNorm.weight")
+        self.emb_b = w(f"{e}.LayerNorm.bias")
+        self.layers = []
+        for i in range(cfg.num_hidden_layers):
+            p = f"{prefix}.encoder.layer.{i}"
+            qkv_w = torch.cat([w(f"{p}.attention.self.{n}.weight") for n in ("query", "key", "value")], 0)
+            qkv_b = torch.cat([w(f"{p}.attention.self.{n}.bias") for n in ("query", "key", "value")], 0)
+            self.layers.append(SimpleNamespace(
+                qkv_wt=qkv_w.t().contiguous(), qkv_b=qkv_b.contiguous(),           # [H, 3H]
+                ao_wt=w(f"{p}.attention.output.dense.weight").t().contiguous(),     # [H, H]
+                ao_b=w(f"{p}.attention.output.dense.bias"),
+                ln1_g=w(f"{p}.attention.output.LayerNorm.weight"), ln1_b=w(f"{p}.attention.output.LayerNorm.bias"),
+                ff1_wt=w(f"{p}.intermediate.dense.weight").t().contiguous(),        # [H, I]
+                ff1_b=w(f"{p}.intermediate.dense.bias"),
+                ff2_wt=w(f"{p}.output.dense.weight").t().contiguous(),              # [I, H]
+                ff2_b=w(f"{p}.output.dense.bias"),
+                ln2_g=w(f"{p}.output.LayerNorm.weight"), ln2_b=w(f"{p}.output.LayerNorm.bias")))
+        self.pool_w = w(f"{prefix}.pooler.dense.weight")   # [H, H] (out, in): read row-wise by the kernel
+        self.pool_b = w(f"{prefix}.pooler.dense.bias")
+        self.proj_w = w(f"{proj_prefix}.weight")           # [128, H]
+        self.proj_b = w(f"{proj_prefix}.bias")
+
+
+class BertForRetriever:
+    """Inference-only dual-tower retriever with the reference's get_embed call shape."""
+
+    def __init__(self, config, args=None, device=None):
+        self.config = config if not isinstance(config, dict) else config_from_dict(config)
+        if self.config.hidden_size != self.config.num_attention_heads * 64:
+            raise ValueError("the attention kernel is built for head_dim 64 (bert-base/large geometry)")
+        if getattr(self.config, "hidden_act", "gelu") != "gelu":
+            raise ValueError("only hidden_act='gelu' (erf) is implemented, as in bert-base-uncased")
+        self.args = args
+        self._lib = _lib.load()
+        _lib.require_gpu()
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.towers = {}
+        self.out_dtype = torch.float16
+        self._ws = {}
+
+    # -- reference-compatible surface -----------------------------------------------------
+    def state_dict_keys(self):
+        n = self.config.num_hidden_layers
+        return (tower_keys("bert_q", n) + tower_keys("bert_c", n)
+                + ["proj_q.weight", "proj_q.bias", "proj_c.weight", "proj_c.bias"])
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Accepts the reference checkpoint layout (get_embed.py:22-27 strips 'module.' first).
+
+        torch-1.4-era checkpoints have no `position_ids` buffers; newer ones may — ignored.
+        """
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("position_ids")}
+        want = self.state_dict_keys()
+        missing = [k for k in want if k not in sd]
+        unexpected = [k for k in sd if k not in set(want)]
+        if missing or (strict and unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for BertForRetriever: "
+                               f"missing keys {missing[:8]}{'...' if len(missing) > 8 else ''}; "
+                               f"unexpected keys {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+        self.towers = {
+            True: _Tower(sd, "bert_q", "proj_q", self.config, self.device),
+            False: _Tower(sd, "bert_c", "proj_c", self.config, self.device),
+        }
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("proqa_amd.BertForRetriever runs on MI355X only; there is no CPU path")
+        if self.towers and device != self.device:
+            raise RuntimeError("move the model before load_state_dict")
+        self.device = device
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def half(self):
+        self.out_dtype = torch.float16
+        return self
+
+    def float(self):
+        self.out_dtype = torch.float32
+        return self
+
+    def __call__(self, batch):
+        raise NotImplementedError("training forward (retriever.py:22-31) is outside the encode/search hot path")
+
+    @torch.no_grad()
+    def get_embed(self, batch, is_query_embed):
+        ids, mask = batch["input_ids"], batch["input_mask"]
+        emb = self.encode(ids, mask, bool(is_query_embed))
+        return {"embed": emb}
+
+    # -- implementation -------------------------------------------------------------------
+    def _buffers(self, B, S):
+        key = (B, S)
+        ws = self._ws.get(key)
+        if ws is None:
+            H, I = self.config.hidden_size, self.config.intermediate_size
+            dev, f16 = self.device, torch.float16
+            n = B * S
+            ws = SimpleNamespace(
+                h=torch.empty((n, H), dtype=f16, device=dev), h1=torch.empty((n, H), dtype=f16, device=dev),
+                qkv=torch.empty((n, 3 * H), dtype=f16, device=dev), ctx=torch.empty((n, H), dtype=f16, device=dev),
+                tmp=torch.empty((n, H), dtype=f16, device=dev), ff=torch.empty((n, I), dtype=f16, device=dev))
+            if len(self._ws) > 8:
+                self._ws.clear()
+            self._ws[key] = ws
+        return ws
+
+    @torch.no_grad()
+    def encode(self, input_ids, input_mask, is_query_embed):
+        if not self.towers:
+            raise RuntimeError("load_state_dict must be called before get_embed")
+        if not input_ids.is_cuda:
+            raise RuntimeError("get_embed expects CUDA tensors (the reference feeds move_to_cuda(batch))")
+        tw = self.towers[bool(is_query_embed)]
+        cfg = self.config
+        lib, chk = self._lib, _lib.check
+        B, S = input_ids.shape
+        if S > cfg.max_position_embeddings:
+            raise ValueError(f"sequence length {S} exceeds max_position_embeddings {cfg.max_position_embeddings}")
+        H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
+        eps = float(cfg.layer_norm_eps)
+        ids = input_ids.contiguous().to(torch.int64)
+        mask = input_mask.to(torch.bool)
+        # em_collate pads on the right: the mask of every row is a prefix of ones
+        if S > 1 and bool((mask[:, 1:] & ~mask[:, :-1]).any()):
+            raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
+        lens = mask.sum(dim=1).to(torch.int32).contiguous()
+        out = torch.empty((B, EMBED_DIM), dtype=self.out_dtype, device=self.device)
+        if B == 0:
+            return out
+        ws = self._buffers(B, S)
+        n = B * S
+        with torch.cuda.device(self.device):
+            st = _lib.current_stream_ptr()
+            chk(lib.proqa_embed_layernorm_f16(ids.data_ptr(), n, S, H, tw.word.data_ptr(), tw.word.shape[0],
+                                              tw.pos.data_ptr(), tw.type0.data_ptr(), tw.emb_g.data_ptr(),
+                                              tw.emb_b.data_ptr(), eps, ws.h.data_ptr(), st))
+            h, h1 = ws.h, ws.h1
+            for L in tw.layers:
+                torch.addmm(L.qkv_b, h, L.qkv_wt, out=ws.qkv)                       # fused Q|K|V projection
+                chk(lib.proqa_attention_f16(ws.qkv.data_ptr(), lens.data_ptr(), B, S, NH, ws.ctx.data_ptr(), st))
+                torch.mm(ws.ctx, L.ao_wt, out=ws.tmp)
+                chk(lib.proqa_bias_residual_layernorm_f16(ws.tmp.data_ptr(), L.ao_b.data_ptr(), h.data_ptr(),
+                                                          L.ln1_g.data_ptr(), L.ln1_b.data_ptr(), eps, n, H,
+                                                          h1.data_ptr(), st))
+                torch.mm(h1, L.ff1_wt, out=ws.ff)
+                chk(lib.proqa_bias_gelu_f16(ws.ff.data_ptr(), L.ff1_b.data_ptr(), n, I, st))
+                torch.mm(ws.ff, L.ff2_wt, out=ws.tmp)
+                chk(lib.proqa_bias_residual_layernorm_f16(ws.tmp.data_ptr(), L.ff2_b.data_ptr(), h1.data_ptr(),
+                                                          L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, n, H,
+                                                          h.data_ptr(), st))
+            chk(lib.proqa_pool_project_f16(h.data_ptr(), B, S, H, tw.pool_w.data_ptr(), tw.pool_b.data_ptr(),
+                                           tw.proj_w.data_ptr(), tw.proj_b.data_ptr(), out.data_ptr(),
+                                           PROQA_F16 if self.out_dtype == torch.float16 else PROQA_F32, st))
+        return out
+
+
+def random_state_dict(config, seed=0, std=0.02):
+    """N(0, std) weights in the reference checkpoint layout (synthetic benchmark / tests)."""
+    cfg = config if not isinstance(config, dict) else config_from_dict(config)
+    g = torch.Generator().manual_seed(seed)
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    shapes = {}
+    for t in ("bert_q", "bert_c"):
+        shapes[f"{t}.embeddings.word_embeddings.weight"] = (cfg.vocab_size, H)
+        shapes[f"{t}.embeddings.position_embeddings.weight"] = (cfg.max_position_embeddings, H)
+        shapes[f"{t}.embeddings.token_type_embeddings.weight"] = (cfg.type_vocab_size, H)
+        for k in tower_keys(t, cfg.num_hidden_layers):
+            if k in shapes:
+                continue
+            if k.endswith("LayerNorm.weight") or k.endswith("LayerNorm.bias") or k.endswith(".bias"):
+                width = I if "intermediate.dense" in k else H
+                shapes[k] = (width,)
+            elif "intermediate.dense.weight" in k:
+                shapes[k] = (I, H)
+            elif re.search(r"layer\.\d+\.output\.dense\.weight", k):
+                shapes[k] = (H, I)
+            else:
+                shapes[k] = (H, H)
+    for p in ("proj_q", "proj_c"):
+        shapes[f"{p}.weight"] = (EMBED_DIM, H)
+        shapes[f"{p}.bias"] = (EMBED_DIM,)
+    sd = {}
+    for k, shp in shapes.items():
+        if k.endswith("LayerNorm.weight"):
+            sd[k] = 1.0 + std * torch.randn(shp, generator=g)
+        else:
+            sd[k] = std * torch.randn(shp, generator=g)
+    return sd
