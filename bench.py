@@ -1,0 +1,250 @@
+"""Benchmark of the hot path on MI355X: exhaustive top-80 MIPS over an 18M x 128 fp16 index
+(BASELINE.json configs[2]/[3]) as the headline line, plus the bert-base encode leg
+(configs[1]) as a secondary object of the same JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A search "step" is one pass of all 2032 queries over the whole corpus (row-sharded over the N
+ranks, one RCCL all-gather of the per-shard top-80 lists, GPU merge).  Inputs are synthetic,
+generated on the device from fixed seeds and resident in HBM before the timed region.  An encode
+"step" is one batch of 512 pre-tokenised 128-token passages through the bert-base tower.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16_TFLOPS = 2500.0   # dense fp16 MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBS = 8000.0           # HBM3E spec peak, same table
+D = 128
+GEN_CHUNK = 250_000             # rows per seeded generation chunk (divides every 18M/G shard)
+ENCODE_GFLOP_PER_PASSAGE = 22.35  # 128-token passage through bert-base
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=18_000_000)
+    p.add_argument("--queries", type=int, default=2032)
+    p.add_argument("--topk", type=int, default=80)
+    p.add_argument("--encode-steps", type=int, default=8)
+    p.add_argument("--encode-batch", type=int, default=512)
+    p.add_argument("--seq-len", type=int, default=128)
+    p.add_argument("--skip-encode", action="store_true")
+    p.add_argument("--skip-cpu", action="store_true")
+    return p.parse_args()
+
+
+def gen_rows(lo, hi, device):
+    """Rows [lo, hi) of the synthetic corpus: chunk c is randn(seed=1000+c) rounded to fp16, so
+    the corpus is the same for every sharding."""
+    out = torch.empty((hi - lo, D), dtype=torch.float16, device=device)
+    g = torch.Generator(device=device)
+    c0, c1 = lo // GEN_CHUNK, (hi + GEN_CHUNK - 1) // GEN_CHUNK
+    for c in range(c0, c1):
+        g.manual_seed(1000 + c)
+        chunk = torch.randn((GEN_CHUNK, D), generator=g, device=device, dtype=torch.float32).to(torch.float16)
+        a, b = max(lo, c * GEN_CHUNK), min(hi, (c + 1) * GEN_CHUNK)
+        out[a - lo:b - lo] = chunk[a - c * GEN_CHUNK:b - c * GEN_CHUNK]
+    return out
+
+
+def gen_queries(nq, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(1)
+    return torch.randn((nq, D), generator=g, device=device, dtype=torch.float32).to(torch.float16)
+
+
+def timed(fn, steps, warmup, world, device):
+    """W untimed steps, then exactly K steps between barrier+synchronize; max over ranks (seconds)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def cpu_search_baseline(xb_sample, xq_sample, k, rows_total):
+    """The reference's CPU path (eval_retrieval.py:98-104 restated in NumPy: float32 upcast, BLAS
+    GEMM, exact top-k) timed on a bounded sample and scaled linearly in corpus rows."""
+    from oracle import search_oracle
+    xb = xb_sample.cpu().numpy()
+    xq = xq_sample.cpu().numpy()
+    search_oracle.topk_ip(xq[:8], xb[:4096], k)  # warm BLAS threads
+    t0 = time.perf_counter()
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    dt = time.perf_counter() - t0
+    qps_sample = xq.shape[0] / dt
+    return qps_sample * (xb.shape[0] / rows_total), dt, Do, Io
+
+
+def encode_leg(args, device, world, rank):
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
+    B, S = args.encode_batch, args.seq_len
+    sd = random_state_dict(BERT_BASE, seed=0)
+    model = BertForRetriever(BERT_BASE, device=device)
+    model.load_state_dict(sd)
+    g = torch.Generator(device=device)
+    g.manual_seed(rank)
+    ids = torch.randint(1000, 30522, (B, S), generator=g, device=device, dtype=torch.int64)
+    ids[:, 0], ids[:, -1] = 101, 102
+    mask = torch.ones((B, S), dtype=torch.bool, device=device)
+    batch = {"input_ids": ids, "input_mask": mask}
+    outs = []
+
+    def step():
+        outs.append(model.get_embed(batch, False)["embed"])
+        if len(outs) > 4:
+            outs.pop(0)
+
+    dt = timed(step, args.encode_steps, 2, world, device)
+    pps = world * B * args.encode_steps / dt
+    tf = pps / world * ENCODE_GFLOP_PER_PASSAGE / 1e3   # per-GPU TFLOP/s
+    res = {
+        "metric": "passages/sec encoded", "value": pps, "unit": "passages/s", "ms_per_step": dt / args.encode_steps * 1e3,
+        "steps": args.encode_steps, "scaling": "weak", "dtype": "f16",
+        "config": {"workload": "bert-base-uncased shape (12x768x12x3072), batch 512 x 128 pre-tokenised ids, "
+                               "fp16 weights/activations, fp32 accumulate, random N(0,0.02) weights", "batch": B,
+                   "seq_len": S},
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tf / PEAK_MFMA_F16_TFLOPS, "traffic": None,
+                     "note": "whole-step algorithmic flops (22.35 GFLOP/passage) / step time; the GEMMs are hipBLASLt"},
+    }
+    if rank == 0 and not args.skip_cpu:
+        from oracle import bert_oracle
+        nb = 4
+        sd_np = {k: v.numpy() for k, v in sd.items()}
+        ids_np, mask_np = ids[:nb].cpu().numpy(), mask[:nb].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = bert_oracle.get_embed(sd_np, ids_np, mask_np, False, 12, 12)
+        cdt = time.perf_counter() - t0
+        got = outs[-1][:nb].float().cpu().numpy()
+        res["cpu_baseline"] = {"value": nb / cdt, "unit": "passages/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"{nb} passages x 128 tokens, NumPy fp32 oracle of BertForRetriever.get_embed"}
+        res["parity_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+    return res
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl")   # RCCL
+
+    from proqa_amd.index import IndexFlatIP, ShardedIndexFlatIP, shard_bounds
+
+    n, nq, k = args.rows, args.queries, args.topk
+    lo, hi = shard_bounds(n, world, rank)
+    xb = gen_rows(lo, hi, device)
+    xq = gen_queries(nq, device)
+    sharded = ShardedIndexFlatIP(n, preallocate=False)
+    sharded.adopt_local(xb)
+    sharded.local_index.set_profiling(True)
+    result = {}
+
+    def step():
+        result["DI"] = sharded.search(xq, k)
+
+    dt = timed(step, args.steps, args.warmup, world, device)
+    qps = nq * args.steps / dt
+    st = sharded.local_index.last_stats()
+    # roofline of the dominant kernel (mips_filter_f16): algorithmic flops 2*Q*N_local*d per search
+    # over the HIP-event time of its launches in that search (recorded on the search stream)
+    flops = 2.0 * nq * (hi - lo) * D
+    filter_s = st["filter_ms"] / 1e3
+    tflops = flops / filter_s / 1e12
+    hbm_gbs = (hi - lo) * D * 2 / filter_s / 1e9
+
+    line = {
+        "metric": "queries/sec top-80 MIPS over 18M x 128 index", "value": qps, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+        "data": "synthetic",
+        "config": {"workload": f"HIP Q.P^T + top-{k}: {nq} queries over {n} x 128 fp16 index resident in HBM "
+                               f"(BASELINE.json configs[2]; row-sharded over {world} GPU(s), configs[3])",
+                   "rows": n, "queries": nq, "topk": k, "parallelism": f"corpus-row-shard x{world}",
+                   "rounds": st["rounds"], "fallback_rounds": st["fallback_rounds"],
+                   "candidates_per_query": st["candidates"] / max(nq, 1)},
+        "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / PEAK_MFMA_F16_TFLOPS, "traffic": pmc_traffic(),
+                     "kernel": "mips_filter_f16", "filter_ms_per_search": st["filter_ms"],
+                     "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / PEAK_HBM_GBS},
+    }
+
+    if rank == 0 and not args.skip_cpu:
+        # CPU baseline + id parity on a bounded sample of the same workload
+        ns, qs = min(1_000_000, hi - lo), min(256, nq)
+        cpu_qps, cdt, Do, Io = cpu_search_baseline(xb[:ns], xq[:qs], k, n)
+        ix = IndexFlatIP(128)
+        ix.adopt_device(xb[:ns])
+        Dg, Ig = ix.search_device(xq[:qs], k)
+        Ig = Ig.cpu().numpy()
+        rec = {f"overlap@{c}": float(np.mean([len(set(a[:c]) & set(b[:c])) / c for a, b in zip(Ig, Io)]))
+               for c in (5, 20, 80)}
+        line["cpu_baseline"] = {"value": cpu_qps, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+                                "sample": f"{qs} queries x {ns} rows (NumPy restatement of eval_retrieval.py:98-104, "
+                                          f"{cdt:.1f} s), scaled linearly to {n} rows"}
+        line["recall_parity"] = dict(rec, sample=f"GPU vs NumPy oracle top-k id overlap, {qs} q x {ns} rows",
+                                     max_abs_score_diff=float(np.abs(Dg.cpu().numpy() - Do).max()))
+    if world > 1:
+        dist.barrier()
+
+    if not args.skip_encode:
+        del sharded, xb
+        torch.cuda.empty_cache()
+        enc = encode_leg(args, device, world, rank)
+        line["encode"] = enc
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per mips_filter launch from the committed rocprofv3 PMC pass, if present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_search")
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

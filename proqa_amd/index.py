@@ -186,7 +186,7 @@ class ShardedIndexFlatIP:
     distributed plumbing can be exercised with the gloo backend on CPU in the tests.
     """
 
-    def __init__(self, n_total, d=EMBED_DIM, group=None, local_search=None, merge=None):
+    def __init__(self, n_total, d=EMBED_DIM, group=None, local_search=None, merge=None, preallocate=True):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -199,7 +199,7 @@ class ShardedIndexFlatIP:
         self._merge = merge or merge_topk_device
         self._index = None
         if local_search is None:
-            self._index = IndexFlatIP(d, capacity=self.hi - self.lo)
+            self._index = IndexFlatIP(d, capacity=(self.hi - self.lo) if preallocate else 0)
 
     def add_local(self, xb_local):
         """Add this rank's rows (exactly rows [lo, hi) of the corpus, in order)."""
@@ -208,6 +208,18 @@ class ShardedIndexFlatIP:
         self._index.add(xb_local)
         if self._index.ntotal > self.hi - self.lo:
             raise ValueError("more rows added than this rank's shard holds")
+
+    def adopt_local(self, xb_local):
+        """Search this rank's rows [lo, hi) in place: a contiguous CUDA fp16 tensor, not copied."""
+        if self._index is None:
+            raise RuntimeError("adopt_local is only available with the built-in HIP searcher")
+        if xb_local.shape[0] != self.hi - self.lo:
+            raise ValueError(f"rank {self.rank} holds rows [{self.lo}, {self.hi}), got {xb_local.shape[0]} rows")
+        self._index.adopt_device(xb_local)
+
+    @property
+    def local_index(self):
+        return self._index
 
     def search(self, xq, k):
         """All ranks call with the same queries; returns torch tensors (D, I) on xq's device."""
