@@ -10,6 +10,8 @@
 //   duplicate removal in the merge.  The result is exact either way.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,10 +44,13 @@ struct proqa_index {
   unsigned* run_n = nullptr;
   uint2* cand = nullptr;
   unsigned long long* run_keys = nullptr;
+  proqa::WaveRecord* wave_log = nullptr;   // per-wave candidate records of one filter launch
+  unsigned* wave_log_cnt = nullptr;
+  unsigned wave_log_slots = 0;             // waves the log is sized for
   unsigned* overflow = nullptr;            // [kMaxRounds] device
   unsigned* overflow_host = nullptr;       // pinned mirror
-  unsigned long long* stat_dev = nullptr;  // candidate counter
-  unsigned long long* stat_host = nullptr; // pinned
+  unsigned long long* stat_dev = nullptr;  // [ws_nq_pad] candidates per query (part of the workspace)
+  unsigned long long* stat_host = nullptr; // pinned mirror, kStatHostEntries
   void* stage_dev = nullptr;               // staging for host-pointer add/search
   size_t stage_bytes = 0;
   void* stage_pinned = nullptr;
@@ -54,7 +59,7 @@ struct proqa_index {
   hipEvent_t ev_filter[2 * 64] = {};       // per-round brackets, created when profiling is on
   bool profile = false;
   // tuning
-  unsigned cand_capacity = 2048;
+  unsigned cand_capacity = 944;   // k=80 + 944 = one 1024-key LDS sort per query
   int first_slab_rows = 256;
   int growth = 4;
   proqa_search_stats stats = {};
@@ -101,7 +106,8 @@ int ensure_stage(proqa_index* idx, size_t bytes) {
 }
 
 void free_workspace(proqa_index* idx) {
-  void* ptrs[] = {idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n, idx->cand, idx->run_keys};
+  void* ptrs[] = {idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n, idx->cand, idx->run_keys, idx->stat_dev};
+  idx->stat_dev = nullptr;
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   idx->xq_pad = nullptr;
@@ -125,9 +131,26 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k, unsigned cap) {
   PROQA_HIP(hipMalloc((void**)&idx->run_n, (size_t)q * sizeof(unsigned)));
   PROQA_HIP(hipMalloc((void**)&idx->cand, (size_t)q * cap * sizeof(uint2)));
   PROQA_HIP(hipMalloc((void**)&idx->run_keys, (size_t)q * k * sizeof(unsigned long long)));
+  PROQA_HIP(hipMalloc((void**)&idx->stat_dev, (size_t)q * sizeof(unsigned long long)));
+  if (idx->stat_host) PROQA_HIP(hipHostFree(idx->stat_host));
+  PROQA_HIP(hipHostMalloc((void**)&idx->stat_host, (size_t)q * sizeof(unsigned long long), hipHostMallocDefault));
   idx->ws_nq_pad = q;
   idx->ws_k = k;
   idx->ws_cap = cap;
+  return PROQA_OK;
+}
+
+int ensure_wave_log(proqa_index* idx, unsigned slots) {
+  if (slots <= idx->wave_log_slots) return PROQA_OK;
+  if (idx->wave_log) PROQA_HIP(hipFree(idx->wave_log));
+  if (idx->wave_log_cnt) PROQA_HIP(hipFree(idx->wave_log_cnt));
+  idx->wave_log = nullptr;
+  idx->wave_log_cnt = nullptr;
+  idx->wave_log_slots = 0;
+  PROQA_HIP(hipMalloc((void**)&idx->wave_log, (size_t)slots * kWaveLogCap * sizeof(WaveRecord)));
+  PROQA_HIP(hipMalloc((void**)&idx->wave_log_cnt, (size_t)slots * sizeof(unsigned)));
+  PROQA_HIP(hipMemset(idx->wave_log_cnt, 0, (size_t)slots * sizeof(unsigned)));
+  idx->wave_log_slots = slots;
   return PROQA_OK;
 }
 
@@ -176,6 +199,10 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   fa.cand = idx->cand;
   fa.cap = idx->ws_cap;
   fa.overflow = overflow_word;
+  if (int rc = ensure_wave_log(idx, g.grid * kFilterWaves)) return rc;
+  fa.wave_log = idx->wave_log;
+  fa.wave_log_cnt = idx->wave_log_cnt;
+  fa.wave_log_cap = kWaveLogCap;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
   PROQA_HIP(launch_filter(fa, qw, inclusive, g.grid, st));
   if (f1) PROQA_HIP(hipEventRecord(f1, st));
@@ -216,8 +243,8 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
 
   PROQA_HIP(hipEventRecord(idx->ev[0], st));
   PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
-  PROQA_HIP(hipMemsetAsync(idx->stat_dev, 0, sizeof(unsigned long long), st));
-  PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, nq_pad, idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n, st));
+  PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, nq_pad, idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n,
+                                idx->stat_dev, st));
 
   std::vector<Slab> slabs = plan_slabs(idx->n, idx->first_slab_rows, idx->growth);
   if ((int)slabs.size() > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
@@ -226,6 +253,13 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
     hipEvent_t f1 = idx->profile ? idx->ev_filter[2 * r + 1] : nullptr;
     if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, k, false, idx->overflow + r, st, f0, f1))
       return rc;
+    if (getenv("PROQA_DEBUG_CAND")) {
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      unsigned long long c = 0;
+      for (int64_t i = 0; i < nq; ++i) c += idx->stat_host[i];
+      fprintf(stderr, "after round %zu: cumulative candidates %llu\n", r, c);
+    }
   }
   PROQA_HIP(hipMemcpyAsync(idx->overflow_host, idx->overflow, kMaxRounds * sizeof(unsigned),
                            hipMemcpyDeviceToHost, st));
@@ -246,13 +280,14 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   }
 
   PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, idx_offset, D_dev, (long long*)I_dev, st));
-  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, st));
   PROQA_HIP(hipEventRecord(idx->ev[1], st));
   PROQA_HIP(hipStreamSynchronize(st));
 
   idx->stats.rounds = (int)slabs.size();
   idx->stats.fallback_rounds = fallback;
-  idx->stats.candidates = (int64_t)*idx->stat_host;
+  for (int64_t i = 0; i < nq; ++i) idx->stats.candidates += (int64_t)idx->stat_host[i];
   (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
   if (idx->profile) {
     float sum = 0.f;
@@ -262,6 +297,15 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
       sum += ms;
     }
     idx->stats.filter_ms = sum;
+    if (getenv("PROQA_DEBUG_ROUNDS")) {
+      for (size_t r = 0; r < slabs.size(); ++r) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, idx->ev_filter[2 * r], idx->ev_filter[2 * r + 1]);
+        const LaunchGeom g = geometry(slabs[r].r1 - slabs[r].r0, n_qtiles);
+        fprintf(stderr, "round %zu rows [%lld,%lld) grid %u rpc %d filter %.3f ms\n", r, slabs[r].r0, slabs[r].r1,
+                g.grid, g.rows_per_chunk, ms);
+      }
+    }
   }
   return PROQA_OK;
 }
@@ -285,9 +329,7 @@ int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out) {
   PROQA_HIP(hipGetDevice(&idx->device));
   for (auto& e : idx->ev) PROQA_HIP(hipEventCreate(&e));
   PROQA_HIP(hipMalloc((void**)&idx->overflow, kMaxRounds * sizeof(unsigned)));
-  PROQA_HIP(hipMalloc((void**)&idx->stat_dev, sizeof(unsigned long long)));
   PROQA_HIP(hipHostMalloc((void**)&idx->overflow_host, kMaxRounds * sizeof(unsigned), hipHostMallocDefault));
-  PROQA_HIP(hipHostMalloc((void**)&idx->stat_host, sizeof(unsigned long long), hipHostMallocDefault));
   if (capacity_rows > 0) {
     if (int rc = reserve_rows(idx, capacity_rows)) {
       proqa_index_free(idx);
@@ -303,7 +345,8 @@ int proqa_index_free(proqa_index* idx) {
   free_workspace(idx);
   if (idx->xb && idx->owns_xb) (void)hipFree(idx->xb);
   if (idx->overflow) (void)hipFree(idx->overflow);
-  if (idx->stat_dev) (void)hipFree(idx->stat_dev);
+  if (idx->wave_log) (void)hipFree(idx->wave_log);
+  if (idx->wave_log_cnt) (void)hipFree(idx->wave_log_cnt);
   if (idx->overflow_host) (void)hipHostFree(idx->overflow_host);
   if (idx->stat_host) (void)hipHostFree(idx->stat_host);
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
@@ -336,8 +379,8 @@ int proqa_index_ntotal(const proqa_index* idx, int64_t* n) {
 int proqa_index_configure(proqa_index* idx, int cand_capacity, int first_slab_rows, int growth) {
   if (!idx) return fail(PROQA_EINVAL, "index_configure: NULL handle");
   if (cand_capacity) {
-    if (cand_capacity < kStageRows || cand_capacity % kStageRows || cand_capacity >= kMaxSortKeys)
-      return fail(PROQA_EINVAL, "index_configure: capacity must be a multiple of %d below %d", kStageRows, kMaxSortKeys);
+    if (cand_capacity < 2 * kStageRows || cand_capacity >= kMaxSortKeys)
+      return fail(PROQA_EINVAL, "index_configure: capacity must be in [%d, %d)", 2 * kStageRows, kMaxSortKeys);
     idx->cand_capacity = (unsigned)cand_capacity;
   }
   if (first_slab_rows) {

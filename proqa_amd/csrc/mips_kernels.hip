@@ -20,6 +20,7 @@
 //   threshold tightens quickly and later slabs produce only a few candidates per query.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mips_kernels.h"
 
@@ -52,26 +53,97 @@ __device__ __forceinline__ unsigned long long pack_key(float score, unsigned row
 // ---------------------------------------------------------------------------------------
 // filter kernel
 // ---------------------------------------------------------------------------------------
-// Rare path: at least one lane of the wave holds a score that beats its query's threshold.
-// `rel_row0` is laundered through an empty asm so none of this arithmetic is hoisted into the
-// MFMA loop.
-template <bool INCLUSIVE>
-__device__ __forceinline__ void emit_candidates(const f32x16& acc, float tau, int rel_row0, int half,
-                                                int n_rows, unsigned row_begin32, unsigned q,
-                                                const FilterArgs& a) {
-  asm volatile("" : "+v"(rel_row0));
+// Tiling: a workgroup = 8 waves; wave w keeps query blocks (32 queries each) w*QW .. w*QW+QW-1 of
+// its query tile as MFMA B fragments in VGPRs and every wave reads the same corpus sub-tile
+// (32 rows, MFMA A operand) from LDS.  The loop is arranged so that the MFMA pipe always has
+// queued work from a single wave:
+//   * unit = one 32-row sub-tile x QW query blocks (QW independent MFMA chains, interleaved);
+//   * the A fragments of unit g+1 are read from LDS while unit g's chains run;
+//   * the lane-local max-tree + threshold test of unit g-1 sits in the same basic block as unit
+//     g's MFMAs (ONE wave-wide branch per unit, re-tested per tile only on the rare path);
+//   * three LDS stage buffers and ONE barrier per stage placed mid-stage: crossing a stage
+//     boundary needs no barrier, so the fragment prefetch runs straight across it.
+//     At the barrier of stage s (before its unit 2): every wave is past stage s-1, whose buffer
+//     (s+2)%3 is therefore free for DMA(s+2); and every wave has drained (vmcnt 0) its pieces of
+//     DMA(s+1), issued one full stage earlier, so buffer (s+1)%3 is readable from unit 3 on.
+// Candidate records.  A lane whose 16-score column beats its query's threshold appends ONE 80-byte
+// record {query, first row, rows left in the chunk, 16 scores} to its wave's private log in HBM:
+// the slot is the wave's running count (an SGPR) plus the lane's rank among the hit lanes, so the
+// MFMA loop contains no atomics and never waits on memory.  When the wave has finished its chunk it
+// drains its own log (drain_wave_log): one lane per record picks the individual scores that pass
+// and appends them to the per-query candidate lists in HBM.
+__device__ __forceinline__ void append_records(const f32x16& acc, bool hit, float tau, unsigned q, int rel_row0, int half,
+                                               int n_rows, unsigned row_begin32, WaveRecord* wave_log,
+                                               int& log_cnt, const FilterArgs& a) {
+  const unsigned long long mask = __ballot(hit);
+  const int n_hit = __builtin_popcountll(mask);
+  if (log_cnt + n_hit > (int)a.wave_log_cap) {  // wave-uniform
+    *a.overflow = 1u;
+    return;
+  }
+  if (hit) {
+    const int idx = log_cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    const int rel = rel_row0 + 4 * half;
+    uint4* dst = (uint4*)(wave_log + idx);
+    dst[0] = make_uint4(q, row_begin32 + (unsigned)rel, (unsigned)(n_rows - rel), __float_as_uint(tau));
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float s = acc[r];
-    const bool hit = INCLUSIVE ? (s >= tau) : (s > tau);
-    if (hit) {
-      const int rel = rel_row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (rel < n_rows) {  // rows past the chunk end are DMA padding
-        const unsigned slot = atomicAdd(&a.cand_cnt[q], 1u);
-        if (slot < a.cap) {
-          a.cand[(size_t)q * a.cap + slot] = make_uint2(__float_as_uint(s), row_begin32 + (unsigned)rel);
-        } else {
-          *a.overflow = 1u;
+    for (int g = 0; g < 4; ++g)
+      dst[1 + g] = make_uint4(__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1]),
+                              __float_as_uint(acc[4 * g + 2]), __float_as_uint(acc[4 * g + 3]));
+  }
+  log_cnt += n_hit;
+}
+
+// Epilogue of a filter wave: move the survivors of its record log to the per-query candidate
+// lists.  The log only holds the wave's own <= 64 queries, so the survivors are first counted per
+// query in LDS and ONE returning global atomic per query reserves their slots — the per-query
+// counters are shared by every corpus chunk (every XCD), device-scope atomics on them are slow.
+// One lane handles one record at a time (five 16-byte loads in flight per lane).
+template <bool INCLUSIVE>
+__device__ __forceinline__ void drain_wave_log(const WaveRecord* wave_log, int log_cnt, int lane, unsigned q0,
+                                               unsigned* s_cnt, unsigned* s_base, const FilterArgs& a) {
+  if (log_cnt == 0) return;  // wave-uniform
+  s_cnt[lane] = 0;
+  // the records were written by other lanes of this wave: wait until L2 acknowledged the stores
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (int i = lane; i < log_cnt; i += 64) {
+    const uint4* src = (const uint4*)(wave_log + i);
+    const uint4 h = src[0];
+    const float tau = __uint_as_float(h.w);
+    const int rows_left = (int)h.z;
+    unsigned n = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint4 v = src[1 + g];
+      const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        n += ((INCLUSIVE ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) ? 1u : 0u;
+    }
+    if (n) atomicAdd(&s_cnt[h.x - q0], n);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const unsigned mine = s_cnt[lane];
+  s_base[lane] = mine ? atomicAdd(&a.cand_cnt[q0 + lane], mine) : 0u;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  for (int i = lane; i < log_cnt; i += 64) {
+    const uint4* src = (const uint4*)(wave_log + i);
+    const uint4 h = src[0];
+    const float tau = __uint_as_float(h.w);
+    const int rows_left = (int)h.z;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const uint4 v = src[1 + g];
+      const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if ((INCLUSIVE ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
+          const unsigned pos = atomicAdd(&s_base[h.x - q0], 1u);  // LDS: next free slot of this query
+          if (pos < a.cap)
+            a.cand[(size_t)h.x * a.cap + pos] = make_uint2(__float_as_uint(sc[e]), h.y + (unsigned)(e + 8 * g));
+          else
+            *a.overflow = 1u;
         }
       }
     }
@@ -79,19 +151,18 @@ __device__ __forceinline__ void emit_candidates(const f32x16& acc, float tau, in
 }
 
 template <int QW, bool INCLUSIVE>
-__global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) {
-  // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads)
-  __shared__ __attribute__((aligned(16))) char lds[2 * kStageBytes];
+__global__ __launch_bounds__(kFilterThreads) void mips_filter_f16_pipe(FilterArgs a) {
+  static_assert(QW == 1 || QW == 2, "two accumulators per unit");
+  // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads):
+  // three stage buffers, then per wave 2 x 64 counters for the log drain
+  __shared__ __attribute__((aligned(16))) char lds[3 * kStageBytes + kFilterWaves * 512];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31;   // MFMA row/column owned by this lane
-  const int half = lane >> 5; // which 8-wide k slice of each 16-wide k step
+  const int li = lane & 31;
+  const int half = lane >> 5;
 
-  // block -> (xcd, query tile, corpus chunk): the n_qtiles workgroups that stream the same
-  // corpus chunk get consecutive dispatch slots on the same XCD, so the chunk is fetched from
-  // HBM once and re-read from that XCD's L2.
   const unsigned b = blockIdx.x;
   const unsigned xcd = b & 7u;
   const unsigned rest = b >> 3;
@@ -99,7 +170,7 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
   const unsigned grp = rest / a.n_qtiles;
   const long long chunk = (long long)grp * 8 + xcd;
   const long long row_begin = a.slab_row0 + chunk * (long long)a.rows_per_chunk;
-  if (row_begin >= a.slab_row1) return;
+  if (row_begin >= a.slab_row1) return;  // launch padding (the grid is a multiple of 8 chunks)
   long long row_end = row_begin + a.rows_per_chunk;
   if (row_end > a.slab_row1) row_end = a.slab_row1;
   const int n_rows = (int)(row_end - row_begin);
@@ -107,11 +178,13 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
   const unsigned row_begin32 = (unsigned)row_begin;
   const char* chunk_base = a.xb + row_begin * kRowBytes;
 
-  // resident query fragments (MFMA B operand): lane (li, half), k-step j holds the 16-byte
-  // chunk 2j+half of query row q0 + blk*32 + li.
+  const unsigned wave_slot = blockIdx.x * kFilterWaves + wave;
+  WaveRecord* wave_log = a.wave_log + (size_t)wave_slot * a.wave_log_cap;
+  int log_cnt = 0;  // wave-uniform
+
   const unsigned q0 = qt * (kFilterWaves * QW * 32) + wave * (QW * 32);
   f16x8 qf[QW][8];
-  float tau[QW];
+  float tau[2] = {0.f, 0.f};
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk) {
     const char* qrow = (const char*)a.xq + (size_t)(q0 + blk * 32 + li) * kRowBytes;
@@ -120,15 +193,10 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
     tau[blk] = a.tau[q0 + blk * 32 + li];
   }
 
-  // LDS read offsets of this lane's corpus fragment (MFMA A operand): row li of a 32-row
-  // sub-tile, chunk 2j+half stored at slot (2j+half) ^ (li & 15).
   unsigned rd_off[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) rd_off[j] = li * kRowBytes + (((2 * j + half) ^ (li & 15)) << 4);
 
-  // LDS-DMA: per stage each wave issues 4 instructions of 1 KiB (4 corpus rows); lane t lands
-  // at base + 16 t = (row t>>4, slot t&15) and therefore fetches chunk (t&15) ^ (row&15).
-  // Rows past the chunk end re-read the chunk's last row (never emitted: rel >= n_rows).
   const int dma_row = lane >> 4;
   const int dma_slot = lane & 15;
   int dma_rel[4];
@@ -138,60 +206,101 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
     dma_rel[e] = (wave * 4 + e) * 4 + dma_row;
     dma_chunk_off[e] = (dma_slot ^ ((e * 4 + dma_row) & 15)) * 16;
   }
-
-  auto issue_stage = [&](int s) {
-    char* buf = lds + (s & 1) * kStageBytes;
+  auto issue_stage = [&](int s, int buf_off) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int rel = s * kStageRows + dma_rel[e];
       rel = rel < n_rows ? rel : n_rows - 1;
       const char* src = chunk_base + (long long)rel * kRowBytes + dma_chunk_off[e];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(buf + (wave * 4 + e) * 1024),
+                                       (__attribute__((address_space(3))) void*)(lds + buf_off + (wave * 4 + e) * 1024),
                                        16, 0, 0);
     }
   };
+  constexpr int kSubs = kStageRows / kSubRows;  // 4 units per stage
+  // rotating LDS offsets of stage s, s+1, s+2
+  int off0 = 0, off1 = kStageBytes, off2 = 2 * kStageBytes;
+  issue_stage(0, off0);
+  if (nstages > 1) issue_stage(1, off1);
+  __syncthreads();  // prologue only: both stages landed
 
-  constexpr int kSubs = kStageRows / kSubRows;
-  issue_stage(0);
+  // A fragments live in ONE register set: k-steps 0-3 of the next unit are re-loaded right after
+  // the current unit's k-steps 0-3 were consumed, k-steps 4-7 after its last MFMA.
+  f16x8 af[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(lds + off0 + rd_off[j]);
+  f32x16 pend[2] = {{0}, {0}};
+  int pend_rel0 = -1;  // no pending unit yet
+
   for (int s = 0; s < nstages; ++s) {
-    // vmcnt(0) + s_barrier: this wave's DMA pieces of stage s (issued one full stage ago) have
-    // landed, and every wave has finished reading the buffer stage s+1 is about to overwrite.
-    __syncthreads();
-    if (s + 1 < nstages) issue_stage(s + 1);
-
-    const char* buf = lds + (s & 1) * kStageBytes;
-    const int stage_rel0 = s * kStageRows;
-
-    // software pipeline: the lane-local filter of tile t runs under the MFMA chain of tile t+1
-    f32x16 pend = {0};
 #pragma unroll
-    for (int t = 0; t <= kSubs * QW; ++t) {
-      f32x16 acc = {0};
-      if (t < kSubs * QW) {
-        const int sub = t / QW, blk = t % QW;
-        f16x8 af[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(buf + sub * kSubBytes + rd_off[j]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[blk][j], acc, 0, 0, 0);
+    for (int u = 0; u < kSubs; ++u) {
+      if (u == 2) {
+        __syncthreads();
+        if (s + 2 < nstages) issue_stage(s + 2, off2);
       }
-      if (t > 0) {
-        const int sub = (t - 1) / QW, blk = (t - 1) % QW;
-        // lane-local top-k test: this lane holds 16 corpus rows of ONE query
-        float m = pend[0];
+      // where the next unit's fragments live (next stage's buffer after the last unit)
+      const char* nxt = (u + 1 < kSubs) ? lds + off0 + (u + 1) * kSubBytes : lds + off1;
+
+      f32x16 cur[2] = {{0}, {0}};
 #pragma unroll
-        for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[r]);
-        const bool any_hit = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
-        if (__builtin_expect(__any(any_hit), 0)) {
-          emit_candidates<INCLUSIVE>(pend, tau[blk], stage_rel0 + sub * kSubRows, half, n_rows,
-                                     row_begin32, q0 + blk * 32 + li, a);
-        }
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk)
+          cur[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[blk][j], cur[blk], 0, 0, 0);
       }
-      pend = acc;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = *(const f16x8*)(nxt + rd_off[j]);
+#pragma unroll
+      for (int j = 4; j < 8; ++j) {
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk)
+          cur[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[blk][j], cur[blk], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 4; j < 8; ++j) af[j] = *(const f16x8*)(nxt + rd_off[j]);
+
+      // lane-local test of the PREVIOUS unit, scheduled under the MFMAs just issued
+      bool hit[2] = {false, false};
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk) {
+        float m = pend[blk][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
+        hit[blk] = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
+      }
+      if (__builtin_expect(__any((hit[0] || hit[1]) && pend_rel0 >= 0), 0)) {
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk)
+          if (__any(hit[blk]))
+            append_records(pend[blk], hit[blk], tau[blk], q0 + blk * 32 + li, pend_rel0, half, n_rows, row_begin32,
+                           wave_log, log_cnt, a);
+      }
+
+      pend[0] = cur[0];
+      pend[1] = cur[1];
+      pend_rel0 = s * kStageRows + u * kSubRows;
+    }
+    const int t = off0;
+    off0 = off1;
+    off1 = off2;
+    off2 = t;
+  }
+  // drain the last unit
+  {
+#pragma unroll
+    for (int blk = 0; blk < QW; ++blk) {
+      float m = pend[blk][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
+      const bool hit = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
+      if (__any(hit))
+        append_records(pend[blk], hit, tau[blk], q0 + blk * 32 + li, pend_rel0, half, n_rows, row_begin32, wave_log,
+                       log_cnt, a);
     }
   }
+  unsigned* s_cnt = (unsigned*)(lds + 3 * kStageBytes + wave * 512);
+  drain_wave_log<INCLUSIVE>(wave_log, log_cnt, lane, q0, s_cnt, s_cnt + 64, a);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -220,6 +329,28 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
     keys[i] = key;
   }
   __syncthreads();
+
+  if (!a.dedupe) {
+    // Keys are distinct (one per corpus row), so the rank of a key = number of larger keys, and
+    // the keys of rank < k ARE the new running list, already in order.  Every thread scans the
+    // whole LDS array (broadcast reads, no barriers) instead of sorting it.
+    const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
+    for (unsigned i = tid; i < total; i += kMergeThreads) {
+      const unsigned long long mine = keys[i];
+      unsigned rank = 0;
+      for (unsigned j = 0; j < total; ++j) rank += keys[j] > mine ? 1u : 0u;
+      if (rank < keep) {
+        a.run_keys[(size_t)q * a.k + rank] = mine;
+        if (rank == (unsigned)a.k - 1) a.tau[q] = float_from_ord((unsigned)(mine >> 32));
+      }
+    }
+    if (tid == 0) {
+      a.run_n[q] = keep;
+      a.cand_cnt[q] = 0;
+      a.stat_candidates[q] += raw_cnt;  // one block per query: no contention
+    }
+    return;
+  }
 
   for (unsigned size = 2; size <= P; size <<= 1) {
     for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
@@ -258,7 +389,7 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
     if (tid == 0) {
       a.tau[q] = keep == (unsigned)a.k ? float_from_ord((unsigned)(keys[a.k - 1] >> 32)) : -__builtin_inff();
       a.cand_cnt[q] = 0;
-      atomicAdd(a.stat_candidates, (unsigned long long)raw_cnt);
+      a.stat_candidates[q] += raw_cnt;  // one block per query: no contention
     }
     return;
   }
@@ -269,7 +400,7 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
     a.run_n[q] = keep;
     a.tau[q] = keep == (unsigned)a.k ? float_from_ord((unsigned)(keys[a.k - 1] >> 32)) : -__builtin_inff();
     a.cand_cnt[q] = 0;
-    atomicAdd(a.stat_candidates, (unsigned long long)raw_cnt);
+    a.stat_candidates[q] += raw_cnt;  // one block per query: no contention
   }
 }
 
@@ -278,7 +409,8 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
 // ---------------------------------------------------------------------------------------
 // pad + convert queries to the fp16 [Qpad,128] operand layout, reset per-query state
 __global__ void prep_queries(const void* xq, int dtype, long long nq, long long nq_pad,
-                             _Float16* xq_pad, float* tau, unsigned* cand_cnt, unsigned* run_n) {
+                             _Float16* xq_pad, float* tau, unsigned* cand_cnt, unsigned* run_n,
+                             unsigned long long* stat, int debug_nohit) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = nq_pad * kDim;
   if (i < n) {
@@ -288,9 +420,10 @@ __global__ void prep_queries(const void* xq, int dtype, long long nq, long long 
     xq_pad[i] = (_Float16)v;
   }
   if (i < nq_pad) {
-    tau[i] = i < nq ? -__builtin_inff() : __builtin_inff();  // padded queries never emit
+    tau[i] = (i < nq && !debug_nohit) ? -__builtin_inff() : __builtin_inff();  // padded queries never emit
     cand_cnt[i] = 0;
     run_n[i] = 0;
+    stat[i] = 0;
   }
 }
 
@@ -384,14 +517,14 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
   dim3 g(grid), blk(kFilterThreads);
   if (qw == 2) {
     if (inclusive)
-      hipLaunchKernelGGL((mips_filter_f16<2, true>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16_pipe<2, true>), g, blk, 0, st, a);
     else
-      hipLaunchKernelGGL((mips_filter_f16<2, false>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16_pipe<2, false>), g, blk, 0, st, a);
   } else {
     if (inclusive)
-      hipLaunchKernelGGL((mips_filter_f16<1, true>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16_pipe<1, true>), g, blk, 0, st, a);
     else
-      hipLaunchKernelGGL((mips_filter_f16<1, false>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16_pipe<1, false>), g, blk, 0, st, a);
   }
   return hipGetLastError();
 }
@@ -406,10 +539,11 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
 }
 
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
-                               float* tau, unsigned* cand_cnt, unsigned* run_n, hipStream_t st) {
+                               float* tau, unsigned* cand_cnt, unsigned* run_n, unsigned long long* stat,
+                               hipStream_t st) {
   const long long n = nq_pad * kDim;
   hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq,
-                     nq_pad, (_Float16*)xq_pad, tau, cand_cnt, run_n);
+                     nq_pad, (_Float16*)xq_pad, tau, cand_cnt, run_n, stat, getenv("PROQA_DEBUG_NOHIT") ? 1 : 0);
   return hipGetLastError();
 }
 
