@@ -97,8 +97,9 @@ typedef struct proqa_search_stats {
 int proqa_index_last_stats(const proqa_index* idx, proqa_search_stats* out);
 /* bracket every mips_filter launch with HIP events on the search stream (bench.py roofline) */
 int proqa_index_set_profiling(proqa_index* idx, int enable);
-/* tuning knobs (0 keeps the default): candidate capacity per query per round, slab growth */
-int proqa_index_configure(proqa_index* idx, int cand_capacity, int first_slab_rows, int growth);
+/* tuning knobs of the round schedule (0 keeps the default): rows of the first slab (scanned with
+ * threshold -inf) and the growth factor of the following slabs */
+int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
  * (the layout an RCCL all-gather of per-rank [nq, k] produces).  Same ordering rule. */

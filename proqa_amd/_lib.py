@@ -58,7 +58,7 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p]),
     "proqa_index_last_stats": (c_int, [c_void_p, ctypes.POINTER(SearchStats)]),
     "proqa_index_set_profiling": (c_int, [c_void_p, c_int]),
-    "proqa_index_configure": (c_int, [c_void_p, c_int, c_int, c_int]),
+    "proqa_index_configure": (c_int, [c_void_p, c_int, c_int]),
     "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p]),
     "proqa_embed_layernorm_f16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64,

@@ -37,16 +37,17 @@ struct proqa_index {
   // search workspace (grown on demand)
   int64_t ws_nq_pad = 0;
   int ws_k = 0;
-  unsigned ws_cap = 0;
   void* xq_pad = nullptr;
   float* tau = nullptr;
-  unsigned* cand_cnt = nullptr;
   unsigned* run_n = nullptr;
-  uint2* cand = nullptr;
   unsigned long long* run_keys = nullptr;
-  proqa::WaveRecord* wave_log = nullptr;   // per-wave candidate records of one filter launch
-  unsigned* wave_log_cnt = nullptr;
-  unsigned wave_log_slots = 0;             // waves the log is sized for
+  // candidate records of one filter launch (see CandidateStore in mips_kernels.h)
+  proqa::WaveRecord* lane_log = nullptr;
+  unsigned* lane_cnt = nullptr;
+  proqa::WaveRecord* spill_log = nullptr;
+  unsigned* spill_cnt = nullptr;
+  unsigned store_chunks = 0;               // chunks the store is sized for (at ws_nq_pad queries)
+  unsigned store_qtiles = 0;
   unsigned* overflow = nullptr;            // [kMaxRounds] device
   unsigned* overflow_host = nullptr;       // pinned mirror
   unsigned long long* stat_dev = nullptr;  // [ws_nq_pad] candidates per query (part of the workspace)
@@ -59,7 +60,6 @@ struct proqa_index {
   hipEvent_t ev_filter[2 * 64] = {};       // per-round brackets, created when profiling is on
   bool profile = false;
   // tuning
-  unsigned cand_capacity = 944;   // k=80 + 944 = one 1024-key LDS sort per query
   int first_slab_rows = 256;
   int growth = 4;
   proqa_search_stats stats = {};
@@ -105,52 +105,63 @@ int ensure_stage(proqa_index* idx, size_t bytes) {
   return PROQA_OK;
 }
 
+void free_store(proqa_index* idx) {
+  void* ptrs[] = {idx->lane_log, idx->lane_cnt, idx->spill_log, idx->spill_cnt};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  idx->lane_log = nullptr;
+  idx->lane_cnt = nullptr;
+  idx->spill_log = nullptr;
+  idx->spill_cnt = nullptr;
+  idx->store_chunks = 0;
+  idx->store_qtiles = 0;
+}
+
 void free_workspace(proqa_index* idx) {
-  void* ptrs[] = {idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n, idx->cand, idx->run_keys, idx->stat_dev};
-  idx->stat_dev = nullptr;
+  void* ptrs[] = {idx->xq_pad, idx->tau, idx->run_n, idx->run_keys, idx->stat_dev};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   idx->xq_pad = nullptr;
   idx->tau = nullptr;
-  idx->cand_cnt = nullptr;
   idx->run_n = nullptr;
-  idx->cand = nullptr;
   idx->run_keys = nullptr;
+  idx->stat_dev = nullptr;
   idx->ws_nq_pad = 0;
   idx->ws_k = 0;
-  idx->ws_cap = 0;
+  free_store(idx);
 }
 
-int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k, unsigned cap) {
-  if (nq_pad <= idx->ws_nq_pad && k <= idx->ws_k && cap == idx->ws_cap) return PROQA_OK;
-  free_workspace(idx);
+int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
+  if (nq_pad <= idx->ws_nq_pad && k <= idx->ws_k) return PROQA_OK;
   const int64_t q = std::max(nq_pad, idx->ws_nq_pad);
+  const int kk = std::max(k, idx->ws_k);
+  free_workspace(idx);
   PROQA_HIP(hipMalloc(&idx->xq_pad, (size_t)q * kDim * 2));
   PROQA_HIP(hipMalloc((void**)&idx->tau, (size_t)q * sizeof(float)));
-  PROQA_HIP(hipMalloc((void**)&idx->cand_cnt, (size_t)q * sizeof(unsigned)));
   PROQA_HIP(hipMalloc((void**)&idx->run_n, (size_t)q * sizeof(unsigned)));
-  PROQA_HIP(hipMalloc((void**)&idx->cand, (size_t)q * cap * sizeof(uint2)));
-  PROQA_HIP(hipMalloc((void**)&idx->run_keys, (size_t)q * k * sizeof(unsigned long long)));
+  PROQA_HIP(hipMalloc((void**)&idx->run_keys, (size_t)q * kk * sizeof(unsigned long long)));
   PROQA_HIP(hipMalloc((void**)&idx->stat_dev, (size_t)q * sizeof(unsigned long long)));
   if (idx->stat_host) PROQA_HIP(hipHostFree(idx->stat_host));
+  idx->stat_host = nullptr;
   PROQA_HIP(hipHostMalloc((void**)&idx->stat_host, (size_t)q * sizeof(unsigned long long), hipHostMallocDefault));
   idx->ws_nq_pad = q;
-  idx->ws_k = k;
-  idx->ws_cap = cap;
+  idx->ws_k = kk;
   return PROQA_OK;
 }
 
-int ensure_wave_log(proqa_index* idx, unsigned slots) {
-  if (slots <= idx->wave_log_slots) return PROQA_OK;
-  if (idx->wave_log) PROQA_HIP(hipFree(idx->wave_log));
-  if (idx->wave_log_cnt) PROQA_HIP(hipFree(idx->wave_log_cnt));
-  idx->wave_log = nullptr;
-  idx->wave_log_cnt = nullptr;
-  idx->wave_log_slots = 0;
-  PROQA_HIP(hipMalloc((void**)&idx->wave_log, (size_t)slots * kWaveLogCap * sizeof(WaveRecord)));
-  PROQA_HIP(hipMalloc((void**)&idx->wave_log_cnt, (size_t)slots * sizeof(unsigned)));
-  PROQA_HIP(hipMemset(idx->wave_log_cnt, 0, (size_t)slots * sizeof(unsigned)));
-  idx->wave_log_slots = slots;
+// candidate store for launches of up to `chunks` corpus chunks x `n_qtiles` query tiles
+int ensure_store(proqa_index* idx, unsigned chunks, unsigned n_qtiles, int64_t nq_pad) {
+  if (chunks <= idx->store_chunks && n_qtiles == idx->store_qtiles) return PROQA_OK;
+  const unsigned c = std::max(chunks, idx->store_chunks);
+  free_store(idx);
+  const size_t lists = (size_t)c * nq_pad * 2;
+  const size_t slots = (size_t)c * n_qtiles * kFilterWaves;
+  PROQA_HIP(hipMalloc((void**)&idx->lane_log, lists * kLaneCap * sizeof(WaveRecord)));
+  PROQA_HIP(hipMalloc((void**)&idx->lane_cnt, lists * sizeof(unsigned)));
+  PROQA_HIP(hipMalloc((void**)&idx->spill_log, slots * kSpillCap * sizeof(WaveRecord)));
+  PROQA_HIP(hipMalloc((void**)&idx->spill_cnt, slots * sizeof(unsigned)));
+  idx->store_chunks = c;
+  idx->store_qtiles = n_qtiles;
   return PROQA_OK;
 }
 
@@ -172,51 +183,61 @@ std::vector<Slab> plan_slabs(long long n, int first, int growth) {
 
 struct LaunchGeom {
   int rows_per_chunk;
-  unsigned grid;
+  unsigned chunks;   // chunks that scan rows
+  unsigned grid;     // workgroups launched (chunks padded to a multiple of 8, times n_qtiles)
 };
 
-LaunchGeom geometry(long long slab_rows, unsigned n_qtiles) {
+LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage) {
   const int cus = device_cu_count();
   // one workgroup per CU: target_chunks * n_qtiles ~= #CUs, chunks a multiple of 8 (XCD map)
   long long target = std::max<long long>(8, (cus / (long long)n_qtiles) / 8 * 8);
   long long rpc = round_up<long long>(ceil_div<long long>(slab_rows, target), kStageRows);
-  long long chunks = round_up<long long>(ceil_div<long long>(slab_rows, rpc), 8);
-  return {(int)rpc, (unsigned)(chunks * n_qtiles)};
+  // dense launches (threshold -inf, or the inclusive overflow-safe re-scan) log EVERY tile: a lane
+  // list holds exactly one stage of them (kLaneCap = 8 tiles), so each chunk is one stage
+  if (single_stage) rpc = kStageRows;
+  const long long chunks = ceil_div<long long>(slab_rows, rpc);
+  return {(int)rpc, (unsigned)chunks, (unsigned)(round_up<long long>(chunks, 8) * n_qtiles)};
+}
+
+CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtiles) {
+  CandidateStore st;
+  st.lane_log = idx->lane_log;
+  st.lane_cnt = idx->lane_cnt;
+  st.spill_log = idx->spill_log;
+  st.spill_cnt = idx->spill_cnt;
+  st.nq_pad = nq_pad;
+  st.n_qtiles = n_qtiles;
+  return st;
 }
 
 int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
-              bool inclusive, unsigned* overflow_word, hipStream_t st, hipEvent_t f0, hipEvent_t f1) {
+              bool inclusive, bool dense, unsigned* overflow_word, hipStream_t st, hipEvent_t f0, hipEvent_t f1) {
+  const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense);
+  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad)) return rc;
   FilterArgs fa;
   fa.xq = idx->xq_pad;
   fa.xb = idx->xb;
   fa.slab_row0 = slab.r0;
   fa.slab_row1 = slab.r1;
-  const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles);
   fa.rows_per_chunk = g.rows_per_chunk;
-  fa.n_qtiles = n_qtiles;
   fa.tau = idx->tau;
-  fa.cand_cnt = idx->cand_cnt;
-  fa.cand = idx->cand;
-  fa.cap = idx->ws_cap;
+  fa.store = store_of(idx, (unsigned)idx->ws_nq_pad, n_qtiles);
   fa.overflow = overflow_word;
-  if (int rc = ensure_wave_log(idx, g.grid * kFilterWaves)) return rc;
-  fa.wave_log = idx->wave_log;
-  fa.wave_log_cnt = idx->wave_log_cnt;
-  fa.wave_log_cap = kWaveLogCap;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
   PROQA_HIP(launch_filter(fa, qw, inclusive, g.grid, st));
   if (f1) PROQA_HIP(hipEventRecord(f1, st));
 
   MergeArgs ma;
-  ma.cand = idx->cand;
-  ma.cand_cnt = idx->cand_cnt;
-  ma.cap = idx->ws_cap;
+  ma.store = fa.store;
+  ma.n_chunks = g.chunks;
+  ma.qw = (unsigned)qw;
   ma.run_keys = idx->run_keys;
   ma.run_n = idx->run_n;
   ma.tau = idx->tau;
   ma.k = k;
-  ma.dedupe = inclusive ? 1 : 0;
+  ma.inclusive = inclusive ? 1 : 0;
   ma.stat_candidates = idx->stat_dev;
+  ma.overflow = overflow_word;
   PROQA_HIP(launch_merge(ma, nq_pad, st));
   return PROQA_OK;
 }
@@ -225,10 +246,8 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
                   float* D_dev, int64_t* I_dev, hipStream_t st) {
   if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
   if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "search: bad dtype %d", dtype);
-  const unsigned cap = idx->cand_capacity;
-  if ((long long)k + cap > kMaxSortKeys)
-    return fail(PROQA_EINVAL, "search: k=%d + candidate capacity %u exceeds %d (large-k search not built yet)",
-                k, cap, kMaxSortKeys);
+  if (k > kMaxSortKeys / 2)
+    return fail(PROQA_EINVAL, "search: k=%d exceeds %d (large-k search is not built yet)", k, kMaxSortKeys / 2);
   if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
   idx->stats = {};
   if (nq == 0) return PROQA_OK;
@@ -239,19 +258,22 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   const unsigned tile_q = kFilterWaves * qw * 32;
   const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
   const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
-  if (int rc = ensure_workspace(idx, nq_pad, k, cap)) return rc;
+  if (int rc = ensure_workspace(idx, nq_pad, k)) return rc;
 
   PROQA_HIP(hipEventRecord(idx->ev[0], st));
   PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
-  PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, nq_pad, idx->xq_pad, idx->tau, idx->cand_cnt, idx->run_n,
-                                idx->stat_dev, st));
+  PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
+                                st));
 
-  std::vector<Slab> slabs = plan_slabs(idx->n, idx->first_slab_rows, idx->growth);
+  // every row of the first slab is a candidate (threshold -inf): it must fit one merge pass
+  const int first = std::min<int>(idx->first_slab_rows, (kMaxSortKeys - k) / kStageRows * kStageRows);
+  std::vector<Slab> slabs = plan_slabs(idx->n, first, idx->growth);
   if ((int)slabs.size() > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
   for (size_t r = 0; r < slabs.size(); ++r) {
     hipEvent_t f0 = idx->profile ? idx->ev_filter[2 * r] : nullptr;
     hipEvent_t f1 = idx->profile ? idx->ev_filter[2 * r + 1] : nullptr;
-    if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, k, false, idx->overflow + r, st, f0, f1))
+    if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, k, false, r == 0, idx->overflow + r, st,
+                           f0, f1))
       return rc;
     if (getenv("PROQA_DEBUG_CAND")) {
       (void)hipStreamSynchronize(st);
@@ -268,11 +290,12 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   int fallback = 0;
   for (size_t r = 0; r < slabs.size(); ++r) {
     if (!idx->overflow_host[r]) continue;
-    // overflow-safe re-scan: sub-slabs can never overflow (rows <= capacity)
-    const long long step = (long long)(cap / kStageRows) * kStageRows;
+    // overflow-safe re-scan: a sub-slab has fewer rows than one merge pass holds keys and every
+    // chunk is a single stage, so neither the lane lists nor the merge can overflow
+    const long long step = (long long)((kMaxSortKeys - k) / kStageRows) * kStageRows;
     for (long long r0 = slabs[r].r0; r0 < slabs[r].r1; r0 += step) {
       Slab sub{r0, std::min(slabs[r].r1, r0 + step)};
-      if (int rc = run_round(idx, sub, qw, n_qtiles, (unsigned)nq_pad, k, true, idx->overflow + kMaxRounds - 1,
+      if (int rc = run_round(idx, sub, qw, n_qtiles, (unsigned)nq_pad, k, true, true, idx->overflow + kMaxRounds - 1,
                              st, nullptr, nullptr))
         return rc;
       ++fallback;
@@ -301,7 +324,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
       for (size_t r = 0; r < slabs.size(); ++r) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, idx->ev_filter[2 * r], idx->ev_filter[2 * r + 1]);
-        const LaunchGeom g = geometry(slabs[r].r1 - slabs[r].r0, n_qtiles);
+        const LaunchGeom g = geometry(slabs[r].r1 - slabs[r].r0, n_qtiles, r == 0);
         fprintf(stderr, "round %zu rows [%lld,%lld) grid %u rpc %d filter %.3f ms\n", r, slabs[r].r0, slabs[r].r1,
                 g.grid, g.rows_per_chunk, ms);
       }
@@ -345,8 +368,6 @@ int proqa_index_free(proqa_index* idx) {
   free_workspace(idx);
   if (idx->xb && idx->owns_xb) (void)hipFree(idx->xb);
   if (idx->overflow) (void)hipFree(idx->overflow);
-  if (idx->wave_log) (void)hipFree(idx->wave_log);
-  if (idx->wave_log_cnt) (void)hipFree(idx->wave_log_cnt);
   if (idx->overflow_host) (void)hipHostFree(idx->overflow_host);
   if (idx->stat_host) (void)hipHostFree(idx->stat_host);
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
@@ -376,23 +397,11 @@ int proqa_index_ntotal(const proqa_index* idx, int64_t* n) {
   return PROQA_OK;
 }
 
-int proqa_index_configure(proqa_index* idx, int cand_capacity, int first_slab_rows, int growth) {
+int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth) {
   if (!idx) return fail(PROQA_EINVAL, "index_configure: NULL handle");
-  if (cand_capacity) {
-    if (cand_capacity < 2 * kStageRows || cand_capacity >= kMaxSortKeys)
-      return fail(PROQA_EINVAL, "index_configure: capacity must be in [%d, %d)", 2 * kStageRows, kMaxSortKeys);
-    idx->cand_capacity = (unsigned)cand_capacity;
-  }
-  if (first_slab_rows) {
-    if (first_slab_rows < 0) return fail(PROQA_EINVAL, "index_configure: first_slab_rows < 0");
-    idx->first_slab_rows = first_slab_rows;
-  }
-  if (growth) {
-    if (growth < 1) return fail(PROQA_EINVAL, "index_configure: growth < 1");
-    idx->growth = growth;
-  }
-  // the first slab runs with threshold -inf: every row is a candidate
-  idx->first_slab_rows = std::min<int>(idx->first_slab_rows, (int)idx->cand_capacity);
+  if (first_slab_rows < 0 || growth < 0) return fail(PROQA_EINVAL, "index_configure: negative argument");
+  if (first_slab_rows) idx->first_slab_rows = first_slab_rows;
+  if (growth) idx->growth = growth;
   return PROQA_OK;
 }
 

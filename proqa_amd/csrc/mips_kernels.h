@@ -12,9 +12,14 @@ constexpr int kFilterWaves = 8;
 constexpr int kFilterThreads = kFilterWaves * 64;
 constexpr int kStageRows = 128;  // corpus rows per LDS stage (32 KiB of fp16 rows)
 constexpr int kMergeThreads = 256;
-constexpr int kMaxSortKeys = 4096;  // k + candidate capacity must fit one LDS sort
+constexpr int kMaxSortKeys = 2048;  // running list + candidates of one query per merge (LDS)
+constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling
+constexpr int kSpillCap = 256;      // shared spill records per (chunk, wave)
+constexpr int kMaxListParts = 4096; // n_parts * k bound of proqa_topk_merge_device
 
-// one lane's 16-score accumulator column that beat its query's threshold (see mips_kernels.hip)
+// One lane's 16-score accumulator column that beat its query's threshold.  The filter kernel
+// logs whole columns (one 80-byte store burst, no per-score work in the MFMA loop); the merge
+// kernel picks the individual scores that pass.
 struct __attribute__((aligned(16))) WaveRecord {
   unsigned q;          // query index (padded numbering)
   unsigned row0;       // shard-local corpus row of score[0]
@@ -24,41 +29,49 @@ struct __attribute__((aligned(16))) WaveRecord {
 };
 static_assert(sizeof(WaveRecord) == 80, "record layout");
 
+// Candidate storage of one filter launch (all written without atomics):
+//   lane_log [chunk][q][half][kLaneCap]  private list of the lane that owns (q, half) in `chunk`
+//   lane_cnt [chunk][q][half]            its length
+//   spill_log[chunk][wave slot][kSpillCap], spill_cnt[chunk][wave slot]
+//                                         shared by the 64 lanes of a wave once a private list is full
+// wave slot = (query tile, wave) = the 32*QW consecutive queries one wave owns.
+struct CandidateStore {
+  WaveRecord* lane_log;
+  unsigned* lane_cnt;
+  WaveRecord* spill_log;
+  unsigned* spill_cnt;
+  unsigned nq_pad;
+  unsigned n_qtiles;
+};
+
 struct FilterArgs {
   const void* xq;        // fp16 [nq_pad,128], zero rows beyond nq
   const char* xb;        // fp16 corpus rows of this shard
   long long slab_row0;   // rows [slab_row0, slab_row1) are scanned by this launch
   long long slab_row1;
   int rows_per_chunk;    // multiple of kStageRows; one workgroup per (chunk, query tile)
-  unsigned n_qtiles;
   const float* tau;      // running k-th best score per query (-inf until k rows were seen)
-  unsigned* cand_cnt;    // per-query append counter
-  uint2* cand;           // [nq_pad, cap] (score bits, shard-local row)
-  unsigned cap;
-  unsigned* overflow;    // set to 1 if any append was dropped in this launch
-  WaveRecord* wave_log;         // [grid * 8 waves, wave_log_cap] private candidate records
-  unsigned* wave_log_cnt;       // records written by each wave of this launch
-  unsigned wave_log_cap;
+  CandidateStore store;
+  unsigned* overflow;    // set to 1 if a record had to be dropped in this launch
 };
-constexpr int kWaveLogCap = 816;   // records per wave (~64 KiB): > 512 = one dense stage (8 tiles x 64 lanes)
 
 struct MergeArgs {
-  uint2* cand;
-  unsigned* cand_cnt;
-  unsigned cap;
+  CandidateStore store;
+  unsigned n_chunks;             // chunks of the filter launch that scanned rows
+  unsigned qw;                   // query blocks per wave of that launch
   unsigned long long* run_keys;  // [nq_pad, k] sorted descending
   unsigned* run_n;               // valid entries per query
   float* tau;
   int k;
-  int dedupe;
+  int inclusive;                 // overflow-safe rounds: >= threshold, duplicates removed
   unsigned long long* stat_candidates;  // [nq_pad] candidates merged per query (statistics)
+  unsigned* overflow;
 };
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st);
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
-                               float* tau, unsigned* cand_cnt, unsigned* run_n, unsigned long long* stat,
-                               hipStream_t st);
+                               float* tau, unsigned* run_n, unsigned long long* stat, hipStream_t st);
 hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int k,
                            long long idx_offset, float* D, long long* I, hipStream_t st);
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,

@@ -3,19 +3,21 @@
 // Replaces faiss.IndexFlatIP.search at /root/reference/retrieval/eval_retrieval.py:102-104.
 //
 // Structure (gfx950 / CDNA4, wave64):
-//   mips_filter_f16   Q.P^T on MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) with the
-//                     score matrix never leaving registers.  A workgroup of 8 waves keeps
-//                     8*QW*32 queries as MFMA B-fragments in VGPRs for its whole lifetime and
-//                     streams a contiguous chunk of corpus rows through a 2x32 KiB LDS ring
-//                     filled by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction,
-//                     XOR-swizzled on the SOURCE address so ds_read_b128 is conflict-free).
-//                     Each lane owns one query column of the 32x32 accumulator, so the top-k
-//                     test is lane-local: max of 16 scores vs. the query's running threshold,
-//                     one wave-wide branch; survivors are appended to a per-query candidate
-//                     list in HBM.
-//   topk_merge        one workgroup per query: bitonic-sorts running top-k + candidates by
-//                     (score desc, row asc) in LDS, keeps the best k, publishes the k-th
-//                     score as the next round's threshold.
+//   mips_filter_f16   Q.P^T on MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) with the score
+//                     matrix never leaving registers.  A workgroup of 8 waves keeps 8*QW*32
+//                     queries as MFMA B fragments in VGPRs for its whole lifetime and streams a
+//                     contiguous chunk of corpus rows through a 3 x 32 KiB LDS ring filled by
+//                     LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, XOR-swizzled
+//                     on the SOURCE address so ds_read_b128 is conflict-free).  Each lane owns one
+//                     query column of the 32x32 accumulator, so the top-k test is lane-local: max
+//                     of 16 scores vs. the query's running threshold and one wave-wide branch per
+//                     32-row unit.  A lane that passes logs its whole 16-score column as one
+//                     80-byte record into a list it owns in HBM: no atomics, no per-score work and
+//                     no memory wait inside the MFMA loop.
+//   topk_merge        one workgroup per query gathers the query's records (its own lists in every
+//                     chunk + the shared spill logs), keeps the scores that pass, and selects the
+//                     best k of {running list, survivors} by (score desc, row asc); publishes the
+//                     k-th score as the next round's threshold.
 //   The host (mips_index.cpp) runs rounds over geometrically growing corpus slabs so the
 //   threshold tightens quickly and later slabs produce only a few candidates per query.
 #include <hip/hip_runtime.h>
@@ -50,126 +52,93 @@ __device__ __forceinline__ unsigned long long pack_key(float score, unsigned row
   return ((unsigned long long)ord_from_float(score) << 32) | (unsigned long long)(0xFFFFFFFFu - row);
 }
 
+__device__ __forceinline__ size_t lane_list_index(const CandidateStore& st, unsigned chunk, unsigned q, int half) {
+  return ((size_t)chunk * st.nq_pad + q) * 2 + half;
+}
+
 // ---------------------------------------------------------------------------------------
 // filter kernel
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void write_record(WaveRecord* dst, const f32x16& acc, unsigned q, unsigned row0,
+                                             int rows_left, float tau) {
+  uint4* d = (uint4*)dst;
+  d[0] = make_uint4(q, row0, (unsigned)rows_left, __float_as_uint(tau));
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    d[1 + g] = make_uint4(__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1]),
+                          __float_as_uint(acc[4 * g + 2]), __float_as_uint(acc[4 * g + 3]));
+}
+
+// Rare path of one 32x32 tile: every hit lane appends its column to the list it owns; a lane
+// whose list is full falls back to the wave's shared spill log (slot = running count + rank of
+// the lane among the spilling lanes).
+__device__ __forceinline__ void log_columns(const f32x16& acc, bool hit, float tau, unsigned q, int rel_row0,
+                                            int half, int n_rows, unsigned row_begin32, WaveRecord* lane_list,
+                                            unsigned& lane_n, WaveRecord* spill_log, int& spill_n,
+                                            unsigned* overflow) {
+  asm volatile("" : "+v"(rel_row0));  // keep this arithmetic out of the MFMA loop
+  const int rel = rel_row0 + 4 * half;
+  bool spill = false;
+  if (hit) {
+    if (lane_n < (unsigned)kLaneCap) {
+      write_record(lane_list + lane_n, acc, q, row_begin32 + (unsigned)rel, n_rows - rel, tau);
+      ++lane_n;
+    } else {
+      spill = true;
+    }
+  }
+  const unsigned long long mask = __ballot(spill);
+  if (mask) {  // wave-uniform
+    const int n_spill = __builtin_popcountll(mask);
+    if (spill_n + n_spill > kSpillCap) {
+      *overflow = 1u;
+    } else {
+      if (spill) {
+        const int idx = spill_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        write_record(spill_log + idx, acc, q, row_begin32 + (unsigned)rel, n_rows - rel, tau);
+      }
+      spill_n += n_spill;
+    }
+  }
+}
+
 // Tiling: a workgroup = 8 waves; wave w keeps query blocks (32 queries each) w*QW .. w*QW+QW-1 of
 // its query tile as MFMA B fragments in VGPRs and every wave reads the same corpus sub-tile
 // (32 rows, MFMA A operand) from LDS.  The loop is arranged so that the MFMA pipe always has
 // queued work from a single wave:
 //   * unit = one 32-row sub-tile x QW query blocks (QW independent MFMA chains, interleaved);
-//   * the A fragments of unit g+1 are read from LDS while unit g's chains run;
+//   * the A fragments live in ONE register set: k-steps 0-3 of the next unit are re-loaded right
+//     after the current unit consumed them, k-steps 4-7 after its last MFMA;
 //   * the lane-local max-tree + threshold test of unit g-1 sits in the same basic block as unit
-//     g's MFMAs (ONE wave-wide branch per unit, re-tested per tile only on the rare path);
+//     g's MFMAs (ONE wave-wide branch per unit);
 //   * three LDS stage buffers and ONE barrier per stage placed mid-stage: crossing a stage
 //     boundary needs no barrier, so the fragment prefetch runs straight across it.
 //     At the barrier of stage s (before its unit 2): every wave is past stage s-1, whose buffer
 //     (s+2)%3 is therefore free for DMA(s+2); and every wave has drained (vmcnt 0) its pieces of
 //     DMA(s+1), issued one full stage earlier, so buffer (s+1)%3 is readable from unit 3 on.
-// Candidate records.  A lane whose 16-score column beats its query's threshold appends ONE 80-byte
-// record {query, first row, rows left in the chunk, 16 scores} to its wave's private log in HBM:
-// the slot is the wave's running count (an SGPR) plus the lane's rank among the hit lanes, so the
-// MFMA loop contains no atomics and never waits on memory.  When the wave has finished its chunk it
-// drains its own log (drain_wave_log): one lane per record picks the individual scores that pass
-// and appends them to the per-query candidate lists in HBM.
-__device__ __forceinline__ void append_records(const f32x16& acc, bool hit, float tau, unsigned q, int rel_row0, int half,
-                                               int n_rows, unsigned row_begin32, WaveRecord* wave_log,
-                                               int& log_cnt, const FilterArgs& a) {
-  const unsigned long long mask = __ballot(hit);
-  const int n_hit = __builtin_popcountll(mask);
-  if (log_cnt + n_hit > (int)a.wave_log_cap) {  // wave-uniform
-    *a.overflow = 1u;
-    return;
-  }
-  if (hit) {
-    const int idx = log_cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-    const int rel = rel_row0 + 4 * half;
-    uint4* dst = (uint4*)(wave_log + idx);
-    dst[0] = make_uint4(q, row_begin32 + (unsigned)rel, (unsigned)(n_rows - rel), __float_as_uint(tau));
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      dst[1 + g] = make_uint4(__float_as_uint(acc[4 * g]), __float_as_uint(acc[4 * g + 1]),
-                              __float_as_uint(acc[4 * g + 2]), __float_as_uint(acc[4 * g + 3]));
-  }
-  log_cnt += n_hit;
-}
-
-// Epilogue of a filter wave: move the survivors of its record log to the per-query candidate
-// lists.  The log only holds the wave's own <= 64 queries, so the survivors are first counted per
-// query in LDS and ONE returning global atomic per query reserves their slots — the per-query
-// counters are shared by every corpus chunk (every XCD), device-scope atomics on them are slow.
-// One lane handles one record at a time (five 16-byte loads in flight per lane).
-template <bool INCLUSIVE>
-__device__ __forceinline__ void drain_wave_log(const WaveRecord* wave_log, int log_cnt, int lane, unsigned q0,
-                                               unsigned* s_cnt, unsigned* s_base, const FilterArgs& a) {
-  if (log_cnt == 0) return;  // wave-uniform
-  s_cnt[lane] = 0;
-  // the records were written by other lanes of this wave: wait until L2 acknowledged the stores
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  for (int i = lane; i < log_cnt; i += 64) {
-    const uint4* src = (const uint4*)(wave_log + i);
-    const uint4 h = src[0];
-    const float tau = __uint_as_float(h.w);
-    const int rows_left = (int)h.z;
-    unsigned n = 0;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const uint4 v = src[1 + g];
-      const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        n += ((INCLUSIVE ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) ? 1u : 0u;
-    }
-    if (n) atomicAdd(&s_cnt[h.x - q0], n);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  const unsigned mine = s_cnt[lane];
-  s_base[lane] = mine ? atomicAdd(&a.cand_cnt[q0 + lane], mine) : 0u;
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  for (int i = lane; i < log_cnt; i += 64) {
-    const uint4* src = (const uint4*)(wave_log + i);
-    const uint4 h = src[0];
-    const float tau = __uint_as_float(h.w);
-    const int rows_left = (int)h.z;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const uint4 v = src[1 + g];
-      const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if ((INCLUSIVE ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
-          const unsigned pos = atomicAdd(&s_base[h.x - q0], 1u);  // LDS: next free slot of this query
-          if (pos < a.cap)
-            a.cand[(size_t)h.x * a.cap + pos] = make_uint2(__float_as_uint(sc[e]), h.y + (unsigned)(e + 8 * g));
-          else
-            *a.overflow = 1u;
-        }
-      }
-    }
-  }
-}
-
 template <int QW, bool INCLUSIVE>
-__global__ __launch_bounds__(kFilterThreads) void mips_filter_f16_pipe(FilterArgs a) {
+__global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) {
   static_assert(QW == 1 || QW == 2, "two accumulators per unit");
-  // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads):
-  // three stage buffers, then per wave 2 x 64 counters for the log drain
-  __shared__ __attribute__((aligned(16))) char lds[3 * kStageBytes + kFilterWaves * 512];
+  // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads)
+  __shared__ __attribute__((aligned(16))) char lds[3 * kStageBytes];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31;
-  const int half = lane >> 5;
+  const int li = lane & 31;   // MFMA row/column owned by this lane
+  const int half = lane >> 5; // which 8-wide k slice of each 16-wide k step
 
+  // block -> (xcd, query tile, corpus chunk): the n_qtiles workgroups that stream the same
+  // corpus chunk get consecutive dispatch slots on the same XCD, so the chunk is fetched from
+  // HBM once and re-read from that XCD's L2.
   const unsigned b = blockIdx.x;
   const unsigned xcd = b & 7u;
   const unsigned rest = b >> 3;
-  const unsigned qt = rest % a.n_qtiles;
-  const unsigned grp = rest / a.n_qtiles;
-  const long long chunk = (long long)grp * 8 + xcd;
-  const long long row_begin = a.slab_row0 + chunk * (long long)a.rows_per_chunk;
+  const unsigned qt = rest % a.store.n_qtiles;
+  const unsigned grp = rest / a.store.n_qtiles;
+  const unsigned chunk = grp * 8 + xcd;
+  const long long row_begin = a.slab_row0 + (long long)chunk * a.rows_per_chunk;
   if (row_begin >= a.slab_row1) return;  // launch padding (the grid is a multiple of 8 chunks)
   long long row_end = row_begin + a.rows_per_chunk;
   if (row_end > a.slab_row1) row_end = a.slab_row1;
@@ -178,45 +147,56 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16_pipe(FilterArg
   const unsigned row_begin32 = (unsigned)row_begin;
   const char* chunk_base = a.xb + row_begin * kRowBytes;
 
-  const unsigned wave_slot = blockIdx.x * kFilterWaves + wave;
-  WaveRecord* wave_log = a.wave_log + (size_t)wave_slot * a.wave_log_cap;
-  int log_cnt = 0;  // wave-uniform
-
+  // resident query fragments (MFMA B operand): lane (li, half), k-step j holds the 16-byte
+  // piece 2j+half of query row q0 + blk*32 + li.
   const unsigned q0 = qt * (kFilterWaves * QW * 32) + wave * (QW * 32);
   f16x8 qf[QW][8];
   float tau[2] = {0.f, 0.f};
+  WaveRecord* lane_list[2] = {nullptr, nullptr};
+  unsigned lane_n[2] = {0u, 0u};
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk) {
-    const char* qrow = (const char*)a.xq + (size_t)(q0 + blk * 32 + li) * kRowBytes;
+    const unsigned q = q0 + blk * 32 + li;
+    const char* qrow = (const char*)a.xq + (size_t)q * kRowBytes;
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[blk][j] = *(const f16x8*)(qrow + (2 * j + half) * 16);
-    tau[blk] = a.tau[q0 + blk * 32 + li];
+    tau[blk] = a.tau[q];
+    lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * kLaneCap;
   }
+  const unsigned wave_slot = (chunk * a.store.n_qtiles + qt) * kFilterWaves + wave;
+  WaveRecord* spill_log = a.store.spill_log + (size_t)wave_slot * kSpillCap;
+  int spill_n = 0;  // wave-uniform
 
+  // LDS read offsets of this lane's corpus fragment (MFMA A operand): row li of a 32-row
+  // sub-tile, piece 2j+half stored at slot (2j+half) ^ (li & 15).
   unsigned rd_off[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) rd_off[j] = li * kRowBytes + (((2 * j + half) ^ (li & 15)) << 4);
 
+  // LDS-DMA: per stage each wave issues 4 instructions of 1 KiB (4 corpus rows); lane t lands
+  // at base + 16 t = (row t>>4, slot t&15) and therefore fetches piece (t&15) ^ (row&15).
+  // Rows past the chunk end re-read the chunk's last row (never logged: rows_left excludes them).
   const int dma_row = lane >> 4;
   const int dma_slot = lane & 15;
   int dma_rel[4];
-  int dma_chunk_off[4];
+  int dma_piece_off[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     dma_rel[e] = (wave * 4 + e) * 4 + dma_row;
-    dma_chunk_off[e] = (dma_slot ^ ((e * 4 + dma_row) & 15)) * 16;
+    dma_piece_off[e] = (dma_slot ^ ((e * 4 + dma_row) & 15)) * 16;
   }
   auto issue_stage = [&](int s, int buf_off) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       int rel = s * kStageRows + dma_rel[e];
       rel = rel < n_rows ? rel : n_rows - 1;
-      const char* src = chunk_base + (long long)rel * kRowBytes + dma_chunk_off[e];
+      const char* src = chunk_base + (long long)rel * kRowBytes + dma_piece_off[e];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(lds + buf_off + (wave * 4 + e) * 1024),
                                        16, 0, 0);
     }
   };
+
   constexpr int kSubs = kStageRows / kSubRows;  // 4 units per stage
   // rotating LDS offsets of stage s, s+1, s+2
   int off0 = 0, off1 = kStageBytes, off2 = 2 * kStageBytes;
@@ -224,13 +204,29 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16_pipe(FilterArg
   if (nstages > 1) issue_stage(1, off1);
   __syncthreads();  // prologue only: both stages landed
 
-  // A fragments live in ONE register set: k-steps 0-3 of the next unit are re-loaded right after
-  // the current unit's k-steps 0-3 were consumed, k-steps 4-7 after its last MFMA.
   f16x8 af[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(lds + off0 + rd_off[j]);
   f32x16 pend[2] = {{0}, {0}};
   int pend_rel0 = -1;  // no pending unit yet
+
+  auto test_and_log = [&](bool valid) {
+    bool hit[2] = {false, false};
+#pragma unroll
+    for (int blk = 0; blk < QW; ++blk) {
+      float m = pend[blk][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
+      hit[blk] = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
+    }
+    if (__builtin_expect(__any((hit[0] || hit[1]) && valid), 0)) {
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk)
+        if (__any(hit[blk]))
+          log_columns(pend[blk], hit[blk], tau[blk], q0 + blk * 32 + li, pend_rel0, half, n_rows, row_begin32,
+                      lane_list[blk], lane_n[blk], spill_log, spill_n, a.overflow);
+    }
+  };
 
   for (int s = 0; s < nstages; ++s) {
 #pragma unroll
@@ -261,21 +257,7 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16_pipe(FilterArg
       for (int j = 4; j < 8; ++j) af[j] = *(const f16x8*)(nxt + rd_off[j]);
 
       // lane-local test of the PREVIOUS unit, scheduled under the MFMAs just issued
-      bool hit[2] = {false, false};
-#pragma unroll
-      for (int blk = 0; blk < QW; ++blk) {
-        float m = pend[blk][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
-        hit[blk] = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
-      }
-      if (__builtin_expect(__any((hit[0] || hit[1]) && pend_rel0 >= 0), 0)) {
-#pragma unroll
-        for (int blk = 0; blk < QW; ++blk)
-          if (__any(hit[blk]))
-            append_records(pend[blk], hit[blk], tau[blk], q0 + blk * 32 + li, pend_rel0, half, n_rows, row_begin32,
-                           wave_log, log_cnt, a);
-      }
+      test_and_log(pend_rel0 >= 0);
 
       pend[0] = cur[0];
       pend[1] = cur[1];
@@ -286,54 +268,106 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16_pipe(FilterArg
     off1 = off2;
     off2 = t;
   }
-  // drain the last unit
-  {
+  test_and_log(true);  // drain the last unit
+
 #pragma unroll
-    for (int blk = 0; blk < QW; ++blk) {
-      float m = pend[blk][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
-      const bool hit = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
-      if (__any(hit))
-        append_records(pend[blk], hit, tau[blk], q0 + blk * 32 + li, pend_rel0, half, n_rows, row_begin32, wave_log,
-                       log_cnt, a);
-    }
-  }
-  unsigned* s_cnt = (unsigned*)(lds + 3 * kStageBytes + wave * 512);
-  drain_wave_log<INCLUSIVE>(wave_log, log_cnt, lane, q0, s_cnt, s_cnt + 64, a);
+  for (int blk = 0; blk < QW; ++blk)
+    a.store.lane_cnt[lane_list_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
+  if (lane == 0) a.store.spill_cnt[wave_slot] = (unsigned)spill_n;
 }
 
 // ---------------------------------------------------------------------------------------
 // merge kernel: one workgroup per query
 // ---------------------------------------------------------------------------------------
+// keys[] collects {survivors of this round} then {running list}.  Forward rounds (distinct rows,
+// strict threshold) select by rank: rank of a key = number of larger keys, every thread scans the
+// LDS array with broadcast reads, no sort.  Overflow-safe rounds (inclusive threshold, rows may
+// repeat) sort bitonically and drop adjacent duplicates.
+__device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
+                                            unsigned long long* keys, unsigned* n_keys) {
+  const uint4* src = (const uint4*)rec;
+  const uint4 h = src[0];
+  if (h.x != q) return;  // spill logs mix the wave's queries
+  const float tau = __uint_as_float(h.w);
+  const int rows_left = (int)h.z;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const uint4 v = src[1 + g];
+    const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if ((inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
+        const unsigned pos = atomicAdd(n_keys, 1u);  // LDS
+        if (pos < (unsigned)kMaxSortKeys) keys[pos] = pack_key(sc[e], h.y + (unsigned)(e + 8 * g));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[kMaxSortKeys];
+  __shared__ unsigned s_lane_cnt[512];   // per (chunk, half) list length of this query
+  __shared__ unsigned s_n_keys;
+
   const unsigned q = blockIdx.x;
   const int tid = threadIdx.x;
-  const unsigned raw_cnt = a.cand_cnt[q];
-  if (raw_cnt == 0) return;  // nothing passed the threshold this round
-  const unsigned cnt = raw_cnt < a.cap ? raw_cnt : a.cap;
-  const unsigned nrun = a.run_n[q];
-  const unsigned total = nrun + cnt;
-  unsigned P = 2;
-  while (P < total) P <<= 1;
+  const CandidateStore& st = a.store;
+  const unsigned n_lists = 2 * a.n_chunks;
+  const bool inclusive = a.inclusive != 0;
 
-  for (unsigned i = tid; i < P; i += kMergeThreads) {
-    unsigned long long key = 0ull;  // below every real key
-    if (i < nrun) {
-      key = a.run_keys[(size_t)q * a.k + i];
-    } else if (i < total) {
-      const uint2 c = a.cand[(size_t)q * a.cap + (i - nrun)];
-      key = pack_key(__uint_as_float(c.x), c.y);
+  if (tid == 0) s_n_keys = 0;
+  __syncthreads();
+
+  // the wave slot that owns q in every chunk
+  const unsigned tile_q = kFilterWaves * a.qw * 32;
+  const unsigned qt = q / tile_q;
+  const unsigned wave = (q - qt * tile_q) / (a.qw * 32);
+
+  for (unsigned base = 0; base < n_lists; base += 512) {
+    // list lengths of this query (chunk-major, half-minor: adjacent words of one chunk)
+    const unsigned n_here = (n_lists - base) < 512u ? (n_lists - base) : 512u;
+    for (unsigned t = tid; t < n_here; t += kMergeThreads) {
+      const unsigned l = base + t;
+      s_lane_cnt[t] = st.lane_cnt[lane_list_index(st, l >> 1, q, (int)(l & 1))];
     }
-    keys[i] = key;
+    __syncthreads();
+    // one thread per (list, slot) pair: every record is fetched with five independent 16-byte loads
+    for (unsigned p = tid; p < n_here * kLaneCap; p += kMergeThreads) {
+      const unsigned t = p / kLaneCap, slot = p - t * kLaneCap;
+      if (slot < s_lane_cnt[t]) {
+        const unsigned l = base + t;
+        const WaveRecord* rec = st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * kLaneCap + slot;
+        keep_scores(rec, q, inclusive, keys, &s_n_keys);
+      }
+    }
+    __syncthreads();
+  }
+
+  // spill logs of the wave slot (usually all empty): one wave per chunk, lanes over records
+  {
+    const int lane = tid & 63, w = tid >> 6;
+    for (unsigned c = w; c < a.n_chunks; c += kMergeThreads / 64) {
+      const unsigned slot = (c * st.n_qtiles + qt) * kFilterWaves + wave;
+      const unsigned n = st.spill_cnt[slot];
+      for (unsigned i = lane; i < n; i += 64)
+        keep_scores(st.spill_log + (size_t)slot * kSpillCap + i, q, inclusive, keys, &s_n_keys);
+    }
   }
   __syncthreads();
 
-  if (!a.dedupe) {
-    // Keys are distinct (one per corpus row), so the rank of a key = number of larger keys, and
-    // the keys of rank < k ARE the new running list, already in order.  Every thread scans the
-    // whole LDS array (broadcast reads, no barriers) instead of sorting it.
+  const unsigned n_seen = s_n_keys;
+  if (n_seen == 0) return;  // nothing passed the threshold this round: list and threshold stand
+  unsigned n_cand = n_seen;
+  const unsigned nrun = a.run_n[q];
+  if (n_cand + nrun > (unsigned)kMaxSortKeys) {  // more survivors than one LDS pass holds
+    if (tid == 0) *a.overflow = 1u;
+    n_cand = kMaxSortKeys - nrun;
+  }
+  for (unsigned i = tid; i < nrun; i += kMergeThreads) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
+  const unsigned total = n_cand + nrun;
+  __syncthreads();
+
+  if (!inclusive) {
     const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
     for (unsigned i = tid; i < total; i += kMergeThreads) {
       const unsigned long long mine = keys[i];
@@ -346,12 +380,17 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
     }
     if (tid == 0) {
       a.run_n[q] = keep;
-      a.cand_cnt[q] = 0;
-      a.stat_candidates[q] += raw_cnt;  // one block per query: no contention
+      a.stat_candidates[q] += n_seen;
     }
     return;
   }
 
+  // inclusive rounds: sort descending, then drop exact duplicates (rows re-scanned by the
+  // overflow-safe path may already be in the running list)
+  unsigned P = 2;
+  while (P < total) P <<= 1;
+  for (unsigned i = total + tid; i < P; i += kMergeThreads) keys[i] = 0ull;  // below every real key
+  __syncthreads();
   for (unsigned size = 2; size <= P; size <<= 1) {
     for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
       for (unsigned i = tid; i < (P >> 1); i += kMergeThreads) {
@@ -367,50 +406,31 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
       __syncthreads();
     }
   }
-
-  if (a.dedupe) {
-    // overflow-safe rounds re-scan rows that may already be in the running list: drop exact
-    // duplicates (adjacent after the sort).  Rare path, serial.
-    if (tid == 0) {
-      unsigned out = 0;
-      unsigned long long prev = 0ull;
-      for (unsigned i = 0; i < total && out < (unsigned)a.k; ++i) {
-        const unsigned long long key = keys[i];
-        if (i > 0 && key == prev) continue;
-        prev = key;
-        keys[out++] = key;  // out <= i, so in-place compaction is safe
-      }
-      a.run_n[q] = out;
-      keys[P] = out;  // scratch slot (P+1 elements allocated)
+  if (tid == 0) {  // rare path, serial
+    unsigned out = 0;
+    unsigned long long prev = 0ull;
+    for (unsigned i = 0; i < total && out < (unsigned)a.k; ++i) {
+      const unsigned long long key = keys[i];
+      if (i > 0 && key == prev) continue;
+      prev = key;
+      keys[out++] = key;  // out <= i: in-place compaction is safe
     }
-    __syncthreads();
-    const unsigned keep = (unsigned)keys[P];
-    for (unsigned i = tid; i < keep; i += kMergeThreads) a.run_keys[(size_t)q * a.k + i] = keys[i];
-    if (tid == 0) {
-      a.tau[q] = keep == (unsigned)a.k ? float_from_ord((unsigned)(keys[a.k - 1] >> 32)) : -__builtin_inff();
-      a.cand_cnt[q] = 0;
-      a.stat_candidates[q] += raw_cnt;  // one block per query: no contention
-    }
-    return;
+    a.run_n[q] = out;
+    a.tau[q] = out == (unsigned)a.k ? float_from_ord((unsigned)(keys[a.k - 1] >> 32)) : -__builtin_inff();
+    a.stat_candidates[q] += n_seen;
+    s_n_keys = out;
   }
-
-  const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
+  __syncthreads();
+  const unsigned keep = s_n_keys;
   for (unsigned i = tid; i < keep; i += kMergeThreads) a.run_keys[(size_t)q * a.k + i] = keys[i];
-  if (tid == 0) {
-    a.run_n[q] = keep;
-    a.tau[q] = keep == (unsigned)a.k ? float_from_ord((unsigned)(keys[a.k - 1] >> 32)) : -__builtin_inff();
-    a.cand_cnt[q] = 0;
-    a.stat_candidates[q] += raw_cnt;  // one block per query: no contention
-  }
 }
 
 // ---------------------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------------------
 // pad + convert queries to the fp16 [Qpad,128] operand layout, reset per-query state
-__global__ void prep_queries(const void* xq, int dtype, long long nq, long long nq_pad,
-                             _Float16* xq_pad, float* tau, unsigned* cand_cnt, unsigned* run_n,
-                             unsigned long long* stat, int debug_nohit) {
+__global__ void prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, _Float16* xq_pad,
+                             float* tau, unsigned* run_n, unsigned long long* stat, int debug_nohit) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = nq_pad * kDim;
   if (i < n) {
@@ -420,8 +440,7 @@ __global__ void prep_queries(const void* xq, int dtype, long long nq, long long 
     xq_pad[i] = (_Float16)v;
   }
   if (i < nq_pad) {
-    tau[i] = (i < nq && !debug_nohit) ? -__builtin_inff() : __builtin_inff();  // padded queries never emit
-    cand_cnt[i] = 0;
+    tau[i] = (i < nq && !debug_nohit) ? -__builtin_inff() : __builtin_inff();  // padded queries never log
     run_n[i] = 0;
     stat[i] = 0;
   }
@@ -517,33 +536,28 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
   dim3 g(grid), blk(kFilterThreads);
   if (qw == 2) {
     if (inclusive)
-      hipLaunchKernelGGL((mips_filter_f16_pipe<2, true>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16<2, true>), g, blk, 0, st, a);
     else
-      hipLaunchKernelGGL((mips_filter_f16_pipe<2, false>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16<2, false>), g, blk, 0, st, a);
   } else {
     if (inclusive)
-      hipLaunchKernelGGL((mips_filter_f16_pipe<1, true>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16<1, true>), g, blk, 0, st, a);
     else
-      hipLaunchKernelGGL((mips_filter_f16_pipe<1, false>), g, blk, 0, st, a);
+      hipLaunchKernelGGL((mips_filter_f16<1, false>), g, blk, 0, st, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
-  // keys for k + cap entries rounded to a power of two, +1 scratch slot
-  unsigned P = 2;
-  while (P < (unsigned)a.k + a.cap) P <<= 1;
-  const size_t lds = ((size_t)P + 1) * sizeof(unsigned long long);
-  hipLaunchKernelGGL(topk_merge, dim3(nq_pad), dim3(kMergeThreads), lds, st, a);
+  hipLaunchKernelGGL(topk_merge, dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
-                               float* tau, unsigned* cand_cnt, unsigned* run_n, unsigned long long* stat,
-                               hipStream_t st) {
+                               float* tau, unsigned* run_n, unsigned long long* stat, hipStream_t st) {
   const long long n = nq_pad * kDim;
-  hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq,
-                     nq_pad, (_Float16*)xq_pad, tau, cand_cnt, run_n, stat, getenv("PROQA_DEBUG_NOHIT") ? 1 : 0);
+  hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
+                     (_Float16*)xq_pad, tau, run_n, stat, getenv("PROQA_DEBUG_NOHIT") ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -557,7 +571,7 @@ hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* r
 }
 
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
-                             int k, float* D, long long* I, hipStream_t st) {
+                              int k, float* D, long long* I, hipStream_t st) {
   if (nq == 0) return hipSuccess;
   unsigned P = 2;
   while (P < (unsigned)n_parts * (unsigned)k) P <<= 1;

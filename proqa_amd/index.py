@@ -134,8 +134,9 @@ class IndexFlatIP:
     def set_profiling(self, enable=True):
         _lib.check(self._lib.proqa_index_set_profiling(self._h, 1 if enable else 0))
 
-    def configure(self, cand_capacity=0, first_slab_rows=0, growth=0):
-        _lib.check(self._lib.proqa_index_configure(self._h, cand_capacity, first_slab_rows, growth))
+    def configure(self, first_slab_rows=0, growth=0):
+        """Round schedule: rows of the first (dense) slab and the growth factor of later slabs."""
+        _lib.check(self._lib.proqa_index_configure(self._h, first_slab_rows, growth))
 
     def close(self):
         if getattr(self, "_h", None):

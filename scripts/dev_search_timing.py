@@ -10,7 +10,7 @@ from proqa_amd.index import IndexFlatIP  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 18_000_000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 2032
-cfgs = [(944, 256, 4)] if len(sys.argv) <= 3 else [tuple(int(x) for x in c.split(",")) for c in sys.argv[3:]]
+cfgs = [(256, 4)] if len(sys.argv) <= 3 else [tuple(int(x) for x in c.split(",")) for c in sys.argv[3:]]
 k = 80
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)

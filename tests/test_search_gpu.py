@@ -92,7 +92,7 @@ def test_adversarial_order_takes_overflow_safe_path(gpu_device):
     xq = np.zeros((70, 128), np.float16)
     xq[:, 0] = 1
     index = IndexFlatIP(128)
-    index.configure(cand_capacity=256, first_slab_rows=128, growth=4)
+    index.configure(first_slab_rows=128, growth=4)
     index.add(base)
     D, I = index.search(xq, 80)
     Do, Io = search_oracle.topk_ip(xq, base, 80)
