@@ -207,7 +207,7 @@ def main():
 
     if rank == 0 and not args.skip_cpu:
         # CPU baseline + id parity on a bounded sample of the same workload
-        ns, qs = min(1_000_000, hi - lo), min(256, nq)
+        ns, qs = min(2_000_000, hi - lo), nq   # ~10-20 s of NumPy/BLAS work on the host
         cpu_qps, cdt, Do, Io = cpu_search_baseline(xb[:ns], xq[:qs], k, n)
         ix = IndexFlatIP(128)
         ix.adopt_device(xb[:ns])

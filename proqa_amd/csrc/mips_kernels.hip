@@ -283,9 +283,8 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 // strict threshold) select by rank: rank of a key = number of larger keys, every thread scans the
 // LDS array with broadcast reads, no sort.  Overflow-safe rounds (inclusive threshold, rows may
 // repeat) sort bitonically and drop adjacent duplicates.
-__device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
-                                            unsigned long long* keys, unsigned* n_keys) {
-  const uint4* src = (const uint4*)rec;
+__device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned q, bool inclusive,
+                                                 unsigned long long* keys, unsigned* n_keys) {
   const uint4 h = src[0];
   if (h.x != q) return;  // spill logs mix the wave's queries
   const float tau = __uint_as_float(h.w);
@@ -304,9 +303,18 @@ __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, b
   }
 }
 
+__device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
+                                            unsigned long long* keys, unsigned* n_keys) {
+  uint4 buf[5];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) buf[g] = ((const uint4*)rec)[g];
+  keep_scores_regs(buf, q, inclusive, keys, n_keys);
+}
+
 __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[kMaxSortKeys];
-  __shared__ unsigned s_lane_cnt[512];   // per (chunk, half) list length of this query
+  __shared__ unsigned short s_lane_cnt[512];   // per (chunk, half) list length of this query
+  __shared__ unsigned short s_spill_cnt[256];  // per chunk: records in the spill log of q's wave slot
   __shared__ unsigned s_n_keys;
 
   const unsigned q = blockIdx.x;
@@ -315,20 +323,24 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   const unsigned n_lists = 2 * a.n_chunks;
   const bool inclusive = a.inclusive != 0;
 
-  if (tid == 0) s_n_keys = 0;
-  __syncthreads();
-
   // the wave slot that owns q in every chunk
   const unsigned tile_q = kFilterWaves * a.qw * 32;
   const unsigned qt = q / tile_q;
   const unsigned wave = (q - qt * tile_q) / (a.qw * 32);
 
+  if (tid == 0) s_n_keys = 0;
+
   for (unsigned base = 0; base < n_lists; base += 512) {
-    // list lengths of this query (chunk-major, half-minor: adjacent words of one chunk)
+    // first-level loads, all independent: list lengths of this query (chunk-major, half-minor:
+    // adjacent words of one chunk) and the spill counters of the same chunks
     const unsigned n_here = (n_lists - base) < 512u ? (n_lists - base) : 512u;
     for (unsigned t = tid; t < n_here; t += kMergeThreads) {
       const unsigned l = base + t;
-      s_lane_cnt[t] = st.lane_cnt[lane_list_index(st, l >> 1, q, (int)(l & 1))];
+      s_lane_cnt[t] = (unsigned short)st.lane_cnt[lane_list_index(st, l >> 1, q, (int)(l & 1))];
+    }
+    for (unsigned t = tid; t < (n_here >> 1); t += kMergeThreads) {
+      const unsigned c = (base >> 1) + t;
+      s_spill_cnt[t] = (unsigned short)st.spill_cnt[(c * st.n_qtiles + qt) * kFilterWaves + wave];
     }
     __syncthreads();
     // one thread per (list, slot) pair: every record is fetched with five independent 16-byte loads
@@ -340,20 +352,20 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
         keep_scores(rec, q, inclusive, keys, &s_n_keys);
       }
     }
+    // spill logs of the wave slot (usually all empty): one wave per non-empty chunk
+    {
+      const int lane = tid & 63, w = tid >> 6;
+      for (unsigned t = w; t < (n_here >> 1); t += kMergeThreads / 64) {
+        const unsigned n = s_spill_cnt[t];
+        if (n == 0) continue;
+        const unsigned c = (base >> 1) + t;
+        const size_t slot = (size_t)(c * st.n_qtiles + qt) * kFilterWaves + wave;
+        for (unsigned i = lane; i < n; i += 64)
+          keep_scores(st.spill_log + slot * kSpillCap + i, q, inclusive, keys, &s_n_keys);
+      }
+    }
     __syncthreads();
   }
-
-  // spill logs of the wave slot (usually all empty): one wave per chunk, lanes over records
-  {
-    const int lane = tid & 63, w = tid >> 6;
-    for (unsigned c = w; c < a.n_chunks; c += kMergeThreads / 64) {
-      const unsigned slot = (c * st.n_qtiles + qt) * kFilterWaves + wave;
-      const unsigned n = st.spill_cnt[slot];
-      for (unsigned i = lane; i < n; i += 64)
-        keep_scores(st.spill_log + (size_t)slot * kSpillCap + i, q, inclusive, keys, &s_n_keys);
-    }
-  }
-  __syncthreads();
 
   const unsigned n_seen = s_n_keys;
   if (n_seen == 0) return;  // nothing passed the threshold this round: list and threshold stand
@@ -372,7 +384,14 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
     for (unsigned i = tid; i < total; i += kMergeThreads) {
       const unsigned long long mine = keys[i];
       unsigned rank = 0;
-      for (unsigned j = 0; j < total; ++j) rank += keys[j] > mine ? 1u : 0u;
+      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+      const unsigned even = total & ~1u;
+#pragma unroll 4
+      for (unsigned j = 0; j < even; j += 2) {  // two keys per 16-byte broadcast read
+        const u64x2 kk = *(const u64x2*)(keys + j);
+        rank += (kk[0] > mine ? 1u : 0u) + (kk[1] > mine ? 1u : 0u);
+      }
+      if (even < total) rank += keys[even] > mine ? 1u : 0u;
       if (rank < keep) {
         a.run_keys[(size_t)q * a.k + rank] = mine;
         if (rank == (unsigned)a.k - 1) a.tau[q] = float_from_ord((unsigned)(mine >> 32));
