@@ -160,10 +160,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl")   # RCCL
+        dist.init_process_group(backend=os.environ.get("PROQA_DIST_BACKEND", "nccl"))   # RCCL
 
     from proqa_amd.index import IndexFlatIP, ShardedIndexFlatIP, shard_bounds
 

@@ -91,10 +91,13 @@ def main(argv=None):
     world, rank, local_rank = _dist_env(args)
     if not torch.cuda.is_available():
         raise RuntimeError("no MI355X visible: the encode path has no CPU fallback")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 and not torch.distributed.is_initialized():
-        torch.distributed.init_process_group(backend="nccl")  # RCCL on ROCm; used for barriers only
+        # RCCL ("nccl") on ROCm; only barriers are issued.  PROQA_DIST_BACKEND=gloo lets two ranks
+        # share one GPU (RCCL refuses that), which is how the GPU test exercises this path.
+        torch.distributed.init_process_group(backend=os.environ.get("PROQA_DIST_BACKEND", "nccl"))
 
     random.seed(args.seed)
     np.random.seed(args.seed)
