@@ -201,7 +201,7 @@ def main():
                    "rounds": st["rounds"], "fallback_rounds": st["fallback_rounds"],
                    "candidates_per_query": st["candidates"] / max(nq, 1)},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / PEAK_MFMA_F16_TFLOPS, "traffic": pmc_traffic(),
+                     "frac": tflops / PEAK_MFMA_F16_TFLOPS, "traffic": pmc_traffic((hi - lo) / n),
                      "kernel": "mips_filter_f16", "filter_ms_per_search": st["filter_ms"],
                      "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / PEAK_HBM_GBS},
     }
@@ -237,12 +237,13 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic():
-    """HBM bytes per mips_filter launch from the committed rocprofv3 PMC pass, if present."""
+def pmc_traffic(shard_fraction):
+    """HBM bytes the mips_filter launches of one search read (committed rocprofv3 PMC pass of the
+    1-GPU run, FETCH_SIZE x 2 per the gfx950 note), scaled to this rank's share of the corpus."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_search")
+            return json.load(f).get("hbm_bytes_per_search") * shard_fraction
     except Exception:
         return None
 

@@ -138,10 +138,10 @@ int proqa_bias_residual_layernorm_f16(const void* x, const void* bias, const voi
 
 /* embed[b,:] = (tanh(h[b,0,:] Wp^T + bp)) Wproj^T + bproj
  * (BertPooler + proj_{q,c}: retrieval/retriever.py:19-20,37-42).  h is [B, S, hidden];
- * out is [B, 128] in out_dtype. */
+ * pooled_ws is caller-provided scratch of B*hidden fp16; out is [B, 128] in out_dtype. */
 int proqa_pool_project_f16(const void* h, int batch, int seq_len, int hidden, const void* w_pool,
                            const void* b_pool, const void* w_proj, const void* b_proj,
-                           void* out, int out_dtype, void* stream);
+                           void* pooled_ws, void* out, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * .npy index files.  Replace np.save (retrieval/get_embed.py:139) and np.load

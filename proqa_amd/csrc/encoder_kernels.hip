@@ -145,63 +145,41 @@ __global__ __launch_bounds__(256) void bias_gelu(_Float16* __restrict__ x, const
   }
 }
 
-// BertPooler + projection head: out[b] = Wproj . tanh(Wp . h[b,0] + bp) + bproj
-// One 256-thread block per kPoolRows sequences; each wave owns output features round-robin and
-// the 64 lanes split the 768-long dot product (16-byte weight loads, shuffle reduction).
-constexpr int kPoolRows = 4;
+// BertPooler + projection head: out[b] = Wproj . tanh(Wp . h[b,0] + bp) + bproj, as two launches
+// of one small MFMA kernel  Y[n][m] = act(sum_k W[m][k] X[n][k] + bias[m]).
+// Orientation: features = M (A operand = rows of the [out,in] weight, read as contiguous 16-byte
+// pieces), sequences = N, so every lane owns one sequence column and 16 features of it; a wave
+// computes a 32x32 tile over the whole K, a workgroup 128 features x 32 sequences.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256) void pool_project(const _Float16* __restrict__ h, int batch, int seq_len,
-                                                    int hidden, const _Float16* __restrict__ w_pool,
-                                                    const _Float16* __restrict__ b_pool,
-                                                    const _Float16* __restrict__ w_proj,
-                                                    const _Float16* __restrict__ b_proj, void* __restrict__ out,
-                                                    int out_dtype, int out_dim) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [kPoolRows][hidden] x2
-  float* xs = smem;                          // CLS rows
-  float* ps = smem + kPoolRows * hidden;     // pooled rows
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * kPoolRows;
-  for (int i = tid; i < kPoolRows * hidden; i += 256) {
-    const int r = i / hidden, c = i - r * hidden;
-    const int b = b0 + r;
-    xs[i] = b < batch ? (float)h[((long long)b * seq_len) * hidden + c] : 0.f;
+template <bool TANH, typename OutT>
+__global__ __launch_bounds__(256) void cls_dense_mfma(const _Float16* __restrict__ x, long long x_stride, int n_seq,
+                                                      const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
+                                                      int n_feat, int k_dim, OutT* __restrict__ y, int y_stride) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  const int n0 = blockIdx.y * 32;
+  if (m0 >= n_feat) return;
+  const int n = n0 + li;
+  const _Float16* wrow = w + (long long)(m0 + li) * k_dim + half * 8;
+  const _Float16* xrow = x + (long long)(n < n_seq ? n : n_seq - 1) * x_stride + half * 8;
+  f32x16 acc = {0};
+  for (int k = 0; k < k_dim; k += 16) {
+    const f16x8 a = *(const f16x8*)(wrow + k);
+    const f16x8 b = *(const f16x8*)(xrow + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);
   }
-  __syncthreads();
-  const int n_chunks = hidden >> 3;
-  for (int o = wave; o < hidden; o += 4) {
-    float acc[kPoolRows] = {0.f, 0.f, 0.f, 0.f};
-    for (int chunk = lane; chunk < n_chunks; chunk += 64) {
-      const f16x8 w = *(const f16x8*)(w_pool + (long long)o * hidden + chunk * 8);
+  if (n >= n_seq) return;
 #pragma unroll
-      for (int r = 0; r < kPoolRows; ++r) {
+  for (int g = 0; g < 4; ++g) {
+    const int m = m0 + 8 * g + 4 * half;  // registers 4g..4g+3 hold features m..m+3
+    const f16x4 bv = *(const f16x4*)(bias + m);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[r] += (float)w[i] * xs[r * hidden + chunk * 8 + i];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < kPoolRows; ++r) acc[r] = wave_sum(acc[r]);
-    if (lane < kPoolRows) ps[lane * hidden + o] = tanhf(acc[lane] + (float)b_pool[o]);
-  }
-  __syncthreads();
-  for (int o = wave; o < out_dim; o += 4) {
-    float acc[kPoolRows] = {0.f, 0.f, 0.f, 0.f};
-    for (int chunk = lane; chunk < n_chunks; chunk += 64) {
-      const f16x8 w = *(const f16x8*)(w_proj + (long long)o * hidden + chunk * 8);
-#pragma unroll
-      for (int r = 0; r < kPoolRows; ++r) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[r] += (float)w[i] * ps[r * hidden + chunk * 8 + i];
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < kPoolRows; ++r) acc[r] = wave_sum(acc[r]);
-    if (lane < kPoolRows && b0 + lane < batch) {
-      const float v = acc[lane] + (float)b_proj[o];
-      const long long dst = (long long)(b0 + lane) * out_dim + o;
-      if (out_dtype == PROQA_F16)
-        ((_Float16*)out)[dst] = (_Float16)v;
-      else
-        ((float*)out)[dst] = v;
+    for (int e = 0; e < 4; ++e) {
+      float v = acc[4 * g + e] + (float)bv[e];
+      if (TANH) v = tanhf(v);
+      y[(long long)n * y_stride + m + e] = (OutT)v;
     }
   }
 }
@@ -263,18 +241,31 @@ int proqa_bias_gelu_f16(void* x, const void* bias, int64_t rows, int cols, void*
 }
 
 int proqa_pool_project_f16(const void* h, int batch, int seq_len, int hidden, const void* w_pool,
-                           const void* b_pool, const void* w_proj, const void* b_proj, void* out, int out_dtype,
-                           void* stream) {
-  if (!h || !w_pool || !b_pool || !w_proj || !b_proj || !out) return fail(PROQA_EINVAL, "pool_project: NULL argument");
-  if (batch < 0 || seq_len <= 0 || hidden <= 0 || hidden % 8) return fail(PROQA_EINVAL, "pool_project: bad sizes");
+                           const void* b_pool, const void* w_proj, const void* b_proj, void* pooled_ws, void* out,
+                           int out_dtype, void* stream) {
+  if (!h || !w_pool || !b_pool || !w_proj || !b_proj || !pooled_ws || !out)
+    return fail(PROQA_EINVAL, "pool_project: NULL argument");
+  if (batch < 0 || seq_len <= 0 || hidden <= 0 || hidden % 32)
+    return fail(PROQA_EINVAL, "pool_project: hidden=%d must be a positive multiple of 32", hidden);
   if (out_dtype != PROQA_F16 && out_dtype != PROQA_F32) return fail(PROQA_EINVAL, "pool_project: bad out dtype");
-  const size_t lds = (size_t)2 * kPoolRows * hidden * sizeof(float);
-  if (lds > 64 * 1024) return fail(PROQA_EINVAL, "pool_project: hidden=%d too large", hidden);
   if (batch == 0) return PROQA_OK;
-  const unsigned grid = (unsigned)ceil_div<int>(batch, kPoolRows);
-  hipLaunchKernelGGL(pool_project, dim3(grid), dim3(256), lds, as_stream(stream), (const _Float16*)h, batch,
-                     seq_len, hidden, (const _Float16*)w_pool, (const _Float16*)b_pool, (const _Float16*)w_proj,
-                     (const _Float16*)b_proj, out, out_dtype, PROQA_EMBED_DIM);
+  hipStream_t st = as_stream(stream);
+  const dim3 blk(256);
+  const unsigned ny = (unsigned)ceil_div<int>(batch, 32);
+  // pooled[b] = tanh(Wp . h[b,0] + bp): the CLS rows are rows of h at stride seq_len*hidden
+  hipLaunchKernelGGL((cls_dense_mfma<true, _Float16>), dim3((unsigned)ceil_div<int>(hidden, 128), ny), blk, 0, st,
+                     (const _Float16*)h, (long long)seq_len * hidden, batch, (const _Float16*)w_pool,
+                     (const _Float16*)b_pool, hidden, hidden, (_Float16*)pooled_ws, hidden);
+  PROQA_LAUNCH_CHECK();
+  const dim3 g2((unsigned)ceil_div<int>(PROQA_EMBED_DIM, 128), ny);
+  if (out_dtype == PROQA_F16)
+    hipLaunchKernelGGL((cls_dense_mfma<false, _Float16>), g2, blk, 0, st, (const _Float16*)pooled_ws, (long long)hidden,
+                       batch, (const _Float16*)w_proj, (const _Float16*)b_proj, PROQA_EMBED_DIM, hidden,
+                       (_Float16*)out, PROQA_EMBED_DIM);
+  else
+    hipLaunchKernelGGL((cls_dense_mfma<false, float>), g2, blk, 0, st, (const _Float16*)pooled_ws, (long long)hidden,
+                       batch, (const _Float16*)w_proj, (const _Float16*)b_proj, PROQA_EMBED_DIM, hidden, (float*)out,
+                       PROQA_EMBED_DIM);
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
 }

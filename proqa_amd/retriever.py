@@ -174,7 +174,8 @@ class BertForRetriever:
             ws = SimpleNamespace(
                 h=torch.empty((n, H), dtype=f16, device=dev), h1=torch.empty((n, H), dtype=f16, device=dev),
                 qkv=torch.empty((n, 3 * H), dtype=f16, device=dev), ctx=torch.empty((n, H), dtype=f16, device=dev),
-                tmp=torch.empty((n, H), dtype=f16, device=dev), ff=torch.empty((n, I), dtype=f16, device=dev))
+                tmp=torch.empty((n, H), dtype=f16, device=dev), ff=torch.empty((n, I), dtype=f16, device=dev),
+                pooled=torch.empty((B, H), dtype=f16, device=dev))
             if len(self._ws) > 8:
                 self._ws.clear()
             self._ws[key] = ws
@@ -225,7 +226,8 @@ class BertForRetriever:
                                                           L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, n, H,
                                                           h.data_ptr(), st))
             chk(lib.proqa_pool_project_f16(h.data_ptr(), B, S, H, tw.pool_w.data_ptr(), tw.pool_b.data_ptr(),
-                                           tw.proj_w.data_ptr(), tw.proj_b.data_ptr(), out.data_ptr(),
+                                           tw.proj_w.data_ptr(), tw.proj_b.data_ptr(), ws.pooled.data_ptr(),
+                                           out.data_ptr(),
                                            PROQA_F16 if self.out_dtype == torch.float16 else PROQA_F32, st))
         return out
 

@@ -130,7 +130,7 @@ def test_attention_with_key_padding(lib, gpu_device, B, S, NH):
     close(out.reshape(B, S, NH * 64), ref2, rtol=3e-3, atol=3e-3)
 
 
-@pytest.mark.parametrize("B,S,H", [(5, 48, 128), (9, 128, 768)])
+@pytest.mark.parametrize("B,S,H", [(5, 48, 128), (9, 128, 768), (70, 3, 768), (512, 128, 768)])
 def test_pool_project(lib, gpu_device, B, S, H):
     from proqa_amd import _lib
     rng = np.random.default_rng(B)
@@ -144,8 +144,10 @@ def test_pool_project(lib, gpu_device, B, S, H):
     t = [dev16(a, gpu_device) for a in (h, wp, bp, wj, bj)]
     for dtype, code in [(torch.float16, 0), (torch.float32, 1)]:
         out = torch.empty((B, 128), dtype=dtype, device=gpu_device)
+        ws = torch.empty((B, H), dtype=torch.float16, device=gpu_device)
         _lib.check(lib.proqa_pool_project_f16(t[0].data_ptr(), B, S, H, t[1].data_ptr(), t[2].data_ptr(),
-                                              t[3].data_ptr(), t[4].data_ptr(), out.data_ptr(), code, stream()))
+                                              t[3].data_ptr(), t[4].data_ptr(), ws.data_ptr(), out.data_ptr(), code,
+                                              stream()))
         close(out, ref)
 
 
