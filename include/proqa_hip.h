@@ -144,6 +144,28 @@ int proqa_pool_project_f16(const void* h, int batch, int seq_len, int hidden, co
                            void* pooled_ws, void* out, int out_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * k-means over passage embeddings.  Replaces faiss.Clustering.train + index.search(data, 1) of
+ * retrieval/group_paras.py:20-53 (IndexFlatL2, IndexFlatIP when --spherical).  The Lloyd loop
+ * (sampling, initialisation, empty-cluster splitting: faiss Clustering.cpp) runs on the host
+ * (proqa_amd/group_paras.py); these are its two heavy steps.  Points are fp16 [n,128] in HBM,
+ * centroids float32 [k,128] in HBM (fp32-grade dot products: hi/lo split on the matrix pipe).
+ * ---------------------------------------------------------------------------------- */
+typedef struct proqa_kmeans proqa_kmeans;
+int proqa_kmeans_create(int d, int64_t n_max, int k, proqa_kmeans** out);
+int proqa_kmeans_free(proqa_kmeans* h);
+/* nearest centroid of every point: assign int32 [n]; dist float32 [n] = squared L2 distance
+ * (metric_l2 != 0) or inner product; exact ties go to the lowest centroid index */
+int proqa_kmeans_assign_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n, const float* centroids_dev,
+                               int metric_l2, int32_t* assign_dev, float* dist_dev, void* stream);
+/* centroid c = mean of its points, summed in fp32 in point order (faiss km_update_centroids);
+ * counts uint32 [k]; centroids of empty clusters are left untouched */
+int proqa_kmeans_update_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n, const int32_t* assign_dev,
+                               float* centroids_dev, uint32_t* counts_dev, void* stream);
+/* faiss' rand_perm(perm, n, seed) (std::mt19937, i2 = i + rng() % (n - i)): the permutation faiss
+ * uses to sub-sample the training set and to pick the initial centroids */
+int proqa_rand_perm(int64_t n, int64_t seed, int32_t* perm_out);
+
+/* ------------------------------------------------------------------------------------
  * .npy index files.  Replace np.save (retrieval/get_embed.py:139) and np.load
  * (retrieval/eval_retrieval.py:99-100) for 2-D C-order '<f2' / '<f4' arrays, format v1.0,
  * header padded so that data starts at a multiple of 64 bytes.

@@ -70,6 +70,12 @@ SIGNATURES = {
                                                   c_float, c_int64, c_int, c_void_p, c_void_p]),
     "proqa_pool_project_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "proqa_kmeans_create": (c_int, [c_int, c_int64, c_int, ctypes.POINTER(c_void_p)]),
+    "proqa_kmeans_free": (c_int, [c_void_p]),
+    "proqa_kmeans_assign_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
+                                           c_void_p]),
+    "proqa_kmeans_update_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "proqa_rand_perm": (c_int, [c_int64, c_int64, c_void_p]),
     "proqa_npy_stat": (c_int, [c_char_p, ctypes.POINTER(NpyInfo)]),
     "proqa_npy_read_rows": (c_int, [c_char_p, c_int64, c_int64, c_void_p, c_size_t]),
     "proqa_npy_write": (c_int, [c_char_p, c_void_p, c_int64, c_int64, c_int]),

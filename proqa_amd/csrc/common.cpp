@@ -2,6 +2,8 @@
 #include "common.h"
 
 #include <cstring>
+#include <random>
+#include <utility>
 
 namespace proqa {
 
@@ -53,6 +55,18 @@ int proqa_device_info(int* n_devices, char* arch_name, size_t arch_name_len) {
     PROQA_HIP(hipGetDeviceProperties(&prop, dev));
     strncpy(arch_name, prop.gcnArchName, arch_name_len - 1);
     arch_name[arch_name_len - 1] = 0;
+  }
+  return PROQA_OK;
+}
+
+// faiss/utils/random.cpp rand_perm, restated: Fisher-Yates driven by std::mt19937
+int proqa_rand_perm(int64_t n, int64_t seed, int32_t* perm_out) {
+  if (n < 0 || n >= (1ll << 31) || (!perm_out && n > 0)) return proqa::fail(PROQA_EINVAL, "rand_perm: bad argument");
+  for (int64_t i = 0; i < n; ++i) perm_out[i] = (int32_t)i;
+  std::mt19937 mt((unsigned)seed);
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    const int64_t i2 = i + (int64_t)(mt() % (uint32_t)(n - i));
+    std::swap(perm_out[i], perm_out[i2]);
   }
   return PROQA_OK;
 }
