@@ -279,10 +279,10 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 // ---------------------------------------------------------------------------------------
 // merge kernel: one workgroup per query
 // ---------------------------------------------------------------------------------------
-// keys[] collects {survivors of this round} then {running list}.  Forward rounds (distinct rows,
-// strict threshold) select by rank: rank of a key = number of larger keys, every thread scans the
-// LDS array with broadcast reads, no sort.  Overflow-safe rounds (inclusive threshold, rows may
-// repeat) sort bitonically and drop adjacent duplicates.
+// keys[] collects {survivors of this round} then {running list} and is sorted bitonically in LDS
+// (a rank-select — count the larger keys — was measured slower: its O(n^2) compares are VALU-bound
+// with 8 workgroups resident per CU).  Overflow-safe rounds (inclusive threshold, rows may repeat)
+// additionally drop adjacent duplicates.
 __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned q, bool inclusive,
                                                  unsigned long long* keys, unsigned* n_keys) {
   const uint4 h = src[0];
@@ -379,33 +379,9 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   const unsigned total = n_cand + nrun;
   __syncthreads();
 
-  if (!inclusive) {
-    const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
-    for (unsigned i = tid; i < total; i += kMergeThreads) {
-      const unsigned long long mine = keys[i];
-      unsigned rank = 0;
-      typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-      const unsigned even = total & ~1u;
-#pragma unroll 4
-      for (unsigned j = 0; j < even; j += 2) {  // two keys per 16-byte broadcast read
-        const u64x2 kk = *(const u64x2*)(keys + j);
-        rank += (kk[0] > mine ? 1u : 0u) + (kk[1] > mine ? 1u : 0u);
-      }
-      if (even < total) rank += keys[even] > mine ? 1u : 0u;
-      if (rank < keep) {
-        a.run_keys[(size_t)q * a.k + rank] = mine;
-        if (rank == (unsigned)a.k - 1) a.tau[q] = float_from_ord((unsigned)(mine >> 32));
-      }
-    }
-    if (tid == 0) {
-      a.run_n[q] = keep;
-      a.stat_candidates[q] += n_seen;
-    }
-    return;
-  }
-
-  // inclusive rounds: sort descending, then drop exact duplicates (rows re-scanned by the
-  // overflow-safe path may already be in the running list)
+  // sort descending (bitonic, in LDS); forward rounds keep the first k keys as they are, inclusive
+  // rounds (rows re-scanned by the overflow-safe path may already be in the running list) drop
+  // exact duplicates first
   unsigned P = 2;
   while (P < total) P <<= 1;
   for (unsigned i = total + tid; i < P; i += kMergeThreads) keys[i] = 0ull;  // below every real key
@@ -424,6 +400,16 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
       }
       __syncthreads();
     }
+  }
+  if (!inclusive) {
+    const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
+    for (unsigned i = tid; i < keep; i += kMergeThreads) a.run_keys[(size_t)q * a.k + i] = keys[i];
+    if (tid == 0) {
+      a.run_n[q] = keep;
+      if (keep == (unsigned)a.k) a.tau[q] = float_from_ord((unsigned)(keys[a.k - 1] >> 32));
+      a.stat_candidates[q] += n_seen;
+    }
+    return;
   }
   if (tid == 0) {  // rare path, serial
     unsigned out = 0;
