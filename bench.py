@@ -117,9 +117,16 @@ def encode_leg(args, device, world, rank):
     mask = torch.ones((B, S), dtype=torch.bool, device=device)
     batch = {"input_ids": ids, "input_mask": mask}
     outs = []
+    # same pipelining as proqa_amd.get_embed.predict: consecutive batches alternate between two
+    # streams so that one batch's HBM-bound kernels overlap the other's GEMMs
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    counter = [0]
 
     def step():
-        outs.append(model.get_embed(batch, False)["embed"])
+        s = streams[counter[0] % 2]
+        counter[0] += 1
+        with torch.cuda.stream(s):
+            outs.append(model.get_embed(batch, False, check_mask=False)["embed"])
         if len(outs) > 4:
             outs.pop(0)
 

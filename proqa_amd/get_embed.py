@@ -53,16 +53,32 @@ def _dist_env(args):
     return 1, 0, 0
 
 
+N_STREAMS = 2   # batches in flight: one batch's HBM-bound kernels overlap the other's GEMMs
+
+
+def _right_padded(mask):
+    """em_collate pads on the right: every mask row must be a prefix of True (checked on the host)."""
+    return mask.shape[1] < 2 or not bool((mask[:, 1:] & ~mask[:, :-1]).any())
+
+
 def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=True):
-    """The reference's hot loop: move batch to the GPU, get_embed, keep embeddings on device."""
+    """The reference's hot loop: move batch to the GPU, get_embed, keep embeddings on device.
+    Batches alternate between N_STREAMS HIP streams (order of the results is kept)."""
     model.eval()
     if fp16:
         model.half()
     chunks = []
-    for batch in eval_dataloader:
-        batch_to_feed = move_to_cuda(batch)
-        with torch.no_grad():
-            chunks.append(model.get_embed(batch_to_feed, is_query_embed)["embed"])
+    streams = [torch.cuda.Stream(device=device) for _ in range(N_STREAMS)]
+    main = torch.cuda.current_stream(device)
+    for i, batch in enumerate(eval_dataloader):
+        if not _right_padded(batch["input_mask"]):
+            raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
+        s = streams[i % N_STREAMS]
+        with torch.cuda.stream(s), torch.no_grad():
+            batch_to_feed = move_to_cuda(batch)
+            chunks.append(model.get_embed(batch_to_feed, is_query_embed, check_mask=False)["embed"])
+    for s in streams:
+        main.wait_stream(s)
     if chunks:
         embeds = torch.cat(chunks)
     else:

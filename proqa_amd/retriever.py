@@ -53,7 +53,7 @@ def tower_keys(prefix, n_layers):
 
 
 class _Tower:
-    """fp16 device weights of one BERT tower, laid out for the kernels (fused QKV, [in,out] GEMM operands)."""
+    """fp16 device weights of one BERT tower, laid out for the kernels (fused QKV, [out,in] GEMM operands)."""
 
     def __init__(self, sd, prefix, proj_prefix, cfg, device):
         def w(name):
@@ -70,14 +70,16 @@ class _Tower:
             p = f"{prefix}.encoder.layer.{i}"
             qkv_w = torch.cat([w(f"{p}.attention.self.{n}.weight") for n in ("query", "key", "value")], 0)
             qkv_b = torch.cat([w(f"{p}.attention.self.{n}.bias") for n in ("query", "key", "value")], 0)
+            # weights stay in nn.Linear's [out, in] layout: x @ W.t() is hipBLASLt's "TN" GEMM, measured
+            # 12-19 % faster at these shapes than the pre-transposed "NN" form (scripts/dev_gemm_timing.py)
             self.layers.append(SimpleNamespace(
-                qkv_wt=qkv_w.t().contiguous(), qkv_b=qkv_b.contiguous(),           # [H, 3H]
-                ao_wt=w(f"{p}.attention.output.dense.weight").t().contiguous(),     # [H, H]
+                qkv_w=qkv_w.contiguous(), qkv_b=qkv_b.contiguous(),                 # [3H, H]
+                ao_w=w(f"{p}.attention.output.dense.weight"),                        # [H, H]
                 ao_b=w(f"{p}.attention.output.dense.bias"),
                 ln1_g=w(f"{p}.attention.output.LayerNorm.weight"), ln1_b=w(f"{p}.attention.output.LayerNorm.bias"),
-                ff1_wt=w(f"{p}.intermediate.dense.weight").t().contiguous(),        # [H, I]
+                ff1_w=w(f"{p}.intermediate.dense.weight"),                           # [I, H]
                 ff1_b=w(f"{p}.intermediate.dense.bias"),
-                ff2_wt=w(f"{p}.output.dense.weight").t().contiguous(),              # [I, H]
+                ff2_w=w(f"{p}.output.dense.weight"),                                 # [H, I]
                 ff2_b=w(f"{p}.output.dense.bias"),
                 ln2_g=w(f"{p}.output.LayerNorm.weight"), ln2_b=w(f"{p}.output.LayerNorm.bias")))
         self.pool_w = w(f"{prefix}.pooler.dense.weight")   # [H, H] (out, in): read row-wise by the kernel
@@ -158,14 +160,18 @@ class BertForRetriever:
         raise NotImplementedError("training forward (retriever.py:22-31) is outside the encode/search hot path")
 
     @torch.no_grad()
-    def get_embed(self, batch, is_query_embed):
+    def get_embed(self, batch, is_query_embed, check_mask=True):
+        """check_mask=False skips the device-side validation of the right-padding (it costs a
+        host sync per batch); callers that validated the mask on the host pass False so that
+        batches can be pipelined on several streams (proqa_amd.get_embed.predict)."""
         ids, mask = batch["input_ids"], batch["input_mask"]
-        emb = self.encode(ids, mask, bool(is_query_embed))
+        emb = self.encode(ids, mask, bool(is_query_embed), check_mask=check_mask)
         return {"embed": emb}
 
     # -- implementation -------------------------------------------------------------------
     def _buffers(self, B, S):
-        key = (B, S)
+        # one workspace per (shape, stream): batches in flight on different streams never share buffers
+        key = (B, S, torch.cuda.current_stream().cuda_stream)
         ws = self._ws.get(key)
         if ws is None:
             H, I = self.config.hidden_size, self.config.intermediate_size
@@ -182,7 +188,7 @@ class BertForRetriever:
         return ws
 
     @torch.no_grad()
-    def encode(self, input_ids, input_mask, is_query_embed):
+    def encode(self, input_ids, input_mask, is_query_embed, check_mask=True):
         if not self.towers:
             raise RuntimeError("load_state_dict must be called before get_embed")
         if not input_ids.is_cuda:
@@ -198,7 +204,7 @@ class BertForRetriever:
         ids = input_ids.contiguous().to(torch.int64)
         mask = input_mask.to(torch.bool)
         # em_collate pads on the right: the mask of every row is a prefix of ones
-        if S > 1 and bool((mask[:, 1:] & ~mask[:, :-1]).any()):
+        if check_mask and S > 1 and bool((mask[:, 1:] & ~mask[:, :-1]).any()):
             raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
         lens = mask.sum(dim=1).to(torch.int32).contiguous()
         out = torch.empty((B, EMBED_DIM), dtype=self.out_dtype, device=self.device)
@@ -213,15 +219,15 @@ class BertForRetriever:
                                               tw.emb_b.data_ptr(), eps, ws.h.data_ptr(), st))
             h, h1 = ws.h, ws.h1
             for L in tw.layers:
-                torch.addmm(L.qkv_b, h, L.qkv_wt, out=ws.qkv)                       # fused Q|K|V projection
+                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=ws.qkv)                       # fused Q|K|V projection
                 chk(lib.proqa_attention_f16(ws.qkv.data_ptr(), lens.data_ptr(), B, S, NH, ws.ctx.data_ptr(), st))
-                torch.mm(ws.ctx, L.ao_wt, out=ws.tmp)
+                torch.mm(ws.ctx, L.ao_w.t(), out=ws.tmp)
                 chk(lib.proqa_bias_residual_layernorm_f16(ws.tmp.data_ptr(), L.ao_b.data_ptr(), h.data_ptr(),
                                                           L.ln1_g.data_ptr(), L.ln1_b.data_ptr(), eps, n, H,
                                                           h1.data_ptr(), st))
-                torch.mm(h1, L.ff1_wt, out=ws.ff)
+                torch.mm(h1, L.ff1_w.t(), out=ws.ff)
                 chk(lib.proqa_bias_gelu_f16(ws.ff.data_ptr(), L.ff1_b.data_ptr(), n, I, st))
-                torch.mm(ws.ff, L.ff2_wt, out=ws.tmp)
+                torch.mm(ws.ff, L.ff2_w.t(), out=ws.tmp)
                 chk(lib.proqa_bias_residual_layernorm_f16(ws.tmp.data_ptr(), L.ff2_b.data_ptr(), h1.data_ptr(),
                                                           L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, n, H,
                                                           h.data_ptr(), st))
