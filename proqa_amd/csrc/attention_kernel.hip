@@ -5,7 +5,8 @@
 // mask comes from the right-padding of em_collate (retrieval/datasets.py:29-45,298-305).
 //
 // One 256-thread workgroup per (sequence, head).  K and V of that head (S x 64 fp16 each) are
-// staged once in LDS with full-line coalesced loads; each wave then owns 32-query blocks.
+// staged once in LDS with full-line coalesced loads (V transposed on the way in); each wave then
+// owns 32-query blocks.
 // Both products run on v_mfma_f32_32x32x16_f16 in the "swapped" orientation so that every lane
 // owns ONE query column of the accumulator:
 //   S^T = K Q^T   : lane (q = lane&31) holds 16 keys of its query per 32-key tile, so the row max
@@ -28,7 +29,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kHeadDim = 64;
 constexpr int kKStride = kHeadDim + 8;  // fp16 elements per K row in LDS (144 B: conflict-free b128)
-constexpr int kVStride = kHeadDim;      // V is read 2 bytes at a time: 128 B rows are conflict-free
+// V is staged TRANSPOSED (V^T[d][key]) so that the four consecutive keys a lane needs are one
+// 8-byte read; rows are s_pad + 4 keys long: (s_pad*2 + 8) bytes = 2 banks more per d row, which
+// spreads the 32 d rows of a ds_read_b64 over distinct bank pairs
+constexpr int kVtPad = 4;
 
 __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict__ qkv,
                                                      const int* __restrict__ seq_lens, int seq_len,
@@ -36,7 +40,8 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   const int s_pad = (seq_len + 31) & ~31;
   _Float16* k_lds = smem;                       // [s_pad][kKStride]
-  _Float16* v_lds = smem + s_pad * kKStride;    // [s_pad][kVStride]
+  _Float16* vt_lds = smem + s_pad * kKStride;   // [kHeadDim][s_pad + kVtPad]  (V transposed)
+  const int vt_stride = s_pad + kVtPad;
 
   const int b = blockIdx.x / n_heads;
   const int head = blockIdx.x - b * n_heads;
@@ -58,7 +63,8 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
       vv = *(const f16x8*)(src + 2 * hidden);
     }
     *(f16x8*)(k_lds + row * kKStride + c * 8) = kv;
-    *(f16x8*)(v_lds + row * kVStride + c * 8) = vv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vt_lds[(c * 8 + e) * vt_stride + row] = vv[e];
   }
   __syncthreads();
 
@@ -116,15 +122,22 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
         o0[r] *= alpha;
         o1[r] *= alpha;
       }
-      // O^T += V^T P^T : A operand = V^T gathered for the keys this lane's P registers hold
+      // O^T += V^T P^T : A operand = row d of V^T at the keys this lane's P registers hold
+      // (keys {0-3, 8-11} + 4*half + 16*jj of the tile: two 8-byte reads per fragment)
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
+        const int key0 = kt * 32 + 16 * jj + 4 * half;
+        const _Float16* r0 = vt_lds + li * vt_stride + key0;
+        const _Float16* r1 = vt_lds + (32 + li) * vt_stride + key0;
         f16x8 v0, v1;
+        const f16x4 a0 = *(const f16x4*)r0, a1 = *(const f16x4*)(r0 + 8);
+        const f16x4 b0 = *(const f16x4*)r1, b1 = *(const f16x4*)(r1 + 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int key = kt * 32 + 16 * jj + (e & 3) + 8 * (e >> 2) + 4 * half;
-          v0[e] = v_lds[key * kVStride + li];
-          v1[e] = v_lds[key * kVStride + 32 + li];
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = a0[e];
+          v0[4 + e] = a1[e];
+          v1[e] = b0[e];
+          v1[4 + e] = b1[e];
         }
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[jj], o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[jj], o1, 0, 0, 0);
@@ -159,7 +172,7 @@ extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev,
   if (!qkv || !ctx_out) return fail(PROQA_EINVAL, "attention: NULL argument");
   if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention: bad sizes");
   const int s_pad = (seq_len + 31) & ~31;
-  const size_t lds = (size_t)s_pad * (kKStride + kVStride) * sizeof(_Float16);
+  const size_t lds = ((size_t)s_pad * kKStride + (size_t)kHeadDim * (s_pad + kVtPad)) * sizeof(_Float16);
   if (lds > 160 * 1024) return fail(PROQA_EINVAL, "attention: seq_len=%d needs %zu B of LDS (> 160 KiB)", seq_len, lds);
   if (batch == 0) return PROQA_OK;
   if (lds > 64 * 1024) {

@@ -68,7 +68,12 @@ def get_score(answer_doc, topk=80):
 
 
 def convert_idx2id(idxs, mapping_path=DEFAULT_IDX_ID):
-    """Row indices of the index -> document ids via idx_id.json ({"<row>": doc_id})."""
+    """Row indices of the index -> document ids via idx_id.json ({"<row>": doc_id}), or via the
+    memory-mapped sidecar written by gen_index_id_map (path ending in .ids): same result."""
+    if mapping_path.endswith(".ids"):
+        from .gen_index_id_map import SidecarMap
+        idx_id = SidecarMap(mapping_path)
+        return [[idx_id[int(i)] for i in row] for row in idxs]
     with open(mapping_path) as f:
         idx_id = json.load(f)
     return [[idx_id[str(int(i))] for i in row] for row in idxs]

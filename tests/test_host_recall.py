@@ -69,3 +69,23 @@ def test_cli_parser_defaults():
     assert (a.topk, a.num_workers, a.idx_id_map) == (80, 10, "../pretrained_models/idx_id.json")
     a = ev.build_parser().parse_args(["qa.txt", "idx.npy", "q.npy", "paras.db", "--topk", "8", "--num-workers", "2"])
     assert (a.topk, a.num_workers) == (8, 2)
+
+
+def test_sidecar_map_equals_json_route(gold, tmp_path):
+    """the binary sidecar returns exactly what idx_id.json returns."""
+    from proqa_amd import gen_index_id_map as gm
+    corpus = tmp_path / "paras.txt"
+    docs = gold["docs"] + [["unié-\u00e9", "x"], [12345, "int id"], ["with \"quote\"", "y"]]
+    corpus.write_text("".join(json.dumps({"id": d[0], "text": d[1]}) + "\n" for d in docs))
+    out = tmp_path / "idx_id.json"
+    n = gm.build(str(corpus), str(out), sidecar=True)
+    assert n == len(docs)
+    assert json.load(open(out)) == {str(i): d[0] for i, d in enumerate(docs)}
+    rows = np.array([[0, 5, n - 1], [n - 2, 3, n - 3]])
+    via_json = ev.convert_idx2id(rows, str(out))
+    via_sidecar = ev.convert_idx2id(rows, str(tmp_path / "idx_id.ids"))
+    assert via_json == via_sidecar
+    with pytest.raises(KeyError):
+        ev.convert_idx2id(np.array([[n]]), str(tmp_path / "idx_id.ids"))
+    with pytest.raises(KeyError):
+        ev.convert_idx2id(np.array([[n]]), str(out))
