@@ -41,6 +41,10 @@ struct proqa_index {
   float* tau = nullptr;
   unsigned* run_n = nullptr;
   unsigned long long* run_keys = nullptr;
+  // paged search (k > kPageK): per query bound of the next page
+  unsigned long long* bound_keys = nullptr;
+  float* ub = nullptr;
+  unsigned char* done = nullptr;
   // candidate records of one filter launch (see CandidateStore in mips_kernels.h)
   proqa::WaveRecord* lane_log = nullptr;
   unsigned* lane_cnt = nullptr;
@@ -57,7 +61,7 @@ struct proqa_index {
   void* stage_pinned = nullptr;
   size_t stage_pinned_bytes = 0;
   hipEvent_t ev[2] = {nullptr, nullptr};
-  hipEvent_t ev_filter[2 * 64] = {};       // per-round brackets, created when profiling is on
+  hipEvent_t ev_filter[2 * 96] = {};       // per-round brackets, created when profiling is on
   bool profile = false;
   // tuning
   int first_slab_rows = 256;
@@ -68,7 +72,7 @@ struct proqa_index {
 namespace proqa {
 namespace {
 
-constexpr int kMaxRounds = 64;
+constexpr int kMaxRounds = 96;
 
 int ensure_device(proqa_index* idx) {
   int dev = 0;
@@ -118,7 +122,10 @@ void free_store(proqa_index* idx) {
 }
 
 void free_workspace(proqa_index* idx) {
-  void* ptrs[] = {idx->xq_pad, idx->tau, idx->run_n, idx->run_keys, idx->stat_dev};
+  void* ptrs[] = {idx->xq_pad, idx->tau, idx->run_n, idx->run_keys, idx->stat_dev, idx->bound_keys, idx->ub, idx->done};
+  idx->bound_keys = nullptr;
+  idx->ub = nullptr;
+  idx->done = nullptr;
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   idx->xq_pad = nullptr;
@@ -141,6 +148,9 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
   PROQA_HIP(hipMalloc((void**)&idx->run_n, (size_t)q * sizeof(unsigned)));
   PROQA_HIP(hipMalloc((void**)&idx->run_keys, (size_t)q * kk * sizeof(unsigned long long)));
   PROQA_HIP(hipMalloc((void**)&idx->stat_dev, (size_t)q * sizeof(unsigned long long)));
+  PROQA_HIP(hipMalloc((void**)&idx->bound_keys, (size_t)q * sizeof(unsigned long long)));
+  PROQA_HIP(hipMalloc((void**)&idx->ub, (size_t)q * sizeof(float)));
+  PROQA_HIP(hipMalloc((void**)&idx->done, (size_t)q));
   if (idx->stat_host) PROQA_HIP(hipHostFree(idx->stat_host));
   idx->stat_host = nullptr;
   PROQA_HIP(hipHostMalloc((void**)&idx->stat_host, (size_t)q * sizeof(unsigned long long), hipHostMallocDefault));
@@ -165,8 +175,14 @@ int ensure_store(proqa_index* idx, unsigned chunks, unsigned n_qtiles, int64_t n
   return PROQA_OK;
 }
 
-// geometric slab schedule over [0, n)
-std::vector<Slab> plan_slabs(long long n, int first, int growth) {
+// Geometric slab schedule over [0, n).  After `seen` rows the threshold is the k-th best of them,
+// so a slab of g*seen rows yields ~g*k candidates per query; g is capped so that those fit the
+// lane lists and one LDS merge pass next to the k running keys (kCandidateBudget per round).
+constexpr double kCandidateBudget = 640.0;
+
+double growth_for(int k, int configured) { return std::min<double>(configured, kCandidateBudget / k); }
+
+std::vector<Slab> plan_slabs(long long n, int first, double growth) {
   std::vector<Slab> out;
   long long seen = 0;
   long long next = std::min<long long>(n, round_up<long long>(first, kStageRows));
@@ -176,7 +192,7 @@ std::vector<Slab> plan_slabs(long long n, int first, int growth) {
     if (n - r1 < next / 4) r1 = n;
     out.push_back({seen, r1});
     seen = r1;
-    next = round_up<long long>(seen * growth, kStageRows);
+    next = std::max<long long>(kStageRows, round_up<long long>((long long)(seen * growth), kStageRows));
   }
   return out;
 }
@@ -189,8 +205,10 @@ struct LaunchGeom {
 
 LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage) {
   const int cus = device_cu_count();
-  // one workgroup per CU: target_chunks * n_qtiles ~= #CUs, chunks a multiple of 8 (XCD map)
-  long long target = std::max<long long>(8, (cus / (long long)n_qtiles) / 8 * 8);
+  // one workgroup per CU: target_chunks * n_qtiles ~= #CUs, chunks a multiple of 8 (XCD map); never
+  // fewer than 64 chunks, so that a round's ~kCandidateBudget records per query spread over >= 128
+  // lane lists (capacity kLaneCap each) however many query tiles there are
+  long long target = std::max<long long>(64, (cus / (long long)n_qtiles) / 8 * 8);
   long long rpc = round_up<long long>(ceil_div<long long>(slab_rows, target), kStageRows);
   // dense launches (threshold -inf, or the inclusive overflow-safe re-scan) log EVERY tile: a lane
   // list holds exactly one stage of them (kLaneCap = 8 tiles), so each chunk is one stage
@@ -211,7 +229,8 @@ CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtil
 }
 
 int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
-              bool inclusive, bool dense, unsigned* overflow_word, hipStream_t st, hipEvent_t f0, hipEvent_t f1) {
+              bool inclusive, bool dense, bool bounded, unsigned* overflow_word, hipStream_t st, hipEvent_t f0,
+              hipEvent_t f1) {
   const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense);
   if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad)) return rc;
   FilterArgs fa;
@@ -221,6 +240,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   fa.slab_row1 = slab.r1;
   fa.rows_per_chunk = g.rows_per_chunk;
   fa.tau = idx->tau;
+  fa.ub = bounded ? idx->ub : nullptr;
   fa.store = store_of(idx, (unsigned)idx->ws_nq_pad, n_qtiles);
   fa.overflow = overflow_word;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
@@ -236,44 +256,30 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.tau = idx->tau;
   ma.k = k;
   ma.inclusive = inclusive ? 1 : 0;
+  ma.bound_keys = bounded ? idx->bound_keys : nullptr;
   ma.stat_candidates = idx->stat_dev;
   ma.overflow = overflow_word;
   PROQA_HIP(launch_merge(ma, nq_pad, st));
   return PROQA_OK;
 }
 
-int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
-                  float* D_dev, int64_t* I_dev, hipStream_t st) {
-  if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
-  if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "search: bad dtype %d", dtype);
-  if (k > kMaxSortKeys / 2)
-    return fail(PROQA_EINVAL, "search: k=%d exceeds %d (large-k search is not built yet)", k, kMaxSortKeys / 2);
-  if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
-  idx->stats = {};
-  if (nq == 0) return PROQA_OK;
-  if (int rc = ensure_device(idx)) return rc;
-
-  // wave tile: 2 query blocks of 32 per wave (512 queries per workgroup) unless the batch is small
-  const int qw = nq > 256 ? 2 : 1;
-  const unsigned tile_q = kFilterWaves * qw * 32;
-  const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
-  const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
-  if (int rc = ensure_workspace(idx, nq_pad, k)) return rc;
-
-  PROQA_HIP(hipEventRecord(idx->ev[0], st));
+// One page of results (page_k <= kPageK best rows below the page bound): rounds of filter + merge
+// over geometrically growing slabs, then the overflow-safe re-scan of any round that overflowed.
+int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
+                hipStream_t st, int* fallback_out) {
   PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
-  PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
-                                st));
-
   // every row of the first slab is a candidate (threshold -inf): it must fit one merge pass
-  const int first = std::min<int>(idx->first_slab_rows, (kMaxSortKeys - k) / kStageRows * kStageRows);
-  std::vector<Slab> slabs = plan_slabs(idx->n, first, idx->growth);
+  const int first = std::min<int>(idx->first_slab_rows, (kMaxSortKeys - page_k) / kStageRows * kStageRows);
+  std::vector<Slab> slabs = plan_slabs(idx->n, first, growth_for(page_k, idx->growth));
   if ((int)slabs.size() > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
+  const bool prof = idx->profile && !bounded;  // the per-round brackets describe the first page
   for (size_t r = 0; r < slabs.size(); ++r) {
-    hipEvent_t f0 = idx->profile ? idx->ev_filter[2 * r] : nullptr;
-    hipEvent_t f1 = idx->profile ? idx->ev_filter[2 * r + 1] : nullptr;
-    if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, k, false, r == 0, idx->overflow + r, st,
-                           f0, f1))
+    hipEvent_t f0 = prof ? idx->ev_filter[2 * r] : nullptr;
+    hipEvent_t f1 = prof ? idx->ev_filter[2 * r + 1] : nullptr;
+    // while fewer than page_k rows have been merged the threshold is still -inf: every row is logged
+    const bool dense = slabs[r].r0 < page_k;
+    if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, page_k, false, dense, bounded,
+                           idx->overflow + r, st, f0, f1))
       return rc;
     if (getenv("PROQA_DEBUG_CAND")) {
       (void)hipStreamSynchronize(st);
@@ -287,32 +293,21 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
                            hipMemcpyDeviceToHost, st));
   PROQA_HIP(hipStreamSynchronize(st));
 
-  int fallback = 0;
   for (size_t r = 0; r < slabs.size(); ++r) {
     if (!idx->overflow_host[r]) continue;
     // overflow-safe re-scan: a sub-slab has fewer rows than one merge pass holds keys and every
     // chunk is a single stage, so neither the lane lists nor the merge can overflow
-    const long long step = (long long)((kMaxSortKeys - k) / kStageRows) * kStageRows;
+    const long long step = (long long)((kMaxSortKeys - page_k) / kStageRows) * kStageRows;
     for (long long r0 = slabs[r].r0; r0 < slabs[r].r1; r0 += step) {
       Slab sub{r0, std::min(slabs[r].r1, r0 + step)};
-      if (int rc = run_round(idx, sub, qw, n_qtiles, (unsigned)nq_pad, k, true, true, idx->overflow + kMaxRounds - 1,
-                             st, nullptr, nullptr))
+      if (int rc = run_round(idx, sub, qw, n_qtiles, (unsigned)nq_pad, page_k, true, true, bounded,
+                             idx->overflow + kMaxRounds - 1, st, nullptr, nullptr))
         return rc;
-      ++fallback;
+      ++*fallback_out;
     }
   }
-
-  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, idx_offset, D_dev, (long long*)I_dev, st));
-  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, st));
-  PROQA_HIP(hipEventRecord(idx->ev[1], st));
-  PROQA_HIP(hipStreamSynchronize(st));
-
-  idx->stats.rounds = (int)slabs.size();
-  idx->stats.fallback_rounds = fallback;
-  for (int64_t i = 0; i < nq; ++i) idx->stats.candidates += (int64_t)idx->stat_host[i];
-  (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
-  if (idx->profile) {
+  idx->stats.rounds += (int)slabs.size();
+  if (prof) {
     float sum = 0.f;
     for (size_t r = 0; r < slabs.size(); ++r) {
       float ms = 0.f;
@@ -324,12 +319,55 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
       for (size_t r = 0; r < slabs.size(); ++r) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, idx->ev_filter[2 * r], idx->ev_filter[2 * r + 1]);
-        const LaunchGeom g = geometry(slabs[r].r1 - slabs[r].r0, n_qtiles, r == 0);
+        const LaunchGeom g = geometry(slabs[r].r1 - slabs[r].r0, n_qtiles, slabs[r].r0 < page_k);
         fprintf(stderr, "round %zu rows [%lld,%lld) grid %u rpc %d filter %.3f ms\n", r, slabs[r].r0, slabs[r].r1,
                 g.grid, g.rows_per_chunk, ms);
       }
     }
   }
+  return PROQA_OK;
+}
+
+int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
+                  float* D_dev, int64_t* I_dev, hipStream_t st) {
+  if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
+  if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "search: bad dtype %d", dtype);
+  if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
+  idx->stats = {};
+  if (nq == 0) return PROQA_OK;
+  if (int rc = ensure_device(idx)) return rc;
+
+  // wave tile: 2 query blocks of 32 per wave (512 queries per workgroup) unless the batch is small
+  const int qw = nq > 256 ? 2 : 1;
+  const unsigned tile_q = kFilterWaves * qw * 32;
+  const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
+  const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
+  if (int rc = ensure_workspace(idx, nq_pad, std::min(k, kPageK))) return rc;
+
+  PROQA_HIP(hipEventRecord(idx->ev[0], st));
+  // k <= kPageK: one page.  Larger k (retrieval/trec_process.py:76 asks for 10000) is served page by
+  // page: page p re-runs the search restricted to keys strictly below the last key of page p-1.
+  int fallback = 0;
+  const int n_pages = ceil_div<int>(k, kPageK);
+  if (n_pages > 1) PROQA_HIP(hipMemsetAsync(idx->done, 0, (size_t)idx->ws_nq_pad, st));
+  for (int p = 0; p < n_pages; ++p) {
+    const int page_k = std::min(kPageK, k - p * kPageK);
+    PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
+                                  p > 0 ? idx->done : nullptr, p == 0, st));
+    if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, st, &fallback)) return rc;
+    PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, idx_offset, D_dev, (long long*)I_dev, k,
+                              p * kPageK, st));
+    if (p + 1 < n_pages)
+      PROQA_HIP(launch_advance_page(idx->run_keys, idx->run_n, nq, page_k, idx->bound_keys, idx->ub, idx->done, st));
+  }
+  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipEventRecord(idx->ev[1], st));
+  PROQA_HIP(hipStreamSynchronize(st));
+
+  idx->stats.fallback_rounds = fallback;
+  for (int64_t i = 0; i < nq; ++i) idx->stats.candidates += (int64_t)idx->stat_host[i];
+  (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
   return PROQA_OK;
 }
 

@@ -13,6 +13,7 @@ constexpr int kFilterThreads = kFilterWaves * 64;
 constexpr int kStageRows = 128;  // corpus rows per LDS stage (32 KiB of fp16 rows)
 constexpr int kMergeThreads = 256;
 constexpr int kMaxSortKeys = 2048;  // running list + candidates of one query per merge (LDS)
+constexpr int kPageK = kMaxSortKeys / 2;  // results per page; k > kPageK is served page by page
 constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling
 constexpr int kSpillCap = 256;      // shared spill records per (chunk, wave)
 constexpr int kMaxListParts = 4096; // n_parts * k bound of proqa_topk_merge_device
@@ -51,6 +52,7 @@ struct FilterArgs {
   long long slab_row1;
   int rows_per_chunk;    // multiple of kStageRows; one workgroup per (chunk, query tile)
   const float* tau;      // running k-th best score per query (-inf until k rows were seen)
+  const float* ub;       // paged (k > kPageK) searches: scores above ub[q] were reported by an earlier page
   CandidateStore store;
   unsigned* overflow;    // set to 1 if a record had to be dropped in this launch
 };
@@ -64,16 +66,22 @@ struct MergeArgs {
   float* tau;
   int k;
   int inclusive;                 // overflow-safe rounds: >= threshold, duplicates removed
+  const unsigned long long* bound_keys;  // paged searches: only keys strictly below bound_keys[q] count (or NULL)
   unsigned long long* stat_candidates;  // [nq_pad] candidates merged per query (statistics)
   unsigned* overflow;
 };
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);
+hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
+                               unsigned long long* bound_keys, float* ub, unsigned char* done, hipStream_t st);
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st);
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
-                               float* tau, unsigned* run_n, unsigned long long* stat, hipStream_t st);
-hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int k,
-                           long long idx_offset, float* D, long long* I, hipStream_t st);
+                               float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
+                               bool reset_stat, hipStream_t st);
+// writes page results: D/I[q * out_stride + out_offset + j], j < page_k
+hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
+                           long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
+                           hipStream_t st);
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
                               int k, float* D, long long* I, hipStream_t st);
 hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, hipStream_t st);

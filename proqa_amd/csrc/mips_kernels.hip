@@ -117,7 +117,7 @@ __device__ __forceinline__ void log_columns(const f32x16& acc, bool hit, float t
 //     At the barrier of stage s (before its unit 2): every wave is past stage s-1, whose buffer
 //     (s+2)%3 is therefore free for DMA(s+2); and every wave has drained (vmcnt 0) its pieces of
 //     DMA(s+1), issued one full stage earlier, so buffer (s+1)%3 is readable from unit 3 on.
-template <int QW, bool INCLUSIVE>
+template <int QW, bool INCLUSIVE, bool BOUNDED>
 __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) {
   static_assert(QW == 1 || QW == 2, "two accumulators per unit");
   // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads)
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
   const unsigned q0 = qt * (kFilterWaves * QW * 32) + wave * (QW * 32);
   f16x8 qf[QW][8];
   float tau[2] = {0.f, 0.f};
+  float ub[2] = {0.f, 0.f};  // BOUNDED (pages after the first of a k > kPageK search)
   WaveRecord* lane_list[2] = {nullptr, nullptr};
   unsigned lane_n[2] = {0u, 0u};
 #pragma unroll
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[blk][j] = *(const f16x8*)(qrow + (2 * j + half) * 16);
     tau[blk] = a.tau[q];
+    if (BOUNDED) ub[blk] = a.ub[q];
     lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * kLaneCap;
   }
   const unsigned wave_slot = (chunk * a.store.n_qtiles + qt) * kFilterWaves + wave;
@@ -214,6 +216,10 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
     bool hit[2] = {false, false};
 #pragma unroll
     for (int blk = 0; blk < QW; ++blk) {
+      if (BOUNDED) {  // rows scoring above the page bound were reported by an earlier page
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pend[blk][r] = pend[blk][r] <= ub[blk] ? pend[blk][r] : -__builtin_inff();
+      }
       float m = pend[blk][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
@@ -284,7 +290,8 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 // with 8 workgroups resident per CU).  Overflow-safe rounds (inclusive threshold, rows may repeat)
 // additionally drop adjacent duplicates.
 __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned q, bool inclusive,
-                                                 unsigned long long* keys, unsigned* n_keys) {
+                                                 unsigned long long bound, unsigned long long* keys,
+                                                 unsigned* n_keys) {
   const uint4 h = src[0];
   if (h.x != q) return;  // spill logs mix the wave's queries
   const float tau = __uint_as_float(h.w);
@@ -296,19 +303,22 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if ((inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
-        const unsigned pos = atomicAdd(n_keys, 1u);  // LDS
-        if (pos < (unsigned)kMaxSortKeys) keys[pos] = pack_key(sc[e], h.y + (unsigned)(e + 8 * g));
+        const unsigned long long key = pack_key(sc[e], h.y + (unsigned)(e + 8 * g));
+        if (key < bound) {  // paged search: ties with the bound score that were already reported
+          const unsigned pos = atomicAdd(n_keys, 1u);  // LDS
+          if (pos < (unsigned)kMaxSortKeys) keys[pos] = key;
+        }
       }
     }
   }
 }
 
 __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
-                                            unsigned long long* keys, unsigned* n_keys) {
+                                            unsigned long long bound, unsigned long long* keys, unsigned* n_keys) {
   uint4 buf[5];
 #pragma unroll
   for (int g = 0; g < 5; ++g) buf[g] = ((const uint4*)rec)[g];
-  keep_scores_regs(buf, q, inclusive, keys, n_keys);
+  keep_scores_regs(buf, q, inclusive, bound, keys, n_keys);
 }
 
 __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   const CandidateStore& st = a.store;
   const unsigned n_lists = 2 * a.n_chunks;
   const bool inclusive = a.inclusive != 0;
+  const unsigned long long bound = a.bound_keys ? a.bound_keys[q] : ~0ull;
 
   // the wave slot that owns q in every chunk
   const unsigned tile_q = kFilterWaves * a.qw * 32;
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
       if (slot < s_lane_cnt[t]) {
         const unsigned l = base + t;
         const WaveRecord* rec = st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * kLaneCap + slot;
-        keep_scores(rec, q, inclusive, keys, &s_n_keys);
+        keep_scores(rec, q, inclusive, bound, keys, &s_n_keys);
       }
     }
     // spill logs of the wave slot (usually all empty): one wave per non-empty chunk
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
         const unsigned c = (base >> 1) + t;
         const size_t slot = (size_t)(c * st.n_qtiles + qt) * kFilterWaves + wave;
         for (unsigned i = lane; i < n; i += 64)
-          keep_scores(st.spill_log + slot * kSpillCap + i, q, inclusive, keys, &s_n_keys);
+          keep_scores(st.spill_log + slot * kSpillCap + i, q, inclusive, bound, keys, &s_n_keys);
       }
     }
     __syncthreads();
@@ -435,7 +446,8 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
 // ---------------------------------------------------------------------------------------
 // pad + convert queries to the fp16 [Qpad,128] operand layout, reset per-query state
 __global__ void prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, _Float16* xq_pad,
-                             float* tau, unsigned* run_n, unsigned long long* stat, int debug_nohit) {
+                             float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
+                             int reset_stat, int debug_nohit) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = nq_pad * kDim;
   if (i < n) {
@@ -445,25 +457,43 @@ __global__ void prep_queries(const void* xq, int dtype, long long nq, long long 
     xq_pad[i] = (_Float16)v;
   }
   if (i < nq_pad) {
-    tau[i] = (i < nq && !debug_nohit) ? -__builtin_inff() : __builtin_inff();  // padded queries never log
+    // padded queries (and queries a paged search has already exhausted) never log
+    const bool live = i < nq && !debug_nohit && !(done && done[i]);
+    tau[i] = live ? -__builtin_inff() : __builtin_inff();
     run_n[i] = 0;
-    stat[i] = 0;
+    if (reset_stat) stat[i] = 0;
   }
 }
 
 __global__ void finalize_topk(const unsigned long long* run_keys, const unsigned* run_n, long long nq,
-                              int k, long long idx_offset, float* D, long long* I) {
+                              int k, long long idx_offset, float* D, long long* I, int out_stride, int out_offset) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq * k) return;
   const long long q = i / k;
   const int j = (int)(i - q * k);
+  const long long o = q * out_stride + out_offset + j;
   if ((unsigned)j < run_n[q]) {
     const unsigned long long key = run_keys[q * k + j];
-    D[i] = float_from_ord((unsigned)(key >> 32));
-    I[i] = idx_offset + (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+    D[o] = float_from_ord((unsigned)(key >> 32));
+    I[o] = idx_offset + (long long)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
   } else {
-    D[i] = -3.4028234663852886e38f;  // faiss CMin<float>::neutral()
-    I[i] = -1;
+    D[o] = -3.4028234663852886e38f;  // faiss CMin<float>::neutral()
+    I[o] = -1;
+  }
+}
+
+// after a page of a k > kPageK search: the last reported key bounds the next page; a query whose
+// page came back short has no more rows
+__global__ void advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
+                             unsigned long long* bound_keys, float* ub, unsigned char* done) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  if (run_n[q] == (unsigned)page_k && !done[q]) {
+    const unsigned long long key = run_keys[q * page_k + page_k - 1];
+    bound_keys[q] = key;
+    ub[q] = float_from_ord((unsigned)(key >> 32));
+  } else {
+    done[q] = 1;
   }
 }
 
@@ -537,19 +567,34 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __rest
 // ---------------------------------------------------------------------------------------
 // launch wrappers (called from mips_index.cpp)
 // ---------------------------------------------------------------------------------------
+template <int QW, bool INCLUSIVE>
+static void launch_filter_bounded(const FilterArgs& a, dim3 g, dim3 blk, hipStream_t st) {
+  if (a.ub)
+    hipLaunchKernelGGL((mips_filter_f16<QW, INCLUSIVE, true>), g, blk, 0, st, a);
+  else
+    hipLaunchKernelGGL((mips_filter_f16<QW, INCLUSIVE, false>), g, blk, 0, st, a);
+}
+
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st) {
   dim3 g(grid), blk(kFilterThreads);
   if (qw == 2) {
     if (inclusive)
-      hipLaunchKernelGGL((mips_filter_f16<2, true>), g, blk, 0, st, a);
+      launch_filter_bounded<2, true>(a, g, blk, st);
     else
-      hipLaunchKernelGGL((mips_filter_f16<2, false>), g, blk, 0, st, a);
+      launch_filter_bounded<2, false>(a, g, blk, st);
   } else {
     if (inclusive)
-      hipLaunchKernelGGL((mips_filter_f16<1, true>), g, blk, 0, st, a);
+      launch_filter_bounded<1, true>(a, g, blk, st);
     else
-      hipLaunchKernelGGL((mips_filter_f16<1, false>), g, blk, 0, st, a);
+      launch_filter_bounded<1, false>(a, g, blk, st);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
+                               unsigned long long* bound_keys, float* ub, unsigned char* done, hipStream_t st) {
+  hipLaunchKernelGGL(advance_page, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, run_keys, run_n, nq, page_k,
+                     bound_keys, ub, done);
   return hipGetLastError();
 }
 
@@ -559,19 +604,22 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
 }
 
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
-                               float* tau, unsigned* run_n, unsigned long long* stat, hipStream_t st) {
+                               float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
+                               bool reset_stat, hipStream_t st) {
   const long long n = nq_pad * kDim;
   hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
-                     (_Float16*)xq_pad, tau, run_n, stat, getenv("PROQA_DEBUG_NOHIT") ? 1 : 0);
+                     (_Float16*)xq_pad, tau, run_n, stat, done, reset_stat ? 1 : 0,
+                     getenv("PROQA_DEBUG_NOHIT") ? 1 : 0);
   return hipGetLastError();
 }
 
-hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int k,
-                           long long idx_offset, float* D, long long* I, hipStream_t st) {
-  const long long n = nq * k;
+hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
+                           long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
+                           hipStream_t st) {
+  const long long n = nq * page_k;
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(finalize_topk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, run_keys, run_n,
-                     nq, k, idx_offset, D, I);
+                     nq, page_k, idx_offset, D, I, out_stride, out_offset);
   return hipGetLastError();
 }
 
