@@ -57,8 +57,6 @@ _REFERENCE_FLAGS = (
 EXTRA_FLAGS = (
     # fp32 .npy output (the reference writes whatever dtype the model emitted: fp16 under --fp16)
     ("--embed_dtype", str, "auto"),
-    # sort each loader window by length before batching (order is restored); 0 disables
-    ("--length_bucket_window", int, 0),
 )
 
 

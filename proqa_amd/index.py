@@ -42,6 +42,9 @@ def _as_matrix(x, d, what):
     return x
 
 
+QUERY_BATCH = 16384   # queries per library call: bounds the per-search candidate store in HBM
+
+
 class IndexFlatIP:
     """Brute-force maximum-inner-product index; rows live in HBM as fp16."""
 
@@ -77,8 +80,10 @@ class IndexFlatIP:
         nq = xq.shape[0]
         D = np.empty((nq, k), dtype=np.float32)
         I = np.empty((nq, k), dtype=np.int64)
-        _lib.check(self._lib.proqa_index_search(self._h, xq.ctypes.data, nq, _np_dtype_code(xq), int(k),
-                                                D.ctypes.data, I.ctypes.data))
+        for q0 in range(0, max(nq, 1), QUERY_BATCH):
+            part = xq[q0:q0 + QUERY_BATCH]
+            _lib.check(self._lib.proqa_index_search(self._h, part.ctypes.data, part.shape[0], _np_dtype_code(xq),
+                                                    int(k), D[q0:].ctypes.data, I[q0:].ctypes.data))
         return D, I
 
     def reset(self):
@@ -119,9 +124,12 @@ class IndexFlatIP:
         D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
         I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
         with torch.cuda.device(xq.device):
-            _lib.check(self._lib.proqa_index_search_device(self._h, xq.data_ptr(), nq, _torch_dtype_code(xq), int(k),
-                                                           int(idx_offset), D.data_ptr(), I.data_ptr(),
-                                                           _lib.current_stream_ptr()))
+            for q0 in range(0, max(nq, 1), QUERY_BATCH):
+                part = xq[q0:q0 + QUERY_BATCH]
+                _lib.check(self._lib.proqa_index_search_device(self._h, part.data_ptr(), part.shape[0],
+                                                               _torch_dtype_code(xq), int(k), int(idx_offset),
+                                                               D[q0:].data_ptr(), I[q0:].data_ptr(),
+                                                               _lib.current_stream_ptr()))
         return D, I
 
     # -- introspection / tuning ---------------------------------------------------------
