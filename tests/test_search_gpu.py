@@ -212,3 +212,30 @@ def test_large_k_random_scores(gpu_device):
     assert all(len(set(r)) == 10000 for r in I)
     agree = np.mean([len(set(a) & set(b)) / 10000.0 for a, b in zip(I, Io)])
     assert agree > 1 - 1e-4
+
+
+def test_randomised_shapes_against_oracle(gpu_device):
+    """Seeded sweep over ragged shapes (rows not a multiple of the 128-row stage or the 32-row tile,
+    query counts straddling the 256/512 tile sizes, k from 1 to several hundred, repeated searches on
+    one handle with growing index and changing k): ids and scores bit-identical on integer data."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(2024)
+    index = IndexFlatIP(128)
+    xb_all = np.zeros((0, 128), np.float16)
+    for trial in range(24):
+        n_add = int(rng.choice([1, 31, 33, 127, 129, 500, 2049, 7777, 20000]))
+        nq = int(rng.choice([1, 2, 31, 32, 33, 255, 256, 257, 511, 513, 700]))
+        k = int(rng.choice([1, 2, 7, 80, 81, 200, 511, 700]))
+        lo, hi = (-1, 1) if trial % 3 == 0 else (-4, 4)      # narrow range => heavy ties
+        xb = _int_corpus(rng, n_add, lo=lo, hi=hi)
+        xq = _int_corpus(rng, nq, lo=lo, hi=hi)
+        if trial % 8 == 7:
+            index.reset()
+            xb_all = np.zeros((0, 128), np.float16)
+        index.add(xb)
+        xb_all = np.concatenate([xb_all, xb])
+        assert index.ntotal == len(xb_all)
+        D, I = index.search(xq, k)
+        Do, Io = search_oracle.topk_ip(xq, xb_all, k)
+        np.testing.assert_array_equal(I, Io, err_msg=f"trial {trial}: n={len(xb_all)} nq={nq} k={k}")
+        np.testing.assert_array_equal(D, Do)
