@@ -265,8 +265,16 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
 
 // One page of results (page_k <= kPageK best rows below the page bound): rounds of filter + merge
 // over geometrically growing slabs, then the overflow-safe re-scan of any round that overflowed.
+struct PageOut {
+  float* D;
+  long long* I;
+  long long idx_offset;
+  int out_stride;  // k of the whole search
+  int out_offset;  // first result slot of this page
+};
+
 int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
-                hipStream_t st, int* fallback_out) {
+                const PageOut& out, hipStream_t st, int* fallback_out) {
   PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
   // every row of the first slab is a candidate (threshold -inf): it must fit one merge pass
   const int first = std::min<int>(idx->first_slab_rows, (kMaxSortKeys - page_k) / kStageRows * kStageRows);
@@ -289,10 +297,18 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
       fprintf(stderr, "after round %zu: cumulative candidates %llu\n", r, c);
     }
   }
+  // results are written optimistically before the one host sync of the page; they are rewritten
+  // below only if a round overflowed and had to be re-scanned
+  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, out.idx_offset, out.D, out.I, out.out_stride,
+                            out.out_offset, st));
   PROQA_HIP(hipMemcpyAsync(idx->overflow_host, idx->overflow, kMaxRounds * sizeof(unsigned),
                            hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipEventRecord(idx->ev[1], st));
   PROQA_HIP(hipStreamSynchronize(st));
 
+  const int fallback_before = *fallback_out;
   for (size_t r = 0; r < slabs.size(); ++r) {
     if (!idx->overflow_host[r]) continue;
     // overflow-safe re-scan: a sub-slab has fewer rows than one merge pass holds keys and every
@@ -305,6 +321,14 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
         return rc;
       ++*fallback_out;
     }
+  }
+  if (*fallback_out != fallback_before) {
+    PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, out.idx_offset, out.D, out.I, out.out_stride,
+                              out.out_offset, st));
+    PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, st));
+    PROQA_HIP(hipEventRecord(idx->ev[1], st));
+    PROQA_HIP(hipStreamSynchronize(st));
   }
   idx->stats.rounds += (int)slabs.size();
   if (prof) {
@@ -354,16 +378,12 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
     const int page_k = std::min(kPageK, k - p * kPageK);
     PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
                                   p > 0 ? idx->done : nullptr, p == 0, st));
-    if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, st, &fallback)) return rc;
-    PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, idx_offset, D_dev, (long long*)I_dev, k,
-                              p * kPageK, st));
+    const PageOut out{D_dev, (long long*)I_dev, idx_offset, k, p * kPageK};
+    if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, out, st, &fallback)) return rc;
     if (p + 1 < n_pages)
       PROQA_HIP(launch_advance_page(idx->run_keys, idx->run_n, nq, page_k, idx->bound_keys, idx->ub, idx->done, st));
   }
-  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, st));
-  PROQA_HIP(hipEventRecord(idx->ev[1], st));
-  PROQA_HIP(hipStreamSynchronize(st));
+  if (n_pages > 1) PROQA_HIP(hipStreamSynchronize(st));  // the last advance_page
 
   idx->stats.fallback_rounds = fallback;
   for (int64_t i = 0; i < nq; ++i) idx->stats.candidates += (int64_t)idx->stat_host[i];
