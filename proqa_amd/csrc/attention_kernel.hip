@@ -33,6 +33,9 @@ constexpr int kKStride = kHeadDim + 8;  // fp16 elements per K row in LDS (144 B
 // 8-byte read; rows are s_pad + 4 keys long: (s_pad*2 + 8) bytes = 2 banks more per d row, which
 // spreads the 32 d rows of a ds_read_b64 over distinct bank pairs
 constexpr int kVtPad = 4;
+// per-wave output staging tile [32 queries][64 + 8]: the lane-owned 8-byte pieces of O^T are
+// transposed through LDS so that the context rows leave as full 128-byte lines
+constexpr int kOutStride = kHeadDim + 8;
 
 __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict__ qkv,
                                                      const int* __restrict__ seq_lens, int seq_len,
@@ -42,6 +45,8 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   _Float16* k_lds = smem;                       // [s_pad][kKStride]
   _Float16* vt_lds = smem + s_pad * kKStride;   // [kHeadDim][s_pad + kVtPad]  (V transposed)
   const int vt_stride = s_pad + kVtPad;
+  // per-wave output staging tile (aliasing it onto the K rows behind a barrier was measured slower)
+  _Float16* out_lds = vt_lds + kHeadDim * vt_stride + (threadIdx.x >> 6) * 32 * kOutStride;
 
   const int b = blockIdx.x / n_heads;
   const int head = blockIdx.x - b * n_heads;
@@ -73,6 +78,30 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   const int li = lane & 31;
   const int half = lane >> 5;
   const int n_qblocks = s_pad >> 5;
+
+  auto write_out = [&](int qb, const f32x16& o0, const f32x16& o1, float l) {
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f16x4 a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = (_Float16)(o0[g * 4 + e] * inv);
+        c[e] = (_Float16)(o1[g * 4 + e] * inv);
+      }
+      *(f16x4*)(out_lds + li * kOutStride + g * 8 + 4 * half) = a;
+      *(f16x4*)(out_lds + li * kOutStride + 32 + g * 8 + 4 * half) = c;
+    }
+    // same wave writes and reads the tile: LDS ops of a wave complete in order
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + (lane >> 3), piece = lane & 7;   // 8 lanes x 16 B = one 128-byte row
+      const int qq = qb * 32 + row;
+      const f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8);
+      if (qq < seq_len)
+        *(f16x8*)(ctx + ((long long)b * seq_len + qq) * hidden + head * kHeadDim + piece * 8) = v;
+    }
+  };
 
   for (int qb = wave; qb < n_qblocks; qb += 4) {
     const int q = qb * 32 + li;
@@ -144,21 +173,7 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
       }
     }
 
-    if (q < seq_len) {
-      const float inv = 1.0f / l;
-      _Float16* dst = ctx + ((long long)b * seq_len + q) * hidden + head * kHeadDim;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f16x4 a, c;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a[e] = (_Float16)(o0[g * 4 + e] * inv);
-          c[e] = (_Float16)(o1[g * 4 + e] * inv);
-        }
-        *(f16x4*)(dst + g * 8 + 4 * half) = a;
-        *(f16x4*)(dst + 32 + g * 8 + 4 * half) = c;
-      }
-    }
+    write_out(qb, o0, o1, l);
   }
 }
 
@@ -172,7 +187,8 @@ extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev,
   if (!qkv || !ctx_out) return fail(PROQA_EINVAL, "attention: NULL argument");
   if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention: bad sizes");
   const int s_pad = (seq_len + 31) & ~31;
-  const size_t lds = ((size_t)s_pad * kKStride + (size_t)kHeadDim * (s_pad + kVtPad)) * sizeof(_Float16);
+  const size_t lds = ((size_t)s_pad * kKStride + (size_t)kHeadDim * (s_pad + kVtPad) + 4 * 32 * kOutStride) *
+                     sizeof(_Float16);
   if (lds > 160 * 1024) return fail(PROQA_EINVAL, "attention: seq_len=%d needs %zu B of LDS (> 160 KiB)", seq_len, lds);
   if (batch == 0) return PROQA_OK;
   if (lds > 64 * 1024) {
