@@ -1,0 +1,115 @@
+// AddressSanitizer/UBSan driver for the host-side C++ of libproqa_hip (npy_io.cpp, common.cpp):
+// round trips, partial row IO and a set of malformed headers.  Built and run by
+// tests/test_native_asan.py with g++ -fsanitize=address,undefined (CPU only; GPU ASAN is not
+// available on the pool).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/proqa_hip.h"
+
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      fprintf(stderr, "CHECK failed: %s (line %d): %s\n", #cond, __LINE__, proqa_last_error()); \
+      return 1;                                                            \
+    }                                                                      \
+  } while (0)
+
+static void write_raw(const std::string& path, const std::string& bytes) {
+  FILE* f = fopen(path.c_str(), "wb");
+  fwrite(bytes.data(), 1, bytes.size(), f);
+  fclose(f);
+}
+
+static std::string header(const char* dict, int major = 1) {
+  std::string h(dict);
+  h.push_back('\n');
+  std::string out("\x93NUMPY", 6);
+  out.push_back((char)major);
+  out.push_back(0);
+  if (major == 1) {
+    out.push_back((char)(h.size() & 0xff));
+    out.push_back((char)(h.size() >> 8));
+  } else {
+    for (int i = 0; i < 4; ++i) out.push_back((char)((h.size() >> (8 * i)) & 0xff));
+  }
+  return out + h;
+}
+
+int main(int argc, char** argv) {
+  const std::string dir = argc > 1 ? argv[1] : "/tmp";
+  const std::string p = dir + "/asan_a.npy";
+  std::vector<uint16_t> a(7 * 128);
+  for (size_t i = 0; i < a.size(); ++i) a[i] = (uint16_t)(i * 31);
+  CHECK(proqa_npy_write(p.c_str(), a.data(), 7, 128, PROQA_F16) == 0);
+  proqa_npy_info info;
+  CHECK(proqa_npy_stat(p.c_str(), &info) == 0);
+  CHECK(info.rows == 7 && info.cols == 128 && info.dtype == PROQA_F16 && info.data_offset % 64 == 0);
+  std::vector<uint16_t> b(3 * 128);
+  CHECK(proqa_npy_read_rows(p.c_str(), 2, 3, b.data(), b.size() * 2) == 0);
+  CHECK(memcmp(b.data(), a.data() + 2 * 128, b.size() * 2) == 0);
+  CHECK(proqa_npy_read_rows(p.c_str(), 5, 3, b.data(), b.size() * 2) == PROQA_EINVAL);   // past the end
+  CHECK(proqa_npy_read_rows(p.c_str(), 0, 3, b.data(), 10) == PROQA_EINVAL);             // small buffer
+  CHECK(proqa_npy_read_rows(p.c_str(), 0, 0, nullptr, 0) == 0);
+
+  const std::string c = dir + "/asan_c.npy";
+  CHECK(proqa_npy_create(c.c_str(), 5, 128, PROQA_F32) == 0);
+  std::vector<float> f(2 * 128, 1.5f);
+  CHECK(proqa_npy_write_rows(c.c_str(), 3, 2, f.data()) == 0);
+  CHECK(proqa_npy_write_rows(c.c_str(), 4, 2, f.data()) == PROQA_EINVAL);
+  std::vector<float> g(5 * 128);
+  CHECK(proqa_npy_read_rows(c.c_str(), 0, 5, g.data(), g.size() * 4) == 0);
+  CHECK(g[0] == 0.f && g[3 * 128] == 1.5f && g[5 * 128 - 1] == 1.5f);
+  CHECK(proqa_npy_write(c.c_str(), nullptr, 0, 128, PROQA_F32) == 0);                    // empty array
+  CHECK(proqa_npy_stat(c.c_str(), &info) == 0 && info.rows == 0);
+
+  // malformed inputs must fail cleanly
+  const std::string m = dir + "/asan_m.npy";
+  const char* bad[] = {
+      "{'descr': '<i8', 'fortran_order': False, 'shape': (2, 128), }",
+      "{'descr': '<f2', 'fortran_order': True, 'shape': (2, 128), }",
+      "{'descr': '<f2', 'fortran_order': False, 'shape': (2,), }",
+      "{'descr': '<f2', 'fortran_order': False, 'shape': (2, 3, 4), }",
+      "{'descr': '<f2', 'fortran_order': False, 'shape': (-2, 128), }",
+      "{'descr': '<f2', 'fortran_order': False, 'shape': (2, 128",
+      "{'fortran_order': False, 'shape': (2, 128), }",
+      "{'descr': '<f2', 'shape': (2, 128), }",
+      "{'descr': '<f2', 'fortran_order': False, }",
+      "{'descr': '<f2', 'fortran_order': False, 'shape': (99999999999999999999, 128), }",
+      "",
+  };
+  for (const char* dict : bad) {
+    write_raw(m, header(dict));
+    CHECK(proqa_npy_stat(m.c_str(), &info) != 0);
+    CHECK(strlen(proqa_last_error()) > 0);
+  }
+  write_raw(m, "\x93NUMPY");                     // truncated preamble
+  CHECK(proqa_npy_stat(m.c_str(), &info) == PROQA_EFORMAT);
+  write_raw(m, std::string("\x93NUMPY\x01\x00\xff\xff", 10) + "{'descr'");   // header length beyond the file
+  CHECK(proqa_npy_stat(m.c_str(), &info) == PROQA_EFORMAT);
+  write_raw(m, header("{'descr': '<f2', 'fortran_order': False, 'shape': (4, 128), }", 2) + std::string(16, 'x'));
+  CHECK(proqa_npy_stat(m.c_str(), &info) == PROQA_EFORMAT);                  // v2 header, data truncated
+  write_raw(m, header("{'descr': '<f2', 'fortran_order': False, 'shape': (1, 4), }", 3) + std::string(8, 'x'));
+  CHECK(proqa_npy_stat(m.c_str(), &info) == 0 && info.cols == 4);
+  CHECK(proqa_npy_stat("/nonexistent/x.npy", &info) == PROQA_EIO);
+  CHECK(proqa_npy_stat(nullptr, &info) == PROQA_EINVAL);
+
+  // rand_perm: a permutation, deterministic in the seed
+  std::vector<int32_t> perm(1000), perm2(1000);
+  CHECK(proqa_rand_perm(1000, 1234, perm.data()) == 0 && proqa_rand_perm(1000, 1234, perm2.data()) == 0);
+  CHECK(perm == perm2);
+  std::vector<int> seen(1000, 0);
+  for (int v : perm) {
+    CHECK(v >= 0 && v < 1000);
+    seen[v]++;
+  }
+  for (int s : seen) CHECK(s == 1);
+  CHECK(proqa_rand_perm(-1, 1, perm.data()) == PROQA_EINVAL);
+  CHECK(proqa_abi_version() == PROQA_ABI_VERSION);
+  printf("asan driver ok\n");
+  return 0;
+}
