@@ -239,9 +239,12 @@ class ShardedIndexFlatIP:
             D, I = self._index.search_device(xq, k, idx_offset=self.lo)
         if self.world_size == 1:
             return D, I
-        D_all = torch.empty((self.world_size,) + tuple(D.shape), dtype=D.dtype, device=D.device)
-        I_all = torch.empty((self.world_size,) + tuple(I.shape), dtype=I.dtype, device=I.device)
-        # rank-ordered slices of one buffer: exactly the [n_parts, nq, k] layout the merge consumes
-        self.dist.all_gather(list(D_all.unbind(0)), D.contiguous(), group=self.group)
-        self.dist.all_gather(list(I_all.unbind(0)), I.contiguous(), group=self.group)
+        # ONE collective: ids (int64) and scores (float32) travel as one byte buffer per rank;
+        # rank-ordered slices of the gathered buffer are exactly the [n_parts, nq, k] layout the merge consumes
+        n_i, n_d = I.numel() * 8, D.numel() * 4
+        mine = torch.cat([I.contiguous().view(torch.uint8).reshape(-1), D.contiguous().view(torch.uint8).reshape(-1)])
+        gathered = torch.empty((self.world_size, n_i + n_d), dtype=torch.uint8, device=D.device)
+        self.dist.all_gather(list(gathered.unbind(0)), mine, group=self.group)
+        I_all = gathered[:, :n_i].contiguous().view(torch.int64).reshape((self.world_size,) + tuple(I.shape))
+        D_all = gathered[:, n_i:].contiguous().view(torch.float32).reshape((self.world_size,) + tuple(D.shape))
         return self._merge(D_all, I_all)
