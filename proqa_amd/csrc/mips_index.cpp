@@ -63,6 +63,8 @@ struct proqa_index {
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipEvent_t ev_filter[2 * 96] = {};       // per-round brackets, created when profiling is on
   bool profile = false;
+  bool allow_rounding = false;             // accept fp32 inputs that are not exactly representable in fp16
+  unsigned* inexact = nullptr;             // device counter of such values (one word)
   // tuning
   int first_slab_rows = 256;
   int growth = 4;
@@ -78,6 +80,19 @@ int ensure_device(proqa_index* idx) {
   int dev = 0;
   PROQA_HIP(hipGetDevice(&dev));
   if (dev != idx->device) PROQA_HIP(hipSetDevice(idx->device));
+  return PROQA_OK;
+}
+
+// fp32 inputs are stored/searched as fp16: refuse values that would change, unless rounding was allowed
+int check_exact(proqa_index* idx, const char* what, hipStream_t st) {
+  unsigned bad = 0;
+  PROQA_HIP(hipMemcpyAsync(&bad, idx->inexact, sizeof bad, hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipStreamSynchronize(st));
+  if (bad && !idx->allow_rounding)
+    return fail(PROQA_EINVAL,
+                "%s: %u float32 values are not exactly representable in fp16; the index stores fp16 (the --fp16 "
+                ".npy format) and an fp32-exact search is not built — pass fp16-representable data or allow rounding "
+                "(proqa_index_allow_rounding)", what, bad);
   return PROQA_OK;
 }
 
@@ -376,8 +391,12 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   if (n_pages > 1) PROQA_HIP(hipMemsetAsync(idx->done, 0, (size_t)idx->ws_nq_pad, st));
   for (int p = 0; p < n_pages; ++p) {
     const int page_k = std::min(kPageK, k - p * kPageK);
+    const bool check_q = p == 0 && dtype == PROQA_F32;
+    if (check_q) PROQA_HIP(hipMemsetAsync(idx->inexact, 0, sizeof(unsigned), st));
     PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
-                                  p > 0 ? idx->done : nullptr, p == 0, st));
+                                  p > 0 ? idx->done : nullptr, p == 0, check_q ? idx->inexact : nullptr, st));
+    if (check_q)
+      if (int rc = check_exact(idx, "index_search (queries)", st)) return rc;
     const PageOut out{D_dev, (long long*)I_dev, idx_offset, k, p * kPageK};
     if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, out, st, &fallback)) return rc;
     if (p + 1 < n_pages)
@@ -410,6 +429,7 @@ int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out) {
   PROQA_HIP(hipGetDevice(&idx->device));
   for (auto& e : idx->ev) PROQA_HIP(hipEventCreate(&e));
   PROQA_HIP(hipMalloc((void**)&idx->overflow, kMaxRounds * sizeof(unsigned)));
+  PROQA_HIP(hipMalloc((void**)&idx->inexact, sizeof(unsigned)));
   PROQA_HIP(hipHostMalloc((void**)&idx->overflow_host, kMaxRounds * sizeof(unsigned), hipHostMallocDefault));
   if (capacity_rows > 0) {
     if (int rc = reserve_rows(idx, capacity_rows)) {
@@ -426,6 +446,7 @@ int proqa_index_free(proqa_index* idx) {
   free_workspace(idx);
   if (idx->xb && idx->owns_xb) (void)hipFree(idx->xb);
   if (idx->overflow) (void)hipFree(idx->overflow);
+  if (idx->inexact) (void)hipFree(idx->inexact);
   if (idx->overflow_host) (void)hipHostFree(idx->overflow_host);
   if (idx->stat_host) (void)hipHostFree(idx->stat_host);
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
@@ -463,6 +484,12 @@ int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth) {
   return PROQA_OK;
 }
 
+int proqa_index_allow_rounding(proqa_index* idx, int allow) {
+  if (!idx) return fail(PROQA_EINVAL, "index_allow_rounding: NULL handle");
+  idx->allow_rounding = allow != 0;
+  return PROQA_OK;
+}
+
 int proqa_index_set_profiling(proqa_index* idx, int enable) {
   if (!idx) return fail(PROQA_EINVAL, "index_set_profiling: NULL handle");
   if (enable && !idx->ev_filter[0]) {
@@ -489,7 +516,9 @@ int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int 
   if (dtype == PROQA_F16) {
     PROQA_HIP(hipMemcpyAsync(dst, xb_dev, (size_t)n * kDim * 2, hipMemcpyDeviceToDevice, st));
   } else {
-    PROQA_HIP(launch_convert_f32_to_f16((const float*)xb_dev, dst, n * kDim, st));
+    PROQA_HIP(hipMemsetAsync(idx->inexact, 0, sizeof(unsigned), st));
+    PROQA_HIP(launch_convert_f32_to_f16((const float*)xb_dev, dst, n * kDim, idx->inexact, st));
+    if (int rc = check_exact(idx, "index_add_device", st)) return rc;
   }
   PROQA_HIP(hipStreamSynchronize(st));
   idx->n += n;
@@ -525,8 +554,9 @@ int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype) {
     } else {
       if (int rc = ensure_stage(idx, (size_t)piece * kDim * 4)) return rc;
       PROQA_HIP(hipMemcpy(idx->stage_dev, src, (size_t)m * kDim * 4, hipMemcpyHostToDevice));
-      PROQA_HIP(launch_convert_f32_to_f16((const float*)idx->stage_dev, dst, m * kDim, nullptr));
-      PROQA_HIP(hipDeviceSynchronize());
+      PROQA_HIP(hipMemsetAsync(idx->inexact, 0, sizeof(unsigned), nullptr));
+      PROQA_HIP(launch_convert_f32_to_f16((const float*)idx->stage_dev, dst, m * kDim, idx->inexact, nullptr));
+      if (int rc = check_exact(idx, "index_add", nullptr)) return rc;
     }
   }
   idx->n += n;

@@ -77,13 +77,13 @@ hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigne
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st);
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                               bool reset_stat, hipStream_t st);
+                               bool reset_stat, unsigned* inexact, hipStream_t st);
 // writes page results: D/I[q * out_stride + out_offset + j], j < page_k
 hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                            long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
                            hipStream_t st);
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
                               int k, float* D, long long* I, hipStream_t st);
-hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, hipStream_t st);
+hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, unsigned* inexact, hipStream_t st);
 
 }  // namespace proqa

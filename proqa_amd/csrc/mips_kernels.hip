@@ -447,14 +447,16 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
 // pad + convert queries to the fp16 [Qpad,128] operand layout, reset per-query state
 __global__ void prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, _Float16* xq_pad,
                              float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                             int reset_stat, int debug_nohit) {
+                             int reset_stat, unsigned* inexact, int debug_nohit) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = nq_pad * kDim;
   if (i < n) {
     const long long q = i / kDim;
     float v = 0.f;
     if (q < nq) v = dtype == PROQA_F16 ? (float)((const _Float16*)xq)[i] : ((const float*)xq)[i];
-    xq_pad[i] = (_Float16)v;
+    const _Float16 hq = (_Float16)v;
+    xq_pad[i] = hq;
+    if (inexact && (float)hq != v && v == v) atomicAdd(inexact, 1u);
   }
   if (i < nq_pad) {
     // padded queries (and queries a paged search has already exhausted) never log
@@ -497,16 +499,27 @@ __global__ void advance_page(const unsigned long long* run_keys, const unsigned*
   }
 }
 
-__global__ void convert_rows_f32_to_f16(const float* src, _Float16* dst, long long n) {
+// fp32 -> fp16 with a count of the values that do not survive the round trip: the index stores
+// fp16, so an fp32 input is accepted only if it is exactly representable (the reference upcasts an
+// fp16 .npy to float32 before faiss; such arrays pass) unless the caller allows rounding
+__global__ void convert_rows_f32_to_f16(const float* src, _Float16* dst, long long n, unsigned* inexact) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  unsigned bad = 0;
   if (i + 3 < n) {
     const f32x4 v = *(const f32x4*)(src + i);
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     f16x4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     *(f16x4*)(dst + i) = o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bad += ((float)o[e] != v[e] && v[e] == v[e]) ? 1u : 0u;
   } else {
-    for (long long j = i; j < n; ++j) dst[j] = (_Float16)src[j];
+    for (long long j = i; j < n; ++j) {
+      const _Float16 h = (_Float16)src[j];
+      dst[j] = h;
+      bad += ((float)h != src[j] && src[j] == src[j]) ? 1u : 0u;
+    }
   }
+  if (inexact && __any(bad != 0) && bad) atomicAdd(inexact, bad);
 }
 
 // Merge per-shard result lists (proqa_topk_merge_device): one workgroup per query sorts the
@@ -605,10 +618,10 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
 
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                               bool reset_stat, hipStream_t st) {
+                               bool reset_stat, unsigned* inexact, hipStream_t st) {
   const long long n = nq_pad * kDim;
   hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
-                     (_Float16*)xq_pad, tau, run_n, stat, done, reset_stat ? 1 : 0,
+                     (_Float16*)xq_pad, tau, run_n, stat, done, reset_stat ? 1 : 0, inexact,
                      getenv("PROQA_DEBUG_NOHIT") ? 1 : 0);
   return hipGetLastError();
 }
@@ -633,11 +646,11 @@ hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, in
   return hipGetLastError();
 }
 
-hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, hipStream_t st) {
+hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, unsigned* inexact, hipStream_t st) {
   if (n == 0) return hipSuccess;
   const long long nthreads = (n + 3) / 4;
   hipLaunchKernelGGL(convert_rows_f32_to_f16, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
-                     src, (_Float16*)dst, n);
+                     src, (_Float16*)dst, n, inexact);
   return hipGetLastError();
 }
 

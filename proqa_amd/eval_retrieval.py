@@ -79,8 +79,11 @@ def convert_idx2id(idxs, mapping_path=DEFAULT_IDX_ID):
     return [[idx_id[str(int(i))] for i in row] for row in idxs]
 
 
-def search(indexpath, query_embed, topk, chunk_rows=1 << 21):
-    """np.load + IndexFlatIP.add + search of the reference, on the GPU (index streamed from an mmap)."""
+def search(indexpath, query_embed, topk, chunk_rows=1 << 21, allow_rounding=False):
+    """np.load + IndexFlatIP.add + search of the reference, on the GPU (index streamed from an mmap).
+
+    float32 .npy files (written without --fp16) are refused unless every value is fp16-representable
+    or allow_rounding is set: the index lives in HBM as fp16."""
     from . import npy
     from .index import IndexFlatIP
     xq = npy.load(query_embed)
@@ -89,6 +92,8 @@ def search(indexpath, query_embed, topk, chunk_rows=1 << 21):
         raise ValueError("embeddings must be 128-d")
     xb = npy.memmap(indexpath)
     index = IndexFlatIP(128, capacity=info["rows"])
+    if allow_rounding:
+        index.allow_rounding(True)
     for r0 in range(0, info["rows"], chunk_rows):
         index.add(np.ascontiguousarray(xb[r0:r0 + chunk_rows]))
     return index.search(xq, topk)
@@ -104,6 +109,8 @@ def build_parser():
     parser.add_argument("--num-workers", type=int, default=10)
     parser.add_argument("--idx-id-map", type=str, default=DEFAULT_IDX_ID,
                         help="idx_id.json (the reference reads ../pretrained_models/idx_id.json)")
+    parser.add_argument("--allow-fp16-rounding", action="store_true",
+                        help="accept float32 embeddings that are not exactly representable in fp16 (rounded)")
     return parser
 
 
@@ -117,7 +124,7 @@ def main(argv=None):
     # fork the scorer pool before any HIP call
     processes = ProcessPool(processes=args.num_workers, initializer=init, initargs=[args.db])
     try:
-        D, I = search(args.indexpath, args.query_embed, args.topk)
+        D, I = search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding)
         retrieval_results = convert_idx2id(I, args.idx_id_map)
         assert len(retrieval_results) == len(questions) == len(answers)
         results = processes.map(partial(get_score, topk=args.topk), zip(questions, answers, retrieval_results))

@@ -142,6 +142,11 @@ class IndexFlatIP:
     def set_profiling(self, enable=True):
         _lib.check(self._lib.proqa_index_set_profiling(self._h, 1 if enable else 0))
 
+    def allow_rounding(self, allow=True):
+        """Accept float32 inputs that are not exactly representable in fp16 (they are rounded).  Off by
+        default: the reference searches float32, so silently rounding would change its results."""
+        _lib.check(self._lib.proqa_index_allow_rounding(self._h, 1 if allow else 0))
+
     def configure(self, first_slab_rows=0, growth=0):
         """Round schedule: rows of the first (dense) slab and the growth factor of later slabs."""
         _lib.check(self._lib.proqa_index_configure(self._h, first_slab_rows, growth))

@@ -116,6 +116,34 @@ def test_f32_inputs_and_incremental_add(gpu_device):
     assert index.ntotal == 0
 
 
+def test_inexact_f32_is_refused_unless_allowed(gpu_device):
+    """The index stores fp16: float32 values that would change are an error, not a silent rounding."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(5)
+    xb = rng.standard_normal((700, 128)).astype(np.float32)       # not fp16-representable
+    xq = rng.standard_normal((9, 128)).astype(np.float32)
+    index = IndexFlatIP(128)
+    with pytest.raises(RuntimeError, match="not exactly representable"):
+        index.add(xb)
+    assert index.ntotal == 0
+    with pytest.raises(RuntimeError, match="not exactly representable"):
+        index.add(torch.from_numpy(xb).to(gpu_device))
+    assert index.ntotal == 0
+    index.add(xb.astype(np.float16))
+    with pytest.raises(RuntimeError, match="not exactly representable"):
+        index.search(xq, 5)
+    nanq = xq.astype(np.float16).astype(np.float32)
+    index.search(nanq, 5)                                          # exact float32 queries are fine
+    index.reset()
+    index.allow_rounding(True)
+    index.add(xb)
+    D, I = index.search(xq, 5)
+    Do, Io = search_oracle.topk_ip(xq.astype(np.float16), xb.astype(np.float16), 5)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_allclose(D, Do, rtol=2e-6, atol=2e-5)      # fp32 summation order only
+
+
 def test_device_search_offsets_and_merge(gpu_device):
     """Two shards searched separately with global ids, merged on the GPU == unsharded search."""
     import torch
