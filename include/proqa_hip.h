@@ -131,6 +131,12 @@ int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_
 int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
                         int n_heads, void* ctx_out, void* stream);
 
+/* the same attention for query row 0 ([CLS]) of every sequence only: ctx_cls_out [B, hidden].
+ * Only h[:, 0] of the last layer reaches the pooler (retrieval/retriever.py:41-42), so the last
+ * layer's attention output / FFN are computed for that row alone. */
+int proqa_attention_cls_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
+                            int n_heads, void* ctx_cls_out, void* stream);
+
 /* x = gelu_erf(x + bias) in place, x [rows, cols] (BertIntermediate, hidden_act='gelu') */
 int proqa_bias_gelu_f16(void* x, const void* bias, int64_t rows, int cols, void* stream);
 

@@ -177,10 +177,84 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   }
 }
 
+// Attention of the [CLS] query only (row 0 of every sequence): the last encoder layer feeds nothing
+// but h[:, 0] to the pooler (retriever.py:41-42 takes BertModel's pooled output), so its attention
+// output is needed for one query per sequence.  One wave per (sequence, head): lanes own keys for
+// q.K^T (fp32), the softmax is a wave reduction, then lanes own the 64 output dims for P.V with the
+// probabilities broadcast from LDS.  Streams K and V once: B*S*2*128 B per head, HBM-bound.
+__global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restrict__ qkv,
+                                                         const int* __restrict__ seq_lens, int seq_len,
+                                                         int n_heads, int n_pairs, _Float16* __restrict__ ctx_cls) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+  float* p_lds = (float*)smem + (threadIdx.x >> 6) * seq_len;   // [4 waves][seq_len] probabilities
+  const int lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pair >= n_pairs) return;
+  const int b = pair / n_heads;
+  const int head = pair - b * n_heads;
+  const int hidden = n_heads * kHeadDim;
+  const long long row_stride = 3ll * hidden;
+  const _Float16* base = qkv + (long long)b * seq_len * row_stride + head * kHeadDim;
+  int len = seq_lens ? seq_lens[b] : seq_len;
+  len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
+
+  float qv[kHeadDim];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const f16x8 q8 = *(const f16x8*)(base + c * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[c * 8 + e] = (float)q8[e];
+  }
+  float m = -__builtin_inff();
+  for (int key = lane; key < len; key += 64) {
+    const _Float16* kr = base + key * row_stride + hidden;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const f16x8 k8 = *(const f16x8*)(kr + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += qv[c * 8 + e] * (float)k8[e];
+    }
+    acc *= 0.125f;
+    p_lds[key] = acc;
+    m = __builtin_fmaxf(m, acc);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
+  float l = 0.f;
+  for (int key = lane; key < len; key += 64) {
+    const float p = __expf(p_lds[key] - m);
+    p_lds[key] = p;
+    l += p;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+  // same wave wrote p_lds: LDS ops of a wave complete in order
+  float o = 0.f;
+  const _Float16* vcol = base + 2 * hidden + lane;
+  for (int key = 0; key < len; ++key) o += p_lds[key] * (float)vcol[key * row_stride];
+  ctx_cls[(long long)b * hidden + head * kHeadDim + lane] = (_Float16)(o / l);
+}
+
 }  // namespace
 }  // namespace proqa
 
 using namespace proqa;
+
+extern "C" int proqa_attention_cls_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
+                                       int n_heads, void* ctx_cls_out, void* stream) {
+  if (!qkv || !ctx_cls_out) return fail(PROQA_EINVAL, "attention_cls: NULL argument");
+  if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention_cls: bad sizes");
+  const size_t lds = (size_t)4 * seq_len * sizeof(float);
+  if (lds > 64 * 1024) return fail(PROQA_EINVAL, "attention_cls: seq_len=%d too long", seq_len);
+  if (batch == 0) return PROQA_OK;
+  const int n_pairs = batch * n_heads;
+  hipLaunchKernelGGL(attention_cls_fwd, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), lds, as_stream(stream),
+                     (const _Float16*)qkv, (const int*)seq_lens_dev, seq_len, n_heads, n_pairs,
+                     (_Float16*)ctx_cls_out);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
 
 extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
                                    int n_heads, void* ctx_out, void* stream) {

@@ -103,6 +103,9 @@ class BertForRetriever:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.towers = {}
         self.out_dtype = torch.float16
+        # last layer: attention output, dense blocks and LayerNorms for the [CLS] rows only (same result:
+        # nothing else of that layer reaches the pooler); False runs every token through it
+        self.cls_only_last_layer = True
         self._ws = {}
 
     # -- reference-compatible surface -----------------------------------------------------
@@ -181,7 +184,11 @@ class BertForRetriever:
                 h=torch.empty((n, H), dtype=f16, device=dev), h1=torch.empty((n, H), dtype=f16, device=dev),
                 qkv=torch.empty((n, 3 * H), dtype=f16, device=dev), ctx=torch.empty((n, H), dtype=f16, device=dev),
                 tmp=torch.empty((n, H), dtype=f16, device=dev), ff=torch.empty((n, I), dtype=f16, device=dev),
-                pooled=torch.empty((B, H), dtype=f16, device=dev))
+                pooled=torch.empty((B, H), dtype=f16, device=dev),
+                # [CLS]-row buffers of the last layer
+                c_ctx=torch.empty((B, H), dtype=f16, device=dev), c_res=torch.empty((B, H), dtype=f16, device=dev),
+                c_tmp=torch.empty((B, H), dtype=f16, device=dev), c_h1=torch.empty((B, H), dtype=f16, device=dev),
+                c_ff=torch.empty((B, I), dtype=f16, device=dev), c_h=torch.empty((B, H), dtype=f16, device=dev))
             if len(self._ws) > 8:
                 self._ws.clear()
             self._ws[key] = ws
@@ -218,7 +225,8 @@ class BertForRetriever:
                                               tw.pos.data_ptr(), tw.type0.data_ptr(), tw.emb_g.data_ptr(),
                                               tw.emb_b.data_ptr(), eps, ws.h.data_ptr(), st))
             h, h1 = ws.h, ws.h1
-            for L in tw.layers:
+            full_layers = tw.layers[:-1] if self.cls_only_last_layer else tw.layers
+            for L in full_layers:
                 torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=ws.qkv)                       # fused Q|K|V projection
                 chk(lib.proqa_attention_f16(ws.qkv.data_ptr(), lens.data_ptr(), B, S, NH, ws.ctx.data_ptr(), st))
                 torch.mm(ws.ctx, L.ao_w.t(), out=ws.tmp)
@@ -231,6 +239,24 @@ class BertForRetriever:
                 chk(lib.proqa_bias_residual_layernorm_f16(ws.tmp.data_ptr(), L.ff2_b.data_ptr(), h1.data_ptr(),
                                                           L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, n, H,
                                                           h.data_ptr(), st))
+            if self.cls_only_last_layer:
+                # the pooler reads h[:, 0] only (retriever.py:41-42): the last layer needs K and V of every
+                # token but the attention output, both dense blocks and LayerNorms for the [CLS] rows alone
+                L = tw.layers[-1]
+                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=ws.qkv)
+                chk(lib.proqa_attention_cls_f16(ws.qkv.data_ptr(), lens.data_ptr(), B, S, NH, ws.c_ctx.data_ptr(), st))
+                ws.c_res.copy_(h.view(B, S, H)[:, 0])
+                torch.mm(ws.c_ctx, L.ao_w.t(), out=ws.c_tmp)
+                chk(lib.proqa_bias_residual_layernorm_f16(ws.c_tmp.data_ptr(), L.ao_b.data_ptr(), ws.c_res.data_ptr(),
+                                                          L.ln1_g.data_ptr(), L.ln1_b.data_ptr(), eps, B, H,
+                                                          ws.c_h1.data_ptr(), st))
+                torch.mm(ws.c_h1, L.ff1_w.t(), out=ws.c_ff)
+                chk(lib.proqa_bias_gelu_f16(ws.c_ff.data_ptr(), L.ff1_b.data_ptr(), B, I, st))
+                torch.mm(ws.c_ff, L.ff2_w.t(), out=ws.c_tmp)
+                chk(lib.proqa_bias_residual_layernorm_f16(ws.c_tmp.data_ptr(), L.ff2_b.data_ptr(), ws.c_h1.data_ptr(),
+                                                          L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, B, H,
+                                                          ws.c_h.data_ptr(), st))
+                h, S = ws.c_h, 1
             chk(lib.proqa_pool_project_f16(h.data_ptr(), B, S, H, tw.pool_w.data_ptr(), tw.pool_b.data_ptr(),
                                            tw.proj_w.data_ptr(), tw.proj_b.data_ptr(), ws.pooled.data_ptr(),
                                            out.data_ptr(),

@@ -159,6 +159,24 @@ def load_golden():
     return z, sd, cfg
 
 
+@pytest.mark.parametrize("B,S,NH", [(3, 48, 2), (5, 128, 12), (2, 512, 4), (3, 77, 3), (1, 1, 12)])
+def test_attention_cls_rows(lib, gpu_device, B, S, NH):
+    """The [CLS]-only attention of the last layer equals row 0 of the full attention."""
+    from proqa_amd import _lib
+    rng = np.random.default_rng(S * 5 + NH)
+    qkv = rng.standard_normal((B * S, 3 * NH * 64)).astype(np.float16)
+    lens = rng.integers(1, S + 1, B).astype(np.int32)
+    lens[0] = S
+    if B > 1:
+        lens[1] = 1
+    ref = attention_ref(qkv, lens, B, S, NH)[:, 0]
+    tq = dev16(qkv, gpu_device)
+    tl = torch.from_numpy(lens).to(gpu_device)
+    out = torch.empty((B, NH * 64), dtype=torch.float16, device=gpu_device)
+    _lib.check(lib.proqa_attention_cls_f16(tq.data_ptr(), tl.data_ptr(), B, S, NH, out.data_ptr(), stream()))
+    close(out, ref, rtol=2e-3, atol=2e-3)
+
+
 def cosine(a, b):
     return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
 
@@ -204,12 +222,15 @@ def test_bert_base_shape_against_oracle(gpu_device):
         ids[b, :n] = rng.integers(1000, 30522, n)
         ids[b, 0], ids[b, n - 1] = 101, 102
         mask[b, :n] = True
-    out = model.get_embed({"input_ids": torch.from_numpy(ids).to(gpu_device),
-                           "input_mask": torch.from_numpy(mask).to(gpu_device)}, False)["embed"]
+    batch = {"input_ids": torch.from_numpy(ids).to(gpu_device), "input_mask": torch.from_numpy(mask).to(gpu_device)}
     ref = bert_oracle.get_embed({k: v.numpy() for k, v in sd.items()}, ids, mask, False, 12, 12)
-    got = out.float().cpu().numpy()
-    assert np.abs(got - ref).max() < 1e-2
-    assert cosine(got, ref).min() > 0.9995
+    got = {}
+    for cls_only in (True, False):          # last layer on the [CLS] rows only / on every token
+        model.cls_only_last_layer = cls_only
+        got[cls_only] = model.get_embed(batch, False)["embed"].float().cpu().numpy()
+        assert np.abs(got[cls_only] - ref).max() < 1e-2
+        assert cosine(got[cls_only], ref).min() > 0.9995
+    assert np.abs(got[True] - got[False]).max() < 3e-3
 
 
 def test_rejects_bad_inputs(gpu_device):
