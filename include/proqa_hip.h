@@ -105,7 +105,9 @@ int proqa_index_set_profiling(proqa_index* idx, int enable);
 int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
- * (the layout an RCCL all-gather of per-rank [nq, k] produces).  Same ordering rule. */
+ * (the layout an RCCL all-gather of per-rank [nq, k] produces).  Same ordering rule.  Up to
+ * 16384 gathered keys per query are sorted in LDS; larger merges (k = 10000 x 8 shards) run as a
+ * segmented radix sort in HBM (temporary buffers are allocated for the call). */
 int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts,
                             int64_t nq, int k, float* D_dev, int64_t* I_dev, void* stream);
 

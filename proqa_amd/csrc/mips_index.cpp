@@ -594,8 +594,8 @@ int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev
                             int k, float* D_dev, int64_t* I_dev, void* stream) {
   if (!D_parts_dev || !I_parts_dev || !D_dev || !I_dev || n_parts <= 0 || nq < 0 || k <= 0)
     return fail(PROQA_EINVAL, "topk_merge_device: bad argument");
-  if ((long long)n_parts * k > kMaxSortKeys)
-    return fail(PROQA_EINVAL, "topk_merge_device: n_parts*k=%lld exceeds %d", (long long)n_parts * k, kMaxSortKeys);
+  if ((long long)n_parts * k >= (1ll << 27))
+    return fail(PROQA_EINVAL, "topk_merge_device: n_parts*k=%lld is too large", (long long)n_parts * k);
   PROQA_HIP(launch_merge_lists(D_parts_dev, (const long long*)I_parts_dev, n_parts, nq, k, D_dev,
                                (long long*)I_dev, as_stream(stream)));
   return PROQA_OK;

@@ -12,6 +12,9 @@ constexpr int kFilterWaves = 8;
 constexpr int kFilterThreads = kFilterWaves * 64;
 constexpr int kStageRows = 128;  // corpus rows per LDS stage (32 KiB of fp16 rows)
 constexpr int kMergeThreads = 256;
+// merge_lists sorts up to this many gathered keys per query in LDS (128 KiB); above it the merge
+// runs as a segmented radix sort in HBM
+constexpr int kMaxMergeListKeys = 16384;
 constexpr int kMaxSortKeys = 2048;  // running list + candidates of one query per merge (LDS)
 constexpr int kPageK = kMaxSortKeys / 2;  // results per page; k > kPageK is served page by page
 constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling

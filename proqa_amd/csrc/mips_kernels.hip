@@ -21,6 +21,8 @@
 //   The host (mips_index.cpp) runs rounds over geometrically growing corpus slabs so the
 //   threshold tightens quickly and later slabs produce only a few candidates per query.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -575,6 +577,47 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __rest
   }
 }
 
+// Large merges (n_parts*k keys do not fit one workgroup's LDS, e.g. k = 10000 x 8 shards for
+// retrieval/trec_process.py:76): the same packed keys, laid out [query][part*k + j] in HBM, are sorted
+// per query by a segmented radix sort; the first k of every segment are the answer.
+__global__ void pack_part_keys(const float* __restrict__ D_parts, const long long* __restrict__ I_parts,
+                               int n_parts, long long nq, int k, long long q0, long long nq_chunk,
+                               unsigned long long* __restrict__ keys) {
+  const long long per_q = (long long)n_parts * k;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq_chunk * per_q) return;
+  const long long qc = t / per_q;
+  const unsigned i = (unsigned)(t - qc * per_q);
+  const unsigned p = i / k, j = i - p * k;
+  const size_t src = ((size_t)p * nq + (q0 + qc)) * k + j;
+  keys[t] = I_parts[src] >= 0 ? pack_key(D_parts[src], i) : 0ull;
+}
+
+__global__ void segment_offsets(long long n_segments, int per_segment, int* __restrict__ offsets) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t <= n_segments) offsets[t] = (int)(t * per_segment);
+}
+
+__global__ void emit_sorted_prefix(const unsigned long long* __restrict__ keys, const long long* __restrict__ I_parts,
+                                   int n_parts, long long nq, int k, long long q0, long long nq_chunk,
+                                   float* __restrict__ D, long long* __restrict__ I) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq_chunk * k) return;
+  const long long qc = t / k;
+  const int j = (int)(t - qc * k);
+  const unsigned long long key = keys[qc * (long long)n_parts * k + j];
+  const long long q = q0 + qc;
+  if (key != 0ull) {
+    const unsigned pos = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+    const unsigned p = pos / k, jj = pos - p * k;
+    D[q * k + j] = float_from_ord((unsigned)(key >> 32));
+    I[q * k + j] = I_parts[((size_t)p * nq + q) * k + jj];
+  } else {
+    D[q * k + j] = -3.4028234663852886e38f;
+    I[q * k + j] = -1;
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
@@ -639,11 +682,57 @@ hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* r
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
                               int k, float* D, long long* I, hipStream_t st) {
   if (nq == 0) return hipSuccess;
-  unsigned P = 2;
-  while (P < (unsigned)n_parts * (unsigned)k) P <<= 1;
-  hipLaunchKernelGGL(merge_lists, dim3((unsigned)nq), dim3(kMergeThreads), (size_t)P * 8, st, D_parts,
-                     I_parts, n_parts, nq, k, D, I);
-  return hipGetLastError();
+  const long long per_q = (long long)n_parts * k;
+  if (per_q <= kMaxMergeListKeys) {
+    unsigned P = 2;
+    while (P < (unsigned)per_q) P <<= 1;
+    if ((size_t)P * 8 > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)merge_lists, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)(P * 8));
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(merge_lists, dim3((unsigned)nq), dim3(kMergeThreads), (size_t)P * 8, st, D_parts,
+                       I_parts, n_parts, nq, k, D, I);
+    return hipGetLastError();
+  }
+  // segmented radix sort in HBM, in query chunks of <= 2^27 keys (1 GiB per key buffer)
+  const long long chunk_q = std::max<long long>(1, std::min<long long>(nq, (1ll << 27) / per_q));
+  unsigned long long *keys_in = nullptr, *keys_out = nullptr;
+  int* offsets = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipSuccess;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(st);
+    if (keys_in) (void)hipFree(keys_in);
+    if (keys_out) (void)hipFree(keys_out);
+    if (offsets) (void)hipFree(offsets);
+    if (tmp) (void)hipFree(tmp);
+  };
+#define MERGE_TRY(expr) if ((e = (expr)) != hipSuccess) { cleanup(); return e; }
+  MERGE_TRY(hipMalloc((void**)&keys_in, (size_t)chunk_q * per_q * 8));
+  MERGE_TRY(hipMalloc((void**)&keys_out, (size_t)chunk_q * per_q * 8));
+  MERGE_TRY(hipMalloc((void**)&offsets, (size_t)(chunk_q + 1) * sizeof(int)));
+  hipLaunchKernelGGL(segment_offsets, dim3((unsigned)((chunk_q + 256) / 256)), dim3(256), 0, st, chunk_q, (int)per_q,
+                     offsets);
+  MERGE_TRY(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(nullptr, tmp_bytes, keys_in, keys_out,
+                                                                  (int)(chunk_q * per_q), (int)chunk_q, offsets,
+                                                                  offsets + 1, 0, 64, st));
+  MERGE_TRY(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  for (long long q0 = 0; q0 < nq; q0 += chunk_q) {
+    const long long m = std::min(chunk_q, nq - q0);
+    const long long items = m * per_q;
+    hipLaunchKernelGGL(pack_part_keys, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, D_parts, I_parts,
+                       n_parts, nq, k, q0, m, keys_in);
+    MERGE_TRY(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(tmp, tmp_bytes, keys_in, keys_out, (int)items,
+                                                                    (int)m, offsets, offsets + 1, 0, 64, st));
+    hipLaunchKernelGGL(emit_sorted_prefix, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, st, keys_out, I_parts,
+                       n_parts, nq, k, q0, m, D, I);
+    MERGE_TRY(hipGetLastError());
+  }
+#undef MERGE_TRY
+  cleanup();
+  return hipSuccess;
 }
 
 hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, unsigned* inexact, hipStream_t st) {

@@ -163,6 +163,39 @@ def test_device_search_offsets_and_merge(gpu_device):
     np.testing.assert_array_equal(D.cpu().numpy(), Do)
 
 
+@pytest.mark.parametrize("n_parts,k,nq", [(8, 1000, 37), (3, 5000, 21), (8, 10000, 9), (5, 7, 300)])
+def test_merge_of_large_lists(gpu_device, n_parts, k, nq):
+    """Sharded merge beyond one LDS pass (retrieval/trec_process.py:76 asks for k = 10000): tie-heavy
+    integer scores, short shards padded with -1, against a NumPy merge of the same lists."""
+    import torch
+    from proqa_amd.index import merge_topk_device
+    rng = np.random.default_rng(n_parts * 1000 + k)
+    Dp = np.empty((n_parts, nq, k), np.float32)
+    Ip = np.empty((n_parts, nq, k), np.int64)
+    base = 0
+    for p in range(n_parts):
+        rows = k if p != 1 else k // 2                       # shard 1 holds fewer than k rows
+        sc = np.sort(rng.integers(-50, 50, (nq, rows)).astype(np.float32), axis=1)[:, ::-1]
+        ids = base + np.sort(rng.permuted(np.tile(np.arange(rows * 3), (nq, 1)), axis=1)[:, :rows], axis=1)
+        # within equal scores a shard reports ascending ids (IndexFlatIP rule)
+        order = np.lexsort((ids, -sc), axis=1)
+        Dp[p, :, :rows] = np.take_along_axis(sc, order, 1)
+        Ip[p, :, :rows] = np.take_along_axis(ids, order, 1)
+        Dp[p, :, rows:] = np.finfo(np.float32).min
+        Ip[p, :, rows:] = -1
+        base += rows * 3
+    D, I = merge_topk_device(torch.from_numpy(Dp).to(gpu_device), torch.from_numpy(Ip).to(gpu_device))
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    allD = Dp.transpose(1, 0, 2).reshape(nq, -1)
+    allI = Ip.transpose(1, 0, 2).reshape(nq, -1)
+    for q in range(nq):
+        valid = allI[q] >= 0
+        order = np.lexsort((allI[q][valid], -allD[q][valid]))[:k]
+        np.testing.assert_array_equal(I[q, :len(order)], allI[q][valid][order])
+        np.testing.assert_array_equal(D[q, :len(order)], allD[q][valid][order])
+        assert (I[q, len(order):] == -1).all()
+
+
 def test_full_size_properties(gpu_device):
     """18M x 128 fp16 (BASELINE.json configs[2] shape) through size-independent properties:
     planted rows must be found at rank 0, scores sorted, ids unique and in range, and a sharded
