@@ -117,17 +117,18 @@ def encode_leg(args, device, world, rank):
     mask = torch.ones((B, S), dtype=torch.bool, device=device)
     batch = {"input_ids": ids, "input_mask": mask}
     outs = []
-    # same pipelining as proqa_amd.get_embed.predict: consecutive batches alternate between two
-    # streams so that one batch's HBM-bound kernels overlap the other's GEMMs
-    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    # same stream discipline as proqa_amd.get_embed.predict: ONE compute stream (concurrent hipBLASLt
+    # stream-K GEMMs on two streams deadlock on ragged batch sizes; see N_STREAMS there)
+    n_streams = int(os.environ.get("PROQA_ENCODE_STREAMS", "1"))
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
     counter = [0]
 
     def step():
-        s = streams[counter[0] % 2]
+        s = streams[counter[0] % n_streams]
         counter[0] += 1
         with torch.cuda.stream(s):
             outs.append(model.get_embed(batch, False, check_mask=False)["embed"])
-        if len(outs) > 4:
+        if len(outs) > 2 * n_streams:
             outs.pop(0)
 
     dt = timed(step, args.encode_steps, 2, world, device)
@@ -149,6 +150,30 @@ def encode_leg(args, device, world, rank):
                      "note": "flops executed per step / step time (the last layer is evaluated on the [CLS] rows "
                              "only); the dense-layer GEMMs are hipBLASLt"},
     }
+    # variable-length variant: lengths ~ U[32, S], right-padded as em_collate does;
+    # the lengths are known on the host (predict() takes them from the collated batch), padding is skipped
+    lens_host = torch.randint(32, S + 1, (B,), generator=torch.Generator().manual_seed(rank)).tolist()
+    lens_dev = torch.tensor(lens_host, device=device)
+    vmask = torch.arange(S, device=device)[None, :] < lens_dev[:, None]
+    vids = torch.where(vmask, ids, torch.zeros_like(ids))
+    vids[torch.arange(B, device=device), lens_dev - 1] = 102
+    vbatch = {"input_ids": vids, "input_mask": vmask}
+
+    def vstep():
+        s = streams[counter[0] % n_streams]
+        counter[0] += 1
+        with torch.cuda.stream(s):
+            outs.append(model.get_embed(vbatch, False, check_mask=False, seq_lens_host=lens_host)["embed"])
+        if len(outs) > 2 * n_streams:
+            outs.pop(0)
+
+    vdt = timed(vstep, args.encode_steps, 2, world, device)
+    res["varlen"] = {"value": world * B * args.encode_steps / vdt, "unit": "passages/s",
+                     "ms_per_step": vdt / args.encode_steps * 1e3, "mean_len": float(np.mean(lens_host)),
+                     "tokens_per_s": world * float(np.sum(lens_host)) * args.encode_steps / vdt,
+                     "workload": f"same model, batch {B}, lengths ~U[32,{S}] right-padded to {S}; valid tokens packed"}
+    step()   # leave a full-length batch in outs[-1] for the parity check below
+
     if rank == 0 and not args.skip_cpu:
         from oracle import bert_oracle
         nb = 4

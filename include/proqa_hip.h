@@ -125,6 +125,18 @@ int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_
                               const void* type_emb, const void* ln_gamma, const void* ln_beta,
                               float eps, void* out, void* stream);
 
+/* Packed ("varlen") token layout: sequences are stored back to back without padding rows,
+ * cu_seqlens[b] = first row of sequence b, cu_seqlens[batch] = total tokens (int32, device).
+ * Every per-token operator is unchanged on the packed [T, hidden] matrix; only the embedding
+ * gather and the attention need the offsets.  Results for the valid tokens equal the padded
+ * evaluation (padding never reaches a valid token: retrieval/datasets.py:29-45 pads on the right,
+ * the attention masks those keys).
+ * ids stay padded [batch, seq_len] (as em_collate produces them); out_packed is [T, hidden]. */
+int proqa_embed_layernorm_varlen_f16(const int64_t* ids_dev, const int32_t* cu_seqlens_dev, int batch,
+                                     int seq_len, int hidden, const void* word_emb, int64_t vocab,
+                                     const void* pos_emb, const void* type_emb, const void* ln_gamma,
+                                     const void* ln_beta, float eps, void* out_packed, void* stream);
+
 /* fused multi-head self-attention for one layer:
  *   ctx = softmax(Q K^T / sqrt(64) + key_mask) V,   head_dim 64
  * qkv is the fused projection output [B*S, 3*hidden] (Q | K | V, each head-major);
@@ -138,6 +150,13 @@ int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch,
  * layer's attention output / FFN are computed for that row alone. */
 int proqa_attention_cls_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
                             int n_heads, void* ctx_cls_out, void* stream);
+
+/* the two attention entry points on the packed layout: qkv_packed [T, 3*hidden], ctx_packed_out
+ * [T, hidden] (ctx_cls_out stays [batch, hidden]); max_seq_len = longest sequence of the batch */
+int proqa_attention_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens_dev, int batch,
+                               int max_seq_len, int n_heads, void* ctx_packed_out, void* stream);
+int proqa_attention_cls_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens_dev, int batch,
+                                   int max_seq_len, int n_heads, void* ctx_cls_out, void* stream);
 
 /* x = gelu_erf(x + bias) in place, x [rows, cols] (BertIntermediate, hidden_act='gelu') */
 int proqa_bias_gelu_f16(void* x, const void* bias, int64_t rows, int cols, void* stream);

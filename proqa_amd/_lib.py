@@ -65,8 +65,13 @@ SIGNATURES = {
     "proqa_embed_layernorm_f16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                           c_void_p, c_void_p]),
+    "proqa_embed_layernorm_varlen_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                 c_void_p, c_void_p]),
     "proqa_attention_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "proqa_attention_cls_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "proqa_attention_varlen_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "proqa_attention_cls_varlen_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "proqa_bias_gelu_f16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "proqa_bias_residual_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_float, c_int64, c_int, c_void_p, c_void_p]),

@@ -37,8 +37,11 @@ constexpr int kVtPad = 4;
 // transposed through LDS so that the context rows leave as full 128-byte lines
 constexpr int kOutStride = kHeadDim + 8;
 
+// Token layout: padded ([B, seq_len] rows, cu_seqlens == nullptr, seq_lens = valid keys per sequence) or
+// packed (cu_seqlens[b] = first token row of sequence b, no padding rows exist; seq_len = longest sequence).
 __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict__ qkv,
-                                                     const int* __restrict__ seq_lens, int seq_len,
+                                                     const int* __restrict__ seq_lens,
+                                                     const int* __restrict__ cu_seqlens, int seq_len,
                                                      int n_heads, _Float16* __restrict__ ctx) {
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   const int s_pad = (seq_len + 31) & ~31;
@@ -52,17 +55,19 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   const int head = blockIdx.x - b * n_heads;
   const int hidden = n_heads * kHeadDim;
   const long long row_stride = 3ll * hidden;
-  const _Float16* base = qkv + (long long)b * seq_len * row_stride + head * kHeadDim;
-  int len = seq_lens ? seq_lens[b] : seq_len;
+  const long long tok0 = cu_seqlens ? cu_seqlens[b] : (long long)b * seq_len;
+  const _Float16* base = qkv + tok0 * row_stride + head * kHeadDim;
+  int len = cu_seqlens ? cu_seqlens[b + 1] - cu_seqlens[b] : (seq_lens ? seq_lens[b] : seq_len);
   len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
   const int n_ktiles = (len + 31) >> 5;
+  const int rows_avail = cu_seqlens ? len : seq_len;   // token rows of this sequence that exist in memory
 
   const int tid = threadIdx.x;
   // stage K and V rows [0, n_ktiles*32): 8 lanes cover one 128-byte row
   for (int i = tid; i < n_ktiles * 32 * 8; i += 256) {
     const int row = i >> 3, c = i & 7;
     f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-    if (row < seq_len) {
+    if (row < rows_avail) {
       const _Float16* src = base + row * row_stride + c * 8;
       kv = *(const f16x8*)(src + hidden);
       vv = *(const f16x8*)(src + 2 * hidden);
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   const int wave = tid >> 6;
   const int li = lane & 31;
   const int half = lane >> 5;
-  const int n_qblocks = s_pad >> 5;
+  const int n_qblocks = (rows_avail + 31) >> 5;
 
   auto write_out = [&](int qb, const f32x16& o0, const f32x16& o1, float l) {
     const float inv = 1.0f / l;
@@ -98,8 +103,8 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
       const int row = it * 8 + (lane >> 3), piece = lane & 7;   // 8 lanes x 16 B = one 128-byte row
       const int qq = qb * 32 + row;
       const f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8);
-      if (qq < seq_len)
-        *(f16x8*)(ctx + ((long long)b * seq_len + qq) * hidden + head * kHeadDim + piece * 8) = v;
+      if (qq < rows_avail)
+        *(f16x8*)(ctx + (tok0 + qq) * hidden + head * kHeadDim + piece * 8) = v;
     }
   };
 
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[j] = q < seq_len ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) : z;
+      qf[j] = q < rows_avail ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) : z;
     }
     float m = -__builtin_inff();
     float l = 0.f;
@@ -183,7 +188,8 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
 // q.K^T (fp32), the softmax is a wave reduction, then lanes own the 64 output dims for P.V with the
 // probabilities broadcast from LDS.  Streams K and V once: B*S*2*128 B per head, HBM-bound.
 __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restrict__ qkv,
-                                                         const int* __restrict__ seq_lens, int seq_len,
+                                                         const int* __restrict__ seq_lens,
+                                                         const int* __restrict__ cu_seqlens, int seq_len,
                                                          int n_heads, int n_pairs, _Float16* __restrict__ ctx_cls) {
   extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
   float* p_lds = (float*)smem + (threadIdx.x >> 6) * seq_len;   // [4 waves][seq_len] probabilities
@@ -194,8 +200,9 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
   const int head = pair - b * n_heads;
   const int hidden = n_heads * kHeadDim;
   const long long row_stride = 3ll * hidden;
-  const _Float16* base = qkv + (long long)b * seq_len * row_stride + head * kHeadDim;
-  int len = seq_lens ? seq_lens[b] : seq_len;
+  const long long tok0 = cu_seqlens ? cu_seqlens[b] : (long long)b * seq_len;
+  const _Float16* base = qkv + tok0 * row_stride + head * kHeadDim;
+  int len = cu_seqlens ? cu_seqlens[b + 1] - cu_seqlens[b] : (seq_lens ? seq_lens[b] : seq_len);
   len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
 
   float qv[kHeadDim];
@@ -241,23 +248,10 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
 
 using namespace proqa;
 
-extern "C" int proqa_attention_cls_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
-                                       int n_heads, void* ctx_cls_out, void* stream) {
-  if (!qkv || !ctx_cls_out) return fail(PROQA_EINVAL, "attention_cls: NULL argument");
-  if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention_cls: bad sizes");
-  const size_t lds = (size_t)4 * seq_len * sizeof(float);
-  if (lds > 64 * 1024) return fail(PROQA_EINVAL, "attention_cls: seq_len=%d too long", seq_len);
-  if (batch == 0) return PROQA_OK;
-  const int n_pairs = batch * n_heads;
-  hipLaunchKernelGGL(attention_cls_fwd, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), lds, as_stream(stream),
-                     (const _Float16*)qkv, (const int*)seq_lens_dev, seq_len, n_heads, n_pairs,
-                     (_Float16*)ctx_cls_out);
-  PROQA_LAUNCH_CHECK();
-  return PROQA_OK;
-}
+namespace {
 
-extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
-                                   int n_heads, void* ctx_out, void* stream) {
+int launch_attention(const void* qkv, const int32_t* seq_lens_dev, const int32_t* cu_seqlens_dev, int batch,
+                     int seq_len, int n_heads, void* ctx_out, void* stream) {
   if (!qkv || !ctx_out) return fail(PROQA_EINVAL, "attention: NULL argument");
   if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention: bad sizes");
   const int s_pad = (seq_len + 31) & ~31;
@@ -269,7 +263,47 @@ extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev,
     PROQA_HIP(hipFuncSetAttribute((const void*)attention_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   hipLaunchKernelGGL(attention_fwd, dim3((unsigned)batch * n_heads), dim3(256), lds, as_stream(stream),
-                     (const _Float16*)qkv, (const int*)seq_lens_dev, seq_len, n_heads, (_Float16*)ctx_out);
+                     (const _Float16*)qkv, (const int*)seq_lens_dev, (const int*)cu_seqlens_dev, seq_len, n_heads,
+                     (_Float16*)ctx_out);
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
+}
+
+int launch_attention_cls(const void* qkv, const int32_t* seq_lens_dev, const int32_t* cu_seqlens_dev, int batch,
+                         int seq_len, int n_heads, void* ctx_cls_out, void* stream) {
+  if (!qkv || !ctx_cls_out) return fail(PROQA_EINVAL, "attention_cls: NULL argument");
+  if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention_cls: bad sizes");
+  const size_t lds = (size_t)4 * seq_len * sizeof(float);
+  if (lds > 64 * 1024) return fail(PROQA_EINVAL, "attention_cls: seq_len=%d too long", seq_len);
+  if (batch == 0) return PROQA_OK;
+  const int n_pairs = batch * n_heads;
+  hipLaunchKernelGGL(attention_cls_fwd, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), lds, as_stream(stream),
+                     (const _Float16*)qkv, (const int*)seq_lens_dev, (const int*)cu_seqlens_dev, seq_len, n_heads,
+                     n_pairs, (_Float16*)ctx_cls_out);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+}  // namespace
+
+extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
+                                   int n_heads, void* ctx_out, void* stream) {
+  return launch_attention(qkv, seq_lens_dev, nullptr, batch, seq_len, n_heads, ctx_out, stream);
+}
+
+extern "C" int proqa_attention_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens_dev, int batch,
+                                          int max_seq_len, int n_heads, void* ctx_packed_out, void* stream) {
+  if (!cu_seqlens_dev) return fail(PROQA_EINVAL, "attention_varlen: NULL cu_seqlens");
+  return launch_attention(qkv_packed, nullptr, cu_seqlens_dev, batch, max_seq_len, n_heads, ctx_packed_out, stream);
+}
+
+extern "C" int proqa_attention_cls_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
+                                       int n_heads, void* ctx_cls_out, void* stream) {
+  return launch_attention_cls(qkv, seq_lens_dev, nullptr, batch, seq_len, n_heads, ctx_cls_out, stream);
+}
+
+extern "C" int proqa_attention_cls_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens_dev, int batch,
+                                              int max_seq_len, int n_heads, void* ctx_cls_out, void* stream) {
+  if (!cu_seqlens_dev) return fail(PROQA_EINVAL, "attention_cls_varlen: NULL cu_seqlens");
+  return launch_attention_cls(qkv_packed, nullptr, cu_seqlens_dev, batch, max_seq_len, n_heads, ctx_cls_out, stream);
 }

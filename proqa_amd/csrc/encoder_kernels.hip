@@ -67,8 +67,10 @@ __device__ __forceinline__ void layernorm_store(float (&x)[kMaxChunksPerLane][8]
 }
 
 // BertEmbeddings: LN(word[id] + pos[s] + type[0])
+// cu_seqlens != nullptr: ids stay padded [B, seq_len] but the output is packed -- token (b, s) with
+// s < len(b) goes to row cu_seqlens[b] + s, padding positions produce nothing
 __global__ __launch_bounds__(256) void embed_layernorm(const long long* __restrict__ ids, long long n_tokens,
-                                                       int seq_len, int hidden,
+                                                       const int* __restrict__ cu_seqlens, int seq_len, int hidden,
                                                        const _Float16* __restrict__ word, long long vocab,
                                                        const _Float16* __restrict__ pos,
                                                        const _Float16* __restrict__ type0,
@@ -81,6 +83,13 @@ __global__ __launch_bounds__(256) void embed_layernorm(const long long* __restri
   long long id = ids[tok];
   if (id < 0 || id >= vocab) id = 0;  // never index outside the table
   const int s = (int)(tok % seq_len);
+  long long out_row = tok;
+  if (cu_seqlens) {
+    const long long b = tok / seq_len;
+    const int first = cu_seqlens[b];
+    if (s >= cu_seqlens[b + 1] - first) return;
+    out_row = first + s;
+  }
   const int n_chunks = hidden >> 3;
   const _Float16* w = word + id * hidden;
   const _Float16* p = pos + (long long)s * hidden;
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256) void embed_layernorm(const long long* __restri
       for (int i = 0; i < 8; ++i) x[c][i] = (float)a[i] + (float)b[i] + (float)t[i];
     }
   }
-  layernorm_store(x, lane, n_chunks, hidden, gamma, beta, eps, out + tok * hidden);
+  layernorm_store(x, lane, n_chunks, hidden, gamma, beta, eps, out + out_row * hidden);
 }
 
 // BertSelfOutput / BertOutput: LN(dense_out + bias + residual)
@@ -191,9 +200,10 @@ using namespace proqa;
 
 extern "C" {
 
-int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_len, int hidden,
-                              const void* word_emb, int64_t vocab, const void* pos_emb, const void* type_emb,
-                              const void* ln_gamma, const void* ln_beta, float eps, void* out, void* stream) {
+static int launch_embed_layernorm(const int64_t* ids_dev, int64_t n_tokens, const int32_t* cu_seqlens_dev, int seq_len,
+                                  int hidden, const void* word_emb, int64_t vocab, const void* pos_emb,
+                                  const void* type_emb, const void* ln_gamma, const void* ln_beta, float eps, void* out,
+                                  void* stream) {
   if (!ids_dev || !word_emb || !pos_emb || !type_emb || !ln_gamma || !ln_beta || !out)
     return fail(PROQA_EINVAL, "embed_layernorm: NULL argument");
   if (n_tokens < 0 || seq_len <= 0 || vocab <= 0) return fail(PROQA_EINVAL, "embed_layernorm: bad sizes");
@@ -203,11 +213,27 @@ int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_
   if (n_tokens == 0) return PROQA_OK;
   const unsigned grid = (unsigned)ceil_div<int64_t>(n_tokens, kRowsPerBlock);
   hipLaunchKernelGGL(embed_layernorm, dim3(grid), dim3(256), 0, as_stream(stream), (const long long*)ids_dev,
-                     (long long)n_tokens, seq_len, hidden, (const _Float16*)word_emb, (long long)vocab,
-                     (const _Float16*)pos_emb, (const _Float16*)type_emb, (const _Float16*)ln_gamma,
+                     (long long)n_tokens, (const int*)cu_seqlens_dev, seq_len, hidden, (const _Float16*)word_emb,
+                     (long long)vocab, (const _Float16*)pos_emb, (const _Float16*)type_emb, (const _Float16*)ln_gamma,
                      (const _Float16*)ln_beta, eps, (_Float16*)out);
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
+}
+
+int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_len, int hidden,
+                              const void* word_emb, int64_t vocab, const void* pos_emb, const void* type_emb,
+                              const void* ln_gamma, const void* ln_beta, float eps, void* out, void* stream) {
+  return launch_embed_layernorm(ids_dev, n_tokens, nullptr, seq_len, hidden, word_emb, vocab, pos_emb, type_emb,
+                                ln_gamma, ln_beta, eps, out, stream);
+}
+
+int proqa_embed_layernorm_varlen_f16(const int64_t* ids_dev, const int32_t* cu_seqlens_dev, int batch, int seq_len,
+                                     int hidden, const void* word_emb, int64_t vocab, const void* pos_emb,
+                                     const void* type_emb, const void* ln_gamma, const void* ln_beta, float eps,
+                                     void* out_packed, void* stream) {
+  if (!cu_seqlens_dev || batch < 0) return fail(PROQA_EINVAL, "embed_layernorm_varlen: bad argument");
+  return launch_embed_layernorm(ids_dev, (int64_t)batch * seq_len, cu_seqlens_dev, seq_len, hidden, word_emb, vocab,
+                                pos_emb, type_emb, ln_gamma, ln_beta, eps, out_packed, stream);
 }
 
 int proqa_bias_residual_layernorm_f16(const void* x, const void* bias, const void* residual, const void* gamma,

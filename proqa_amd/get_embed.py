@@ -53,7 +53,12 @@ def _dist_env(args):
     return 1, 0, 0
 
 
-N_STREAMS = 2   # batches in flight: one batch's HBM-bound kernels overlap the other's GEMMs
+# Batches in flight.  Two streams overlapped one batch's HBM-bound kernels with the other's GEMMs for
+# ~2.5 %, but two hipBLASLt stream-K GEMMs running concurrently deadlock (their workgroups spin on
+# partial tiles of partners that cannot be scheduled) as soon as M is not a multiple of the tile --
+# any ragged batch -- so the encoder stays on ONE side stream (kernel launches are asynchronous: the
+# host collates and uploads batch i+1 while batch i computes).
+N_STREAMS = 1
 
 
 def _right_padded(mask):
@@ -73,10 +78,12 @@ def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=Tru
     for i, batch in enumerate(eval_dataloader):
         if not _right_padded(batch["input_mask"]):
             raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
+        lens = batch["input_mask"].sum(dim=1).tolist()      # host-side: lets the encoder skip the padding
         s = streams[i % N_STREAMS]
         with torch.cuda.stream(s), torch.no_grad():
             batch_to_feed = move_to_cuda(batch)
-            chunks.append(model.get_embed(batch_to_feed, is_query_embed, check_mask=False)["embed"])
+            chunks.append(model.get_embed(batch_to_feed, is_query_embed, check_mask=False,
+                                          seq_lens_host=lens)["embed"])
     for s in streams:
         main.wait_stream(s)
     if chunks:

@@ -52,6 +52,9 @@ def tower_keys(prefix, n_layers):
     return keys
 
 
+ROW_TILE = 256   # token rows handed to the dense layers are a multiple of this (hipBLASLt macro-tile)
+
+
 class _Tower:
     """fp16 device weights of one BERT tower, laid out for the kernels (fused QKV, [out,in] GEMM operands)."""
 
@@ -106,6 +109,8 @@ class BertForRetriever:
         # last layer: attention output, dense blocks and LayerNorms for the [CLS] rows only (same result:
         # nothing else of that layer reaches the pooler); False runs every token through it
         self.cls_only_last_layer = True
+        # evaluate valid tokens only (packed layout) whenever the lengths are known on the host
+        self.pack_tokens = True
         self._ws = {}
 
     # -- reference-compatible surface -----------------------------------------------------
@@ -163,12 +168,13 @@ class BertForRetriever:
         raise NotImplementedError("training forward (retriever.py:22-31) is outside the encode/search hot path")
 
     @torch.no_grad()
-    def get_embed(self, batch, is_query_embed, check_mask=True):
+    def get_embed(self, batch, is_query_embed, check_mask=True, seq_lens_host=None):
         """check_mask=False skips the device-side validation of the right-padding (it costs a
-        host sync per batch); callers that validated the mask on the host pass False so that
-        batches can be pipelined on several streams (proqa_amd.get_embed.predict)."""
+        host sync per batch); callers that validated the mask on the host pass False -- and the
+        per-sequence lengths as seq_lens_host -- so that batches can be pipelined on several
+        streams (proqa_amd.get_embed.predict)."""
         ids, mask = batch["input_ids"], batch["input_mask"]
-        emb = self.encode(ids, mask, bool(is_query_embed), check_mask=check_mask)
+        emb = self.encode(ids, mask, bool(is_query_embed), check_mask=check_mask, seq_lens_host=seq_lens_host)
         return {"embed": emb}
 
     # -- implementation -------------------------------------------------------------------
@@ -179,23 +185,33 @@ class BertForRetriever:
         if ws is None:
             H, I = self.config.hidden_size, self.config.intermediate_size
             dev, f16 = self.device, torch.float16
-            n = B * S
+            # token rows are rounded up to the GEMM tile (ROW_TILE): the dense layers always see a multiple
+            # of it; rows past the last token hold zeros / stale finite values that nothing reads back
+            n = -(-B * S // ROW_TILE) * ROW_TILE
             ws = SimpleNamespace(
-                h=torch.empty((n, H), dtype=f16, device=dev), h1=torch.empty((n, H), dtype=f16, device=dev),
-                qkv=torch.empty((n, 3 * H), dtype=f16, device=dev), ctx=torch.empty((n, H), dtype=f16, device=dev),
-                tmp=torch.empty((n, H), dtype=f16, device=dev), ff=torch.empty((n, I), dtype=f16, device=dev),
+                h=torch.zeros((n, H), dtype=f16, device=dev), h1=torch.zeros((n, H), dtype=f16, device=dev),
+                qkv=torch.zeros((n, 3 * H), dtype=f16, device=dev), ctx=torch.zeros((n, H), dtype=f16, device=dev),
+                tmp=torch.zeros((n, H), dtype=f16, device=dev), ff=torch.zeros((n, I), dtype=f16, device=dev),
                 pooled=torch.empty((B, H), dtype=f16, device=dev),
                 # [CLS]-row buffers of the last layer
                 c_ctx=torch.empty((B, H), dtype=f16, device=dev), c_res=torch.empty((B, H), dtype=f16, device=dev),
                 c_tmp=torch.empty((B, H), dtype=f16, device=dev), c_h1=torch.empty((B, H), dtype=f16, device=dev),
-                c_ff=torch.empty((B, I), dtype=f16, device=dev), c_h=torch.empty((B, H), dtype=f16, device=dev))
+                c_ff=torch.empty((B, I), dtype=f16, device=dev), c_h=torch.empty((B, H), dtype=f16, device=dev),
+                cu=torch.zeros((B + 1,), dtype=torch.int32, device=dev))     # packed-layout sequence offsets
             if len(self._ws) > 8:
                 self._ws.clear()
             self._ws[key] = ws
         return ws
 
     @torch.no_grad()
-    def encode(self, input_ids, input_mask, is_query_embed, check_mask=True):
+    def encode(self, input_ids, input_mask, is_query_embed, check_mask=True, seq_lens_host=None):
+        """[B,S] ids + right-padded bool mask -> [B,128] embeddings.
+
+        Padding is not computed when the sequence lengths are known on the host: tokens are packed
+        back to back ([T, hidden], T = sum of lengths) for every per-token operator, the embedding
+        gather and the attention take the offsets.  The lengths come from `seq_lens_host` (predict()
+        passes them from the collated CPU batch) or from the one host round trip `check_mask` makes
+        anyway; with neither, the padded [B*S] layout is evaluated."""
         if not self.towers:
             raise RuntimeError("load_state_dict must be called before get_embed")
         if not input_ids.is_cuda:
@@ -208,44 +224,85 @@ class BertForRetriever:
             raise ValueError(f"sequence length {S} exceeds max_position_embeddings {cfg.max_position_embeddings}")
         H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
         eps = float(cfg.layer_norm_eps)
-        ids = input_ids.contiguous().to(torch.int64)
-        mask = input_mask.to(torch.bool)
-        # em_collate pads on the right: the mask of every row is a prefix of ones
-        if check_mask and S > 1 and bool((mask[:, 1:] & ~mask[:, :-1]).any()):
-            raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
-        lens = mask.sum(dim=1).to(torch.int32).contiguous()
         out = torch.empty((B, EMBED_DIM), dtype=self.out_dtype, device=self.device)
         if B == 0:
             return out
-        ws = self._buffers(B, S)
+        ids = input_ids.contiguous().to(torch.int64)
+        mask = input_mask.to(torch.bool)
+        lens = mask.sum(dim=1).to(torch.int32).contiguous()
+        n_valid = None
+        if seq_lens_host is not None:
+            n_valid = int(sum(int(v) for v in seq_lens_host))
+        if check_mask:
+            # em_collate pads on the right: the mask of every row is a prefix of ones
+            bad = (mask[:, 1:] & ~mask[:, :-1]).any() if S > 1 else torch.zeros((), dtype=torch.bool, device=mask.device)
+            probe = torch.stack([bad.to(torch.int64), lens.sum(dtype=torch.int64)]).cpu()   # one host round trip
+            if bool(probe[0]):
+                raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
+            if n_valid is not None and n_valid != int(probe[1]):
+                raise ValueError("seq_lens_host does not match input_mask")
+            n_valid = int(probe[1])
         n = B * S
+        packed = self.pack_tokens and n_valid is not None and 0 < n_valid < n
+        ws = self._buffers(B, S)
         with torch.cuda.device(self.device):
             st = _lib.current_stream_ptr()
-            chk(lib.proqa_embed_layernorm_f16(ids.data_ptr(), n, S, H, tw.word.data_ptr(), tw.word.shape[0],
-                                              tw.pos.data_ptr(), tw.type0.data_ptr(), tw.emb_g.data_ptr(),
-                                              tw.emb_b.data_ptr(), eps, ws.h.data_ptr(), st))
-            h, h1 = ws.h, ws.h1
+            if packed:
+                n = n_valid
+                cu = ws.cu                                       # cu[0] stays 0
+                torch.cumsum(lens, 0, dtype=torch.int32, out=cu[1:])
+                cu_ptr = cu.data_ptr()
+                chk(lib.proqa_embed_layernorm_varlen_f16(ids.data_ptr(), cu_ptr, B, S, H, tw.word.data_ptr(),
+                                                         tw.word.shape[0], tw.pos.data_ptr(), tw.type0.data_ptr(),
+                                                         tw.emb_g.data_ptr(), tw.emb_b.data_ptr(), eps,
+                                                         ws.h.data_ptr(), st))
+            else:
+                chk(lib.proqa_embed_layernorm_f16(ids.data_ptr(), n, S, H, tw.word.data_ptr(), tw.word.shape[0],
+                                                  tw.pos.data_ptr(), tw.type0.data_ptr(), tw.emb_g.data_ptr(),
+                                                  tw.emb_b.data_ptr(), eps, ws.h.data_ptr(), st))
+            # row-prefix views of the workspaces: B*S (padded) or the number of valid tokens (packed), rounded
+            # up to the GEMM tile so that hipBLASLt stays on its full-tile kernels for ragged batches
+            if n > 8 * ROW_TILE:                      # small batches: nothing to gain, keep them small
+                n = -(-n // ROW_TILE) * ROW_TILE
+            h, h1, qkv, ctx, tmp, ff = ws.h[:n], ws.h1[:n], ws.qkv[:n], ws.ctx[:n], ws.tmp[:n], ws.ff[:n]
+
+            def attention(cls_only, dst):
+                if packed:
+                    fn = lib.proqa_attention_cls_varlen_f16 if cls_only else lib.proqa_attention_varlen_f16
+                    chk(fn(qkv.data_ptr(), cu_ptr, B, S, NH, dst.data_ptr(), st))
+                else:
+                    fn = lib.proqa_attention_cls_f16 if cls_only else lib.proqa_attention_f16
+                    chk(fn(qkv.data_ptr(), lens.data_ptr(), B, S, NH, dst.data_ptr(), st))
+
             full_layers = tw.layers[:-1] if self.cls_only_last_layer else tw.layers
             for L in full_layers:
-                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=ws.qkv)                       # fused Q|K|V projection
-                chk(lib.proqa_attention_f16(ws.qkv.data_ptr(), lens.data_ptr(), B, S, NH, ws.ctx.data_ptr(), st))
-                torch.mm(ws.ctx, L.ao_w.t(), out=ws.tmp)
-                chk(lib.proqa_bias_residual_layernorm_f16(ws.tmp.data_ptr(), L.ao_b.data_ptr(), h.data_ptr(),
+                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=qkv)                          # fused Q|K|V projection
+                attention(False, ctx)
+                torch.mm(ctx, L.ao_w.t(), out=tmp)
+                chk(lib.proqa_bias_residual_layernorm_f16(tmp.data_ptr(), L.ao_b.data_ptr(), h.data_ptr(),
                                                           L.ln1_g.data_ptr(), L.ln1_b.data_ptr(), eps, n, H,
                                                           h1.data_ptr(), st))
-                torch.mm(h1, L.ff1_w.t(), out=ws.ff)
-                chk(lib.proqa_bias_gelu_f16(ws.ff.data_ptr(), L.ff1_b.data_ptr(), n, I, st))
-                torch.mm(ws.ff, L.ff2_w.t(), out=ws.tmp)
-                chk(lib.proqa_bias_residual_layernorm_f16(ws.tmp.data_ptr(), L.ff2_b.data_ptr(), h1.data_ptr(),
+                torch.mm(h1, L.ff1_w.t(), out=ff)
+                chk(lib.proqa_bias_gelu_f16(ff.data_ptr(), L.ff1_b.data_ptr(), n, I, st))
+                torch.mm(ff, L.ff2_w.t(), out=tmp)
+                chk(lib.proqa_bias_residual_layernorm_f16(tmp.data_ptr(), L.ff2_b.data_ptr(), h1.data_ptr(),
                                                           L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, n, H,
                                                           h.data_ptr(), st))
+
+            def cls_rows(dst):
+                # h[:, 0] of every sequence -> dst [B, H]
+                if packed:
+                    torch.index_select(h, 0, cu[:-1], out=dst)
+                else:
+                    dst.copy_(h.view(B, S, H)[:, 0])
+
             if self.cls_only_last_layer:
                 # the pooler reads h[:, 0] only (retriever.py:41-42): the last layer needs K and V of every
                 # token but the attention output, both dense blocks and LayerNorms for the [CLS] rows alone
                 L = tw.layers[-1]
-                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=ws.qkv)
-                chk(lib.proqa_attention_cls_f16(ws.qkv.data_ptr(), lens.data_ptr(), B, S, NH, ws.c_ctx.data_ptr(), st))
-                ws.c_res.copy_(h.view(B, S, H)[:, 0])
+                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=qkv)
+                attention(True, ws.c_ctx)
+                cls_rows(ws.c_res)
                 torch.mm(ws.c_ctx, L.ao_w.t(), out=ws.c_tmp)
                 chk(lib.proqa_bias_residual_layernorm_f16(ws.c_tmp.data_ptr(), L.ao_b.data_ptr(), ws.c_res.data_ptr(),
                                                           L.ln1_g.data_ptr(), L.ln1_b.data_ptr(), eps, B, H,
@@ -256,8 +313,9 @@ class BertForRetriever:
                 chk(lib.proqa_bias_residual_layernorm_f16(ws.c_tmp.data_ptr(), L.ff2_b.data_ptr(), ws.c_h1.data_ptr(),
                                                           L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, B, H,
                                                           ws.c_h.data_ptr(), st))
-                h, S = ws.c_h, 1
-            chk(lib.proqa_pool_project_f16(h.data_ptr(), B, S, H, tw.pool_w.data_ptr(), tw.pool_b.data_ptr(),
+            else:
+                cls_rows(ws.c_h)
+            chk(lib.proqa_pool_project_f16(ws.c_h.data_ptr(), B, 1, H, tw.pool_w.data_ptr(), tw.pool_b.data_ptr(),
                                            tw.proj_w.data_ptr(), tw.proj_b.data_ptr(), ws.pooled.data_ptr(),
                                            out.data_ptr(),
                                            PROQA_F16 if self.out_dtype == torch.float16 else PROQA_F32, st))

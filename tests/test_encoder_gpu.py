@@ -177,6 +177,60 @@ def test_attention_cls_rows(lib, gpu_device, B, S, NH):
     close(out, ref, rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("B,S,NH", [(3, 48, 2), (6, 128, 12), (2, 512, 4), (4, 77, 3)])
+def test_attention_packed_layout(lib, gpu_device, B, S, NH):
+    """Packed (varlen) token layout: same numbers as the padded evaluation, no padding rows."""
+    from proqa_amd import _lib
+    rng = np.random.default_rng(S * 7 + NH)
+    lens = rng.integers(1, S + 1, B).astype(np.int32)
+    lens[0] = S
+    lens[-1] = 1
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    H = NH * 64
+    qkv_packed = rng.standard_normal((T, 3 * H)).astype(np.float16)
+    padded = np.zeros((B, S, 3 * H), np.float16)
+    for b in range(B):
+        padded[b, :lens[b]] = qkv_packed[cu[b]:cu[b + 1]]
+    ref = attention_ref(padded.reshape(B * S, -1), lens, B, S, NH)
+    tq = dev16(qkv_packed, gpu_device)
+    tcu = torch.from_numpy(cu).to(gpu_device)
+    out = torch.full((T + 1, H), 7.0, dtype=torch.float16, device=gpu_device)     # row T is a canary
+    _lib.check(lib.proqa_attention_varlen_f16(tq.data_ptr(), tcu.data_ptr(), B, S, NH, out.data_ptr(), stream()))
+    for b in range(B):
+        close(out[cu[b]:cu[b + 1]], ref[b, :lens[b]], rtol=3e-3, atol=3e-3)
+    assert (out[T] == 7).all()
+    cls = torch.empty((B, H), dtype=torch.float16, device=gpu_device)
+    _lib.check(lib.proqa_attention_cls_varlen_f16(tq.data_ptr(), tcu.data_ptr(), B, S, NH, cls.data_ptr(), stream()))
+    close(cls, ref[:, 0], rtol=2e-3, atol=2e-3)
+
+
+def test_embed_layernorm_packed_layout(lib, gpu_device):
+    from proqa_amd import _lib
+    rng = np.random.default_rng(4)
+    B, S, H, V = 5, 40, 768, 300
+    lens = np.array([40, 1, 17, 33, 8], np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    ids = rng.integers(0, V, (B, S)).astype(np.int64)
+    word, pos, typ = (rng.standard_normal(sh).astype(np.float16) for sh in [(V, H), (S, H), (H,)])
+    g, bt = rng.standard_normal(H).astype(np.float16), rng.standard_normal(H).astype(np.float16)
+    args = [dev16(a, gpu_device) for a in (word, pos, typ, g, bt)]
+    tid, tcu = torch.from_numpy(ids).to(gpu_device), torch.from_numpy(cu).to(gpu_device)
+    padded = torch.empty((B * S, H), dtype=torch.float16, device=gpu_device)
+    _lib.check(lib.proqa_embed_layernorm_f16(tid.data_ptr(), B * S, S, H, args[0].data_ptr(), V, args[1].data_ptr(),
+                                             args[2].data_ptr(), args[3].data_ptr(), args[4].data_ptr(), 1e-12,
+                                             padded.data_ptr(), stream()))
+    packed = torch.full((T + 1, H), 7.0, dtype=torch.float16, device=gpu_device)
+    _lib.check(lib.proqa_embed_layernorm_varlen_f16(tid.data_ptr(), tcu.data_ptr(), B, S, H, args[0].data_ptr(), V,
+                                                    args[1].data_ptr(), args[2].data_ptr(), args[3].data_ptr(),
+                                                    args[4].data_ptr(), 1e-12, packed.data_ptr(), stream()))
+    padded = padded.view(B, S, H)
+    for b in range(B):
+        assert torch.equal(packed[cu[b]:cu[b + 1]], padded[b, :lens[b]])
+    assert (packed[T] == 7).all()
+
+
 def cosine(a, b):
     return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
 
@@ -225,12 +279,21 @@ def test_bert_base_shape_against_oracle(gpu_device):
     batch = {"input_ids": torch.from_numpy(ids).to(gpu_device), "input_mask": torch.from_numpy(mask).to(gpu_device)}
     ref = bert_oracle.get_embed({k: v.numpy() for k, v in sd.items()}, ids, mask, False, 12, 12)
     got = {}
-    for cls_only in (True, False):          # last layer on the [CLS] rows only / on every token
-        model.cls_only_last_layer = cls_only
-        got[cls_only] = model.get_embed(batch, False)["embed"].float().cpu().numpy()
-        assert np.abs(got[cls_only] - ref).max() < 1e-2
-        assert cosine(got[cls_only], ref).min() > 0.9995
-    assert np.abs(got[True] - got[False]).max() < 3e-3
+    # last layer on the [CLS] rows only / on every token  x  valid tokens packed / padded layout
+    for cls_only in (True, False):
+        for packed in (True, False):
+            model.cls_only_last_layer, model.pack_tokens = cls_only, packed
+            got[cls_only, packed] = model.get_embed(batch, False)["embed"].float().cpu().numpy()
+            assert np.abs(got[cls_only, packed] - ref).max() < 1e-2
+            assert cosine(got[cls_only, packed], ref).min() > 0.9995
+    for key, val in got.items():
+        assert np.abs(val - got[True, True]).max() < 3e-3, key
+    # lengths handed over from the host (predict()) instead of read back from the device
+    model.cls_only_last_layer = model.pack_tokens = True
+    alt = model.get_embed(batch, False, check_mask=False, seq_lens_host=lens.tolist())["embed"].float().cpu().numpy()
+    np.testing.assert_array_equal(alt, got[True, True])
+    with pytest.raises(ValueError, match="seq_lens_host"):
+        model.get_embed(batch, False, seq_lens_host=[128] * B)
 
 
 def test_rejects_bad_inputs(gpu_device):
