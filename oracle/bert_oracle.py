@@ -39,7 +39,10 @@ def layer_norm(x, g, b, eps):
 
 
 def linear(x, w, b):
-    return (x @ _f32(w).T + _f32(b)).astype(np.float32)
+    # one [tokens, in] x [in, out] sgemm (a batched matmul over the leading axes threads poorly)
+    x = _f32(x)
+    y = x.reshape(-1, x.shape[-1]) @ _f32(w).T + _f32(b)
+    return y.reshape(x.shape[:-1] + (y.shape[-1],)).astype(np.float32, copy=False)
 
 
 def gelu_erf(x):

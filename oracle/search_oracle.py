@@ -53,16 +53,26 @@ def merge_lists(D_parts, I_parts, k):
     nq = D.shape[0]
     outD = np.full((nq, k), NEG_FILL, dtype=np.float32)
     outI = np.full((nq, k), -1, dtype=np.int64)
-    for q in range(nq):
-        valid = np.nonzero(I[q] >= 0)[0]
-        order = valid[np.lexsort((I[q, valid], -D[q, valid].astype(np.float64)))][:k]
-        outD[q, :len(order)] = D[q, order]
-        outI[q, :len(order)] = I[q, order]
+    # invalid slots (I < 0) sort last; then (score desc, id asc) by two stable passes
+    big = np.iinfo(np.int64).max
+    ids = np.where(I >= 0, I, big)
+    o = np.argsort(ids, axis=1, kind="stable")
+    ids, Ds = np.take_along_axis(ids, o, axis=1), np.take_along_axis(D, o, axis=1)
+    key = np.where(ids != big, -Ds.astype(np.float64), np.inf)
+    o = np.argsort(key, axis=1, kind="stable")[:, :k]
+    ids, Ds = np.take_along_axis(ids, o, axis=1), np.take_along_axis(Ds, o, axis=1)
+    m = ids.shape[1]
+    valid = ids != big
+    outD[:, :m] = np.where(valid, Ds, NEG_FILL)
+    outI[:, :m] = np.where(valid, ids, -1)
     return outD, outI
 
 
 def topk_ip(xq, xb, k, block_rows=262144, query_block=256):
-    """D, I = IndexFlatIP(d).add(xb).search(xq, k) restated in NumPy (blocked to bound memory)."""
+    """D, I = IndexFlatIP(d).add(xb).search(xq, k) restated in NumPy (blocked to bound memory).
+
+    Like faiss' result heaps, a query keeps its running k-th best score: once k results exist, a
+    block contributes only the scores that reach that threshold (one vectorised compare per block)."""
     xq = np.asarray(xq)
     xb = np.asarray(xb)
     nq, n = xq.shape[0], xb.shape[0]
@@ -71,18 +81,61 @@ def topk_ip(xq, xb, k, block_rows=262144, query_block=256):
     if nq == 0 or n == 0:
         return outD, outI
     xq32 = xq.astype(np.float32)
-    for q0 in range(0, nq, query_block):
-        q1 = min(nq, q0 + query_block)
-        partsD, partsI = [], []
-        for r0 in range(0, n, block_rows):
-            r1 = min(n, r0 + block_rows)
-            S = xq32[q0:q1] @ xb[r0:r1].astype(np.float32).T
-            D, I = _topk_rows(S, k, col_offset=r0)
-            partsD.append(D)
-            partsI.append(I)
-        D, I = merge_lists(partsD, partsI, k)
-        outD[q0:q1] = D
-        outI[q0:q1] = I
+    # a short first block fills the lists (full selection), every later block is threshold-filtered
+    first = min(block_rows, max(4096, 4 * k))
+    bounds = [0] + list(range(first, n, block_rows)) + [n] if n > first else [0, n]
+    # score / mask buffers are allocated once and reused (fresh pages per block cost more than the sgemm)
+    s_buf = np.empty((min(nq, query_block), min(n, max(first, block_rows))), dtype=np.float32)
+    m_buf = np.empty(s_buf.shape, dtype=bool)
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        xb32 = np.asarray(xb[r0:r1], dtype=np.float32)  # the reference's upcast (eval_retrieval.py:99-100)
+        for q0 in range(0, nq, query_block):
+            q1 = min(nq, q0 + query_block)
+            if q1 - q0 == s_buf.shape[0] and r1 - r0 == s_buf.shape[1]:
+                S = np.matmul(xq32[q0:q1], xb32.T, out=s_buf)
+            else:
+                S = xq32[q0:q1] @ xb32.T
+            if r0 < k:                                # fewer than k rows seen so far: no threshold yet
+                D, I = _topk_rows(S, k, col_offset=r0)
+                outD[q0:q1], outI[q0:q1] = merge_lists([outD[q0:q1], D], [outI[q0:q1], I], k)
+                continue
+            tau = outD[q0:q1, k - 1][:, None]
+            mask = np.greater_equal(S, tau, out=m_buf) if S is s_buf else S >= tau
+            flat = np.flatnonzero(mask)
+            if len(flat) == 0:
+                continue
+            rows, cols = np.divmod(flat, S.shape[1])
+            starts = np.searchsorted(rows, np.arange(q1 - q0 + 1))
+            for q in np.unique(rows):
+                c = cols[starts[q]:starts[q + 1]]
+                D = np.concatenate([outD[q0 + q], S[q, c]])
+                I = np.concatenate([outI[q0 + q], c + r0])
+                order = np.lexsort((I, -D.astype(np.float64)))[:k]
+                outD[q0 + q], outI[q0 + q] = D[order], I[order]
+    return outD, outI
+
+
+def topk_ip_threaded(xq, xb, k, workers=8, query_block=128, block_rows=262144):
+    """topk_ip with the query blocks spread over a thread pool (one BLAS thread each) -- the shape of
+    faiss' own CPU search (blocked sgemm + per-query heaps under OpenMP).  Same results as topk_ip;
+    bench.py times this one as the CPU baseline so that the top-k selection is threaded too."""
+    from concurrent.futures import ThreadPoolExecutor
+    from threadpoolctl import threadpool_limits
+    xq = np.asarray(xq)
+    nq = xq.shape[0]
+    outD = np.full((nq, k), NEG_FILL, dtype=np.float32)
+    outI = np.full((nq, k), -1, dtype=np.int64)
+    if nq == 0 or len(xb) == 0:
+        return outD, outI
+    blocks = [(q0, min(nq, q0 + query_block)) for q0 in range(0, nq, query_block)]
+    xb = np.asarray(xb).astype(np.float32)            # upcast once, like eval_retrieval.py:100; shared by the workers
+
+    def run(b):
+        return topk_ip(xq[b[0]:b[1]], xb, k, block_rows=block_rows, query_block=query_block)
+
+    with threadpool_limits(limits=1), ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+        for b, (D, I) in zip(blocks, pool.map(run, blocks)):
+            outD[b[0]:b[1]], outI[b[0]:b[1]] = D, I
     return outD, outI
 
 
