@@ -15,7 +15,9 @@ root = sys.argv[1]
 
 
 def short(name):
-    for key in ("mips_filter_f16", "topk_merge", "merge_lists", "prep_queries", "finalize_topk", "attention_fwd",
+    if "mips_filter_f16<1" in name:
+        return "mips_filter_f16_qw1"      # the HBM-bound small-batch instantiation (bench.py scan_small_batch)
+    for key in ("mips_filter_f16", "topk_merge", "merge_lists", "prep_queries", "finalize_topk", "attention_fwd", "attention_cls_fwd",
                 "bias_gelu", "bias_residual_layernorm", "embed_layernorm", "pool_project", "Cijk_"):
         if key in name:
             return key if key != "Cijk_" else "hipblaslt_gemm(" + name.split("_MT")[1].split("_")[0] + ")" if "_MT" in name else "hipblaslt_gemm"
@@ -34,6 +36,17 @@ if os.path.exists(stats_in):
                 w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
 summary = {}
+def bench_line(log):
+    """The JSON line bench.py printed under the profiler (last line of the pass's log)."""
+    try:
+        for line in reversed(open(os.path.join(root, log)).read().strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception:
+        pass
+    return {}
+
+
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
     path = os.path.join(root, sub, "bench_counter_collection.csv")
     if not os.path.exists(path):
@@ -44,7 +57,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
     seen = set()
     for r in csv.DictReader(open(path)):
         n = short(r["Kernel_Name"])
-        if not n or n.startswith("hipblaslt"):
+        if not n:
             continue
         per[n][r["Counter_Name"]] += float(r["Counter_Value"])
         launches[n].add(r["Dispatch_Id"])
@@ -61,8 +74,10 @@ f = summary.get("mips_filter_f16", {})
 derived = {}
 searches = None
 if "launches_pmc_fetch" in f:
-    # bench.py --steps 2 --warmup 1 runs 3 searches of 8 rounds each
-    searches = 3
+    # full-size searches in the pass = launches of the QW=2 instantiation / rounds per search (bench line)
+    rounds = bench_line("pmc_fetch.log").get("config", {}).get("rounds", 8)
+    searches = f["launches_pmc_fetch"] / rounds
+    derived["rounds_per_search"] = rounds
     derived["searches_profiled"] = searches
     derived["FETCH_SIZE_KB_per_search_raw"] = f["FETCH_SIZE"] / searches
     derived["hbm_read_bytes_per_search"] = 2 * f["FETCH_SIZE"] * 1024 / searches   # gfx950: FETCH_SIZE counts 1/2
@@ -78,7 +93,50 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in f and "SQ_BUSY_CYCLES" in f:
     derived["lds_active_fraction"] = f["SQ_LDS_IDX_ACTIVE"] / (256 * cycles)
     derived["wave_wait_fraction"] = f["SQ_WAIT_ANY"] / f["SQ_WAVE_CYCLES"]
     derived["wave_issue_stall_fraction"] = f["SQ_WAIT_INST_ANY"] / f["SQ_WAVE_CYCLES"]
+g = summary.get("mips_filter_f16_qw1", {})
+if "FETCH_SIZE" in g:
+    # bench.py's scan_small_batch leg: 6 searches of 32 queries (3 plain + 3 with HIP-event brackets)
+    derived["small_batch_hbm_read_bytes_per_search"] = 2 * g["FETCH_SIZE"] * 1024 / 6
 summary["derived_mips_filter"] = derived
+
+# encoder passes (collect_profiles.sh: enc_pmc_sq / enc_pmc_grbm run bench.py with a token-size search)
+enc = {}
+for sub in ("enc_pmc_sq", "enc_pmc_grbm"):
+    path = os.path.join(root, sub, "bench_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        n = short(r["Kernel_Name"])
+        if not n or n.startswith("mips_") or n in ("topk_merge", "prep_queries", "finalize_topk", "merge_lists"):
+            continue
+        d = enc.setdefault(n, collections.defaultdict(float))
+        d[r["Counter_Name"]] += float(r["Counter_Value"])
+        if (sub, r["Dispatch_Id"]) not in seen:
+            seen.add((sub, r["Dispatch_Id"]))
+            d["duration_ns_" + sub] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            d["launches_" + sub] += 1
+derived_enc = {}
+tot_busy = tot_cycles = 0.0
+for n, d in enc.items():
+    o = {}
+    if d.get("SQ_BUSY_CYCLES"):
+        cycles = d["SQ_BUSY_CYCLES"] / 32
+        o["mfma_pipe_busy_fraction"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)
+        o["share_of_encoder_gpu_cycles"] = cycles
+        tot_busy += d["SQ_VALU_MFMA_BUSY_CYCLES"]
+        tot_cycles += cycles
+    if d.get("GRBM_GUI_ACTIVE") and d.get("duration_ns_enc_pmc_grbm"):
+        o["effective_clock_GHz_profiled"] = d["GRBM_GUI_ACTIVE"] / 8 / d["duration_ns_enc_pmc_grbm"]
+        o["avg_duration_us"] = d["duration_ns_enc_pmc_grbm"] / d["launches_enc_pmc_grbm"] / 1e3
+    derived_enc[n] = o
+for o in derived_enc.values():
+    if "share_of_encoder_gpu_cycles" in o and tot_cycles:
+        o["share_of_encoder_gpu_cycles"] /= tot_cycles
+if tot_cycles:
+    derived_enc["whole_encoder"] = {"mfma_pipe_busy_fraction": tot_busy / (1024 * tot_cycles)}
+if derived_enc:
+    summary["derived_encoder"] = derived_enc
 json.dump(summary, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
 if "hbm_read_bytes_per_search" in derived:
     json.dump({"hbm_bytes_per_search": derived["hbm_read_bytes_per_search"],
@@ -86,3 +144,4 @@ if "hbm_read_bytes_per_search" in derived:
                        "algorithmic bytes are N*256 = 4.608e9"},
               open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(derived, indent=1))
+print(json.dumps(summary.get('derived_encoder', {}), indent=1))
