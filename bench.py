@@ -188,7 +188,7 @@ def encode_leg(args, device, world, rank):
                      "workload": f"same model, batch {B}, lengths ~U[32,{S}] right-padded to {S}; valid tokens packed"}
     step()   # leave a full-length batch in outs[-1] for the parity check below
 
-    if rank == 0 and not args.skip_cpu:
+    if rank == 0 and world == 1 and not args.skip_cpu:   # CPU baselines: single-GPU runs only (contract)
         from oracle import bert_oracle, bert_torch_cpu
         # parity: the pinned NumPy oracle on 4 passages of the timed batch
         nb = 4
@@ -296,7 +296,7 @@ def main():
                      "frac": small_gbs / PEAK_HBM_GBS, "kernel": "mips_filter_f16<QW=1>",
                      "note": "algorithmic bytes = rows x 256 B per search; ~6.3 TB/s is the measured copy ceiling"}}
 
-    if rank == 0 and not args.skip_cpu:
+    if rank == 0 and world == 1 and not args.skip_cpu:   # CPU baselines: single-GPU runs only (contract)
         # CPU baseline + id parity on a bounded sample of the same workload
         cores = host_cores()
         ns, qs = hi - lo, nq   # rank 0's whole shard: ~10 s of NumPy/BLAS work on 16 usable cores at 18M rows
