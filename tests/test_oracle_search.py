@@ -71,3 +71,20 @@ def test_merge_lists_matches_unsharded():
     D2, I2 = search_oracle.topk_ip(xq, xb, 20)
     np.testing.assert_array_equal(I, I2)
     np.testing.assert_array_equal(D, D2)
+
+
+def test_against_torch_topk_and_threaded_variant():
+    """An independent exact top-k (torch.topk over the float32 score matrix) agrees with the oracle on
+    tie-free data, and the thread-pooled variant bench.py times returns the oracle's result."""
+    import torch
+    rng = np.random.default_rng(99)
+    xb = rng.standard_normal((20000, 128)).astype(np.float16)
+    xq = rng.standard_normal((70, 128)).astype(np.float16)
+    D, I = search_oracle.topk_ip(xq, xb, 80, block_rows=3000, query_block=32)
+    S = torch.from_numpy(xq.astype(np.float32)) @ torch.from_numpy(xb.astype(np.float32)).T
+    Dt, It = torch.topk(S, 80, dim=1, largest=True, sorted=True)
+    np.testing.assert_array_equal(I, It.numpy())
+    np.testing.assert_allclose(D, Dt.numpy(), rtol=1e-6, atol=1e-5)
+    D2, I2 = search_oracle.topk_ip_threaded(xq, xb, 80, workers=3, query_block=16, block_rows=3000)
+    np.testing.assert_array_equal(I2, I)
+    np.testing.assert_array_equal(D2, D)
