@@ -58,3 +58,27 @@ def test_train_decreases_objective_and_subsamples():
     assert c2.shape == (5, 128) and len(obj2) == 3
     D, I, _ = ko.clustering(x, 3, 5, 1000)
     assert D.shape == (600, 1) and I.shape == (600, 1)
+
+
+def test_lloyd_iterations_match_scikit_learn():
+    """Independent implementation of the same Lloyd iteration (no void clusters, same initial
+    centroids): scikit-learn's KMeans lands on the centroids the restated faiss loop produces."""
+    import warnings
+    from sklearn.cluster import KMeans
+    rng = np.random.default_rng(3)
+    k, n, niter = 6, 900, 4
+    centers = 3 * rng.standard_normal((k, 128))
+    x = (centers[rng.integers(0, k, n)] + 0.7 * rng.standard_normal((n, 128))).astype(np.float16)
+    init = (centers + 0.5 * rng.standard_normal((k, 128))).astype(np.float32)   # one start per true cluster
+    c = init.copy()
+    for _ in range(niter):
+        _, a = ko.assign(x, c, True)
+        c, h, nsplit = ko.update_centroids(x, c, a, k)
+        assert nsplit == 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        km = KMeans(n_clusters=k, init=init.astype(np.float64), n_init=1, max_iter=niter, tol=0.0,
+                    algorithm="lloyd").fit(x.astype(np.float64))
+    np.testing.assert_allclose(c, km.cluster_centers_, rtol=1e-4, atol=1e-4)
+    _, a = ko.assign(x, c, True)
+    np.testing.assert_array_equal(a, km.predict(x.astype(np.float64)))
