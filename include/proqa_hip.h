@@ -64,17 +64,26 @@ typedef struct proqa_index proqa_index;
 
 /* d must be 128.  capacity_rows > 0 preallocates HBM for that many rows (avoids regrowth). */
 int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out);
-/* append n rows from host memory (row-major [n, d], dtype PROQA_F16 or PROQA_F32).  F32 input is
- * stored as fp16: it must be exactly representable (true for the float32 upcast of an '<f2' index,
- * retrieval/eval_retrieval.py:99-100); otherwise the call fails with PROQA_EINVAL unless
- * proqa_index_allow_rounding(idx, 1) was called.  The same rule applies to F32 queries.  May be
- * called repeatedly, e.g. once per mmap chunk of para_embed.npy. */
+/* append n rows from host memory (row-major [n, d], dtype PROQA_F16 or PROQA_F32).  May be called
+ * repeatedly, e.g. once per mmap chunk of para_embed.npy.
+ *
+ * Precision.  The scan runs on fp16 rows.  float32 input that is exactly representable in fp16 (the
+ * float32 upcast of an '<f2' index, retrieval/eval_retrieval.py:99-100) is simply stored as fp16.
+ * The first float32 value fp16 cannot hold -- in an added row or in a query -- switches the index to
+ * EXACT-FLOAT32 mode: it keeps a float32 copy of every row next to the fp16 roundings; the fp16 scan
+ * then only nominates rows (its thresholds are lowered by a rigorous bound on the rounding error,
+ * ||q^||.max||x-x^|| + ||q-q^||.max||x^|| + ...), and every nominated row is re-scored from the float32
+ * data (double accumulation, rounded once).  Results are the exact float32 top-k; the scan costs the
+ * same, the merge more.  Values beyond the fp16 range (|x| > 65504) are refused.
+ * proqa_index_allow_rounding(idx, 1) opts out: float32 inputs are rounded to fp16 instead. */
 int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype);
 /* same, source already in HBM (used by the synthetic benchmark and the sharded path) */
 int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int dtype, void* stream);
 /* adopt caller-owned fp16 rows already in HBM without copying; the caller keeps them alive
  * until proqa_index_free/reset */
 int proqa_index_adopt_device(proqa_index* idx, const void* xb_dev_f16, int64_t n);
+/* 1 once the index has switched to exact-float32 mode (see above) */
+int proqa_index_is_exact_f32(const proqa_index* idx, int* enabled);
 int proqa_index_allow_rounding(proqa_index* idx, int allow);
 int proqa_index_ntotal(const proqa_index* idx, int64_t* n);
 int proqa_index_reset(proqa_index* idx);

@@ -139,6 +139,23 @@ def topk_ip_threaded(xq, xb, k, workers=8, query_block=128, block_rows=262144):
     return outD, outI
 
 
+def topk_ip_exact(xq, xb, k):
+    """Order-independent float32 reference for float32 inputs: inner products accumulated in float64
+    (products of two float32 are exact there), rounded once to float32, then the usual top-k rule.
+    A float32 sgemm (faiss, eval_retrieval.py:102-104) returns these scores up to its own summation
+    order, i.e. to ~1e-6 relative; this is what the HIP exact-float32 mode computes bit for bit."""
+    xq = np.asarray(xq, dtype=np.float32)
+    xb = np.asarray(xb, dtype=np.float32)
+    outD = np.full((xq.shape[0], k), NEG_FILL, dtype=np.float32)
+    outI = np.full((xq.shape[0], k), -1, dtype=np.int64)
+    if xq.shape[0] == 0 or xb.shape[0] == 0:
+        return outD, outI
+    S = (xq.astype(np.float64) @ xb.astype(np.float64).T).astype(np.float32)
+    D, I = _topk_rows(S, k)
+    outD[:, :D.shape[1]], outI[:, :I.shape[1]] = D, I
+    return outD, outI
+
+
 def topk_ip_argsort(xq, xb, k):
     """Smallest possible definition (full stable argsort) used to pin topk_ip itself."""
     S = scores_f32(xq, xb)

@@ -51,6 +51,7 @@ SIGNATURES = {
     "proqa_index_add_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "proqa_index_adopt_device": (c_int, [c_void_p, c_void_p, c_int64]),
     "proqa_index_allow_rounding": (c_int, [c_void_p, c_int]),
+    "proqa_index_is_exact_f32": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "proqa_index_ntotal": (c_int, [c_void_p, ctypes.POINTER(c_int64)]),
     "proqa_index_reset": (c_int, [c_void_p]),
     "proqa_index_free": (c_int, [c_void_p]),

@@ -30,8 +30,19 @@ struct Slab {
 struct proqa_index {
   int device = 0;
   // corpus
-  char* xb = nullptr;       // fp16 rows
+  char* xb = nullptr;       // fp16 rows (in exact-float32 mode: the fp16 roundings the filter scans)
   bool owns_xb = true;
+  // exact-float32 mode: float32 inputs fp16 cannot hold keep a float32 copy of every row; the fp16
+  // filter then only nominates rows (threshold lowered by a rigorous error margin) and the merge
+  // re-scores them from xb32
+  bool exact = false;
+  float* xb32 = nullptr;
+  int64_t capacity32 = 0;
+  unsigned* norm_stats = nullptr;          // device: {max ||x - fp16(x)||, max ||fp16(x)||} as float bits
+  float* xq32 = nullptr;                   // workspace [ws_nq_pad,128]
+  float* margin = nullptr;                 // workspace [ws_nq_pad]
+  float* tau_filter = nullptr;             // workspace [ws_nq_pad]
+  float* ub_filter = nullptr;              // workspace [ws_nq_pad]
   int64_t n = 0;
   int64_t capacity = 0;
   // search workspace (grown on demand)
@@ -64,7 +75,7 @@ struct proqa_index {
   hipEvent_t ev_filter[2 * 96] = {};       // per-round brackets, created when profiling is on
   bool profile = false;
   bool allow_rounding = false;             // accept fp32 inputs that are not exactly representable in fp16
-  unsigned* inexact = nullptr;             // device counter of such values (one word)
+  unsigned* inexact = nullptr;             // device counters: {not exact in fp16, beyond the fp16 range}
   // tuning
   int first_slab_rows = 256;
   int growth = 0;                          // 0 = automatic (see growth_for)
@@ -83,16 +94,59 @@ int ensure_device(proqa_index* idx) {
   return PROQA_OK;
 }
 
-// fp32 inputs are stored/searched as fp16: refuse values that would change, unless rounding was allowed
-int check_exact(proqa_index* idx, const char* what, hipStream_t st) {
-  unsigned bad = 0;
-  PROQA_HIP(hipMemcpyAsync(&bad, idx->inexact, sizeof bad, hipMemcpyDeviceToHost, st));
+// counters of the last float32 -> fp16 conversion: {values fp16 cannot hold exactly, values beyond its range}
+int read_inexact(proqa_index* idx, const char* what, hipStream_t st, unsigned* n_inexact) {
+  unsigned c[2] = {0, 0};
+  PROQA_HIP(hipMemcpyAsync(c, idx->inexact, sizeof c, hipMemcpyDeviceToHost, st));
   PROQA_HIP(hipStreamSynchronize(st));
-  if (bad && !idx->allow_rounding)
-    return fail(PROQA_EINVAL,
-                "%s: %u float32 values are not exactly representable in fp16; the index stores fp16 (the --fp16 "
-                ".npy format) and an fp32-exact search is not built — pass fp16-representable data or allow rounding "
-                "(proqa_index_allow_rounding)", what, bad);
+  if (c[1])
+    return fail(PROQA_EINVAL, "%s: %u float32 values exceed the fp16 range (|x| > 65504); such embeddings are not "
+                              "supported", what, c[1]);
+  *n_inexact = c[0];
+  return PROQA_OK;
+}
+
+int reserve_rows32(proqa_index* idx, int64_t rows) {
+  if (rows <= idx->capacity32) return PROQA_OK;
+  int64_t cap = std::max<int64_t>(rows, std::max(idx->capacity, idx->capacity32 + idx->capacity32 / 2));
+  cap = round_up<int64_t>(cap, kStageRows);
+  float* p = nullptr;
+  hipError_t e = hipMalloc((void**)&p, (size_t)cap * kDim * 4);
+  if (e != hipSuccess) return fail(PROQA_ENOMEM, "hipMalloc of %lld float32 index rows failed: %s", (long long)cap,
+                                   hipGetErrorString(e));
+  if (idx->n > 0 && idx->xb32)
+    PROQA_HIP(hipMemcpy(p, idx->xb32, (size_t)idx->n * kDim * 4, hipMemcpyDeviceToDevice));
+  if (idx->xb32) PROQA_HIP(hipFree(idx->xb32));
+  idx->xb32 = p;
+  idx->capacity32 = cap;
+  return PROQA_OK;
+}
+
+// Switch the index to exact-float32 mode: float32 copies of the rows already stored (exact upcasts of
+// their fp16 values) and the norm statistics the error margin is built from.
+int enable_exact(proqa_index* idx, hipStream_t st) {
+  if (idx->exact) return PROQA_OK;
+  PROQA_HIP(hipStreamSynchronize(st));
+  if (!idx->norm_stats) PROQA_HIP(hipMalloc((void**)&idx->norm_stats, 2 * sizeof(unsigned)));
+  PROQA_HIP(hipMemsetAsync(idx->norm_stats, 0, 2 * sizeof(unsigned), st));
+  if (int rc = reserve_rows32(idx, std::max<int64_t>(idx->n, 1))) return rc;
+  PROQA_HIP(launch_upconvert_f16_to_f32(idx->xb, idx->xb32, idx->n * kDim, st));
+  PROQA_HIP(launch_row_norm_stats(idx->xb32, idx->xb, idx->n, idx->norm_stats, st));
+  idx->exact = true;
+  return PROQA_OK;
+}
+
+// rows [r0, r0+m) were just written to xb (fp16); in exact mode give them float32 copies (from
+// `src32` when the caller had float32 data, else exact upcasts) and fold them into the statistics
+int finish_rows_exact(proqa_index* idx, int64_t r0, int64_t m, const float* src32_dev, hipStream_t st) {
+  if (!idx->exact || m == 0) return PROQA_OK;
+  if (int rc = reserve_rows32(idx, r0 + m)) return rc;
+  float* dst = idx->xb32 + (size_t)r0 * kDim;
+  if (src32_dev)
+    PROQA_HIP(hipMemcpyAsync(dst, src32_dev, (size_t)m * kDim * 4, hipMemcpyDeviceToDevice, st));
+  else
+    PROQA_HIP(launch_upconvert_f16_to_f32(idx->xb + (size_t)r0 * kDim * 2, dst, m * kDim, st));
+  PROQA_HIP(launch_row_norm_stats(dst, idx->xb + (size_t)r0 * kDim * 2, m, idx->norm_stats, st));
   return PROQA_OK;
 }
 
@@ -137,7 +191,12 @@ void free_store(proqa_index* idx) {
 }
 
 void free_workspace(proqa_index* idx) {
-  void* ptrs[] = {idx->xq_pad, idx->tau, idx->run_n, idx->run_keys, idx->stat_dev, idx->bound_keys, idx->ub, idx->done};
+  void* ptrs[] = {idx->xq_pad, idx->tau, idx->run_n, idx->run_keys, idx->stat_dev, idx->bound_keys, idx->ub, idx->done,
+                  idx->xq32, idx->margin, idx->tau_filter, idx->ub_filter};
+  idx->xq32 = nullptr;
+  idx->margin = nullptr;
+  idx->tau_filter = nullptr;
+  idx->ub_filter = nullptr;
   idx->bound_keys = nullptr;
   idx->ub = nullptr;
   idx->done = nullptr;
@@ -166,6 +225,10 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
   PROQA_HIP(hipMalloc((void**)&idx->bound_keys, (size_t)q * sizeof(unsigned long long)));
   PROQA_HIP(hipMalloc((void**)&idx->ub, (size_t)q * sizeof(float)));
   PROQA_HIP(hipMalloc((void**)&idx->done, (size_t)q));
+  PROQA_HIP(hipMalloc((void**)&idx->xq32, (size_t)q * kDim * sizeof(float)));
+  PROQA_HIP(hipMalloc((void**)&idx->margin, (size_t)q * sizeof(float)));
+  PROQA_HIP(hipMalloc((void**)&idx->tau_filter, (size_t)q * sizeof(float)));
+  PROQA_HIP(hipMalloc((void**)&idx->ub_filter, (size_t)q * sizeof(float)));
   if (idx->stat_host) PROQA_HIP(hipHostFree(idx->stat_host));
   idx->stat_host = nullptr;
   PROQA_HIP(hipHostMalloc((void**)&idx->stat_host, (size_t)q * sizeof(unsigned long long), hipHostMallocDefault));
@@ -260,8 +323,9 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   fa.slab_row0 = slab.r0;
   fa.slab_row1 = slab.r1;
   fa.rows_per_chunk = g.rows_per_chunk;
-  fa.tau = idx->tau;
-  fa.ub = bounded ? idx->ub : nullptr;
+  // exact-float32 mode: the fp16 filter tests against thresholds moved by the error margin
+  fa.tau = idx->exact ? idx->tau_filter : idx->tau;
+  fa.ub = bounded ? (idx->exact ? idx->ub_filter : idx->ub) : nullptr;
   fa.store = store_of(idx, (unsigned)idx->ws_nq_pad, n_qtiles);
   fa.overflow = overflow_word;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
@@ -280,6 +344,10 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.bound_keys = bounded ? idx->bound_keys : nullptr;
   ma.stat_candidates = idx->stat_dev;
   ma.overflow = overflow_word;
+  ma.xq32 = idx->exact ? idx->xq32 : nullptr;
+  ma.xb32 = idx->exact ? idx->xb32 : nullptr;
+  ma.margin = idx->exact ? idx->margin : nullptr;
+  ma.tau_filter = idx->exact ? idx->tau_filter : nullptr;
   PROQA_HIP(launch_merge(ma, nq_pad, st));
   return PROQA_OK;
 }
@@ -398,15 +466,24 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   for (int p = 0; p < n_pages; ++p) {
     const int page_k = std::min(kPageK, k - p * kPageK);
     const bool check_q = p == 0 && dtype == PROQA_F32;
-    if (check_q) PROQA_HIP(hipMemsetAsync(idx->inexact, 0, sizeof(unsigned), st));
+    if (check_q) PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), st));
     PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
                                   p > 0 ? idx->done : nullptr, p == 0, check_q ? idx->inexact : nullptr, st));
-    if (check_q)
-      if (int rc = check_exact(idx, "index_search (queries)", st)) return rc;
+    if (check_q) {
+      // float32 queries fp16 cannot hold: search exactly (float32 copies of the rows) unless rounding is allowed
+      unsigned bad = 0;
+      if (int rc = read_inexact(idx, "index_search (queries)", st, &bad)) return rc;
+      if (bad && !idx->allow_rounding)
+        if (int rc = enable_exact(idx, st)) return rc;
+    }
+    if (idx->exact)
+      PROQA_HIP(launch_query_margins(xq_dev, dtype, nq, idx->ws_nq_pad, idx->norm_stats, idx->xq32, idx->margin,
+                                     idx->tau, idx->tau_filter, st));
     const PageOut out{D_dev, (long long*)I_dev, idx_offset, k, p * kPageK};
     if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, out, st, &fallback)) return rc;
     if (p + 1 < n_pages)
-      PROQA_HIP(launch_advance_page(idx->run_keys, idx->run_n, nq, page_k, idx->bound_keys, idx->ub, idx->done, st));
+      PROQA_HIP(launch_advance_page(idx->run_keys, idx->run_n, nq, page_k, idx->bound_keys, idx->ub, idx->done,
+                                    idx->exact ? idx->margin : nullptr, idx->exact ? idx->ub_filter : nullptr, st));
   }
   if (n_pages > 1) PROQA_HIP(hipStreamSynchronize(st));  // the last advance_page
 
@@ -435,7 +512,7 @@ int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out) {
   PROQA_HIP(hipGetDevice(&idx->device));
   for (auto& e : idx->ev) PROQA_HIP(hipEventCreate(&e));
   PROQA_HIP(hipMalloc((void**)&idx->overflow, kMaxRounds * sizeof(unsigned)));
-  PROQA_HIP(hipMalloc((void**)&idx->inexact, sizeof(unsigned)));
+  PROQA_HIP(hipMalloc((void**)&idx->inexact, 2 * sizeof(unsigned)));
   PROQA_HIP(hipHostMalloc((void**)&idx->overflow_host, kMaxRounds * sizeof(unsigned), hipHostMallocDefault));
   if (capacity_rows > 0) {
     if (int rc = reserve_rows(idx, capacity_rows)) {
@@ -453,6 +530,8 @@ int proqa_index_free(proqa_index* idx) {
   if (idx->xb && idx->owns_xb) (void)hipFree(idx->xb);
   if (idx->overflow) (void)hipFree(idx->overflow);
   if (idx->inexact) (void)hipFree(idx->inexact);
+  if (idx->xb32) (void)hipFree(idx->xb32);
+  if (idx->norm_stats) (void)hipFree(idx->norm_stats);
   if (idx->overflow_host) (void)hipHostFree(idx->overflow_host);
   if (idx->stat_host) (void)hipHostFree(idx->stat_host);
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
@@ -473,6 +552,7 @@ int proqa_index_reset(proqa_index* idx) {
     idx->owns_xb = true;
   }
   idx->n = 0;
+  idx->exact = false;   // the float32 buffer stays allocated for the next use
   return PROQA_OK;
 }
 
@@ -487,6 +567,12 @@ int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth) {
   if (first_slab_rows < 0 || growth < 0) return fail(PROQA_EINVAL, "index_configure: negative argument");
   if (first_slab_rows) idx->first_slab_rows = first_slab_rows;
   if (growth) idx->growth = growth;
+  return PROQA_OK;
+}
+
+int proqa_index_is_exact_f32(const proqa_index* idx, int* enabled) {
+  if (!idx || !enabled) return fail(PROQA_EINVAL, "index_is_exact_f32: NULL argument");
+  *enabled = idx->exact ? 1 : 0;
   return PROQA_OK;
 }
 
@@ -522,10 +608,14 @@ int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int 
   if (dtype == PROQA_F16) {
     PROQA_HIP(hipMemcpyAsync(dst, xb_dev, (size_t)n * kDim * 2, hipMemcpyDeviceToDevice, st));
   } else {
-    PROQA_HIP(hipMemsetAsync(idx->inexact, 0, sizeof(unsigned), st));
+    PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), st));
     PROQA_HIP(launch_convert_f32_to_f16((const float*)xb_dev, dst, n * kDim, idx->inexact, st));
-    if (int rc = check_exact(idx, "index_add_device", st)) return rc;
+    unsigned bad = 0;
+    if (int rc = read_inexact(idx, "index_add_device", st, &bad)) return rc;
+    if (bad && !idx->allow_rounding)
+      if (int rc = enable_exact(idx, st)) return rc;
   }
+  if (int rc = finish_rows_exact(idx, idx->n, n, dtype == PROQA_F32 ? (const float*)xb_dev : nullptr, st)) return rc;
   PROQA_HIP(hipStreamSynchronize(st));
   idx->n += n;
   return PROQA_OK;
@@ -539,6 +629,7 @@ int proqa_index_adopt_device(proqa_index* idx, const void* xb_dev_f16, int64_t n
   idx->owns_xb = false;
   idx->n = n;
   idx->capacity = n;
+  idx->exact = false;
   return PROQA_OK;
 }
 
@@ -560,10 +651,21 @@ int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype) {
     } else {
       if (int rc = ensure_stage(idx, (size_t)piece * kDim * 4)) return rc;
       PROQA_HIP(hipMemcpy(idx->stage_dev, src, (size_t)m * kDim * 4, hipMemcpyHostToDevice));
-      PROQA_HIP(hipMemsetAsync(idx->inexact, 0, sizeof(unsigned), nullptr));
+      PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), nullptr));
       PROQA_HIP(launch_convert_f32_to_f16((const float*)idx->stage_dev, dst, m * kDim, idx->inexact, nullptr));
-      if (int rc = check_exact(idx, "index_add", nullptr)) return rc;
+      unsigned bad = 0;
+      if (int rc = read_inexact(idx, "index_add", nullptr, &bad)) return rc;
+      if (bad && !idx->allow_rounding && !idx->exact) {
+        // first values fp16 cannot hold: from here on the index keeps float32 copies.  enable_exact covers the
+        // rows counted in idx->n; the pieces of THIS call that were already uploaded are caught up below
+        if (int rc = enable_exact(idx, nullptr)) return rc;
+        if (int rc = finish_rows_exact(idx, idx->n, r0, nullptr, nullptr)) return rc;   // earlier pieces were exact
+      }
     }
+    if (int rc = finish_rows_exact(idx, idx->n + r0, m, dtype == PROQA_F32 ? (const float*)idx->stage_dev : nullptr,
+                                   nullptr))
+      return rc;
+    if (idx->exact) PROQA_HIP(hipDeviceSynchronize());   // stage_dev is reused by the next piece
   }
   idx->n += n;
   return PROQA_OK;

@@ -72,11 +72,20 @@ struct MergeArgs {
   const unsigned long long* bound_keys;  // paged searches: only keys strictly below bound_keys[q] count (or NULL)
   unsigned long long* stat_candidates;  // [nq_pad] candidates merged per query (statistics)
   unsigned* overflow;
+  // exact-float32 mode (all NULL otherwise): the filter ran on the fp16 roundings against
+  // tau_filter = tau - margin; every logged score that passed is re-scored from the float32 rows
+  // (double accumulation, rounded once) and compared with the exact threshold `tau`
+  const float* xq32;             // [nq_pad,128] float32 queries
+  const float* xb32;             // float32 corpus rows of this shard
+  const float* margin;           // [nq_pad] bound on |float32 score - fp16 score| for any row
+  float* tau_filter;             // [nq_pad] threshold of the next filter launch
 };
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);
+// margin/ub_filter: exact-float32 mode (NULL otherwise): ub_filter[q] = ub[q] + margin[q]
 hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
-                               unsigned long long* bound_keys, float* ub, unsigned char* done, hipStream_t st);
+                               unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,
+                               float* ub_filter, hipStream_t st);
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st);
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
@@ -88,5 +97,13 @@ hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* r
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
                               int k, float* D, long long* I, hipStream_t st);
 hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, unsigned* inexact, hipStream_t st);
+// exact-float32 mode helpers
+hipError_t launch_upconvert_f16_to_f32(const void* src, float* dst, long long n, hipStream_t st);
+// norm_stats[0] = max over rows of ||x32 - fp16(x32)||, norm_stats[1] = max ||fp16(x32)|| (float bits, atomicMax)
+hipError_t launch_row_norm_stats(const float* xb32, const void* xb16, long long n_rows, unsigned* norm_stats,
+                                 hipStream_t st);
+// float32 copies of the queries, the per-query error margin, and tau_filter = tau (still +-inf here)
+hipError_t launch_query_margins(const void* xq, int dtype, long long nq, long long nq_pad, const unsigned* norm_stats,
+                                float* xq32, float* margin, const float* tau, float* tau_filter, hipStream_t st);
 
 }  // namespace proqa

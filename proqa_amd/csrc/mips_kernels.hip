@@ -291,9 +291,24 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 // (a rank-select — count the larger keys — was measured slower: its O(n^2) compares are VALU-bound
 // with 8 workgroups resident per CU).  Overflow-safe rounds (inclusive threshold, rows may repeat)
 // additionally drop adjacent duplicates.
+// exact-float32 mode: the fp16 filter must log every row whose float32 score can exceed the exact
+// threshold t: it tests against t - margin (margin bounds |float32 score - fp16 score| for this
+// query over all rows), lowered by a few ulps for the rounding of the subtraction itself
+__device__ __forceinline__ float filter_threshold(float t, float margin) {
+  if (!(t > -__builtin_inff())) return t;  // -inf: everything is a candidate
+  return t - margin - __builtin_fabsf(t) * 0x1p-21f;
+}
+
+// exact-float32 mode: rows the fp16 scan nominated are collected first (nom/n_nom, LDS) and re-scored
+// afterwards by groups of 8 lanes (rescore_nominated)
+struct ExactCtx {
+  unsigned* nom;        // LDS list of nominated shard-local rows, or nullptr in fp16 mode
+  unsigned* n_nom;
+};
+
 __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned q, bool inclusive,
-                                                 unsigned long long bound, unsigned long long* keys,
-                                                 unsigned* n_keys) {
+                                                 unsigned long long bound, const ExactCtx& ex,
+                                                 unsigned long long* keys, unsigned* n_keys) {
   const uint4 h = src[0];
   if (h.x != q) return;  // spill logs mix the wave's queries
   const float tau = __uint_as_float(h.w);
@@ -305,7 +320,13 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if ((inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
-        const unsigned long long key = pack_key(sc[e], h.y + (unsigned)(e + 8 * g));
+        const unsigned row = h.y + (unsigned)(e + 8 * g);
+        if (ex.nom) {  // the fp16 score only nominates the row
+          const unsigned pos = atomicAdd(ex.n_nom, 1u);  // LDS
+          if (pos < (unsigned)kMaxSortKeys) ex.nom[pos] = row;
+          continue;
+        }
+        const unsigned long long key = pack_key(sc[e], row);
         if (key < bound) {  // paged search: ties with the bound score that were already reported
           const unsigned pos = atomicAdd(n_keys, 1u);  // LDS
           if (pos < (unsigned)kMaxSortKeys) keys[pos] = key;
@@ -316,22 +337,37 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
 }
 
 __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
-                                            unsigned long long bound, unsigned long long* keys, unsigned* n_keys) {
+                                            unsigned long long bound, const ExactCtx& ex, unsigned long long* keys,
+                                            unsigned* n_keys) {
   uint4 buf[5];
 #pragma unroll
   for (int g = 0; g < 5; ++g) buf[g] = ((const uint4*)rec)[g];
-  keep_scores_regs(buf, q, inclusive, bound, keys, n_keys);
+  keep_scores_regs(buf, q, inclusive, bound, ex, keys, n_keys);
 }
 
+// EXACT = exact-float32 mode (own instantiation: its LDS list and registers stay out of the fp16 kernel)
+template <bool EXACT>
 __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[kMaxSortKeys];
   __shared__ unsigned short s_lane_cnt[512];   // per (chunk, half) list length of this query
   __shared__ unsigned short s_spill_cnt[256];  // per chunk: records in the spill log of q's wave slot
   __shared__ unsigned s_n_keys;
-
   const unsigned q = blockIdx.x;
   const int tid = threadIdx.x;
   const CandidateStore& st = a.store;
+  ExactCtx ex = {nullptr, nullptr};
+  float* xq32_lds = nullptr;
+  if constexpr (EXACT) {
+    // this query's float32 vector and the rows the fp16 scan nominated
+    __shared__ __attribute__((aligned(16))) float s_xq32[kDim];
+    __shared__ unsigned s_nom[kMaxSortKeys];
+    __shared__ unsigned s_n_nom;
+    if (tid < kDim) s_xq32[tid] = a.xq32[(size_t)q * kDim + tid];   // visible after the first barrier below
+    if (tid == 0) s_n_nom = 0;
+    ex.nom = s_nom;
+    ex.n_nom = &s_n_nom;
+    xq32_lds = s_xq32;
+  }
   const unsigned n_lists = 2 * a.n_chunks;
   const bool inclusive = a.inclusive != 0;
   const unsigned long long bound = a.bound_keys ? a.bound_keys[q] : ~0ull;
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
       if (slot < s_lane_cnt[t]) {
         const unsigned l = base + t;
         const WaveRecord* rec = st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * kLaneCap + slot;
-        keep_scores(rec, q, inclusive, bound, keys, &s_n_keys);
+        keep_scores(rec, q, inclusive, bound, ex, keys, &s_n_keys);
       }
     }
     // spill logs of the wave slot (usually all empty): one wave per non-empty chunk
@@ -374,7 +410,51 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
         const unsigned c = (base >> 1) + t;
         const size_t slot = (size_t)(c * st.n_qtiles + qt) * kFilterWaves + wave;
         for (unsigned i = lane; i < n; i += 64)
-          keep_scores(st.spill_log + slot * kSpillCap + i, q, inclusive, bound, keys, &s_n_keys);
+          keep_scores(st.spill_log + slot * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys);
+      }
+    }
+    __syncthreads();
+  }
+
+  if constexpr (EXACT) {
+    // Re-score the nominated rows from the float32 data: 8 lanes per row, each 4 x 16 bytes of the
+    // 512-byte row; products of two floats are exact in double, the 128 of them are summed in double
+    // and rounded ONCE -- the correctly rounded score, independent of summation order (unlike an sgemm).
+    unsigned n_nom = *ex.n_nom;
+    if (n_nom > (unsigned)kMaxSortKeys) {  // more nominations than the list holds: overflow-safe path
+      if (tid == 0) *a.overflow = 1u;
+      n_nom = kMaxSortKeys;
+    }
+    const float tau_exact = a.tau[q];
+    const int sub = tid & 7;
+    for (unsigned c = tid >> 3; c < ((n_nom + 31u) & ~31u); c += kMergeThreads / 8) {
+      const bool live = c < n_nom;
+      const unsigned row = live ? ex.nom[c] : 0u;
+      double acc = 0.0;
+      if (live) {
+        const f32x4* xr = (const f32x4*)(a.xb32 + (size_t)row * kDim);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 x = xr[sub + 8 * t];
+          const f32x4 qv = ((const f32x4*)xq32_lds)[sub + 8 * t];
+          acc += (double)x[0] * (double)qv[0];
+          acc += (double)x[1] * (double)qv[1];
+          acc += (double)x[2] * (double)qv[2];
+          acc += (double)x[3] * (double)qv[3];
+        }
+      }
+      acc += __shfl_xor(acc, 4, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 1, 64);
+      if (live && sub == 0) {
+        const float score = (float)acc;
+        if (inclusive ? (score >= tau_exact) : (score > tau_exact)) {
+          const unsigned long long key = pack_key(score, row);
+          if (key < bound) {
+            const unsigned pos = atomicAdd(&s_n_keys, 1u);
+            if (pos < (unsigned)kMaxSortKeys) keys[pos] = key;
+          }
+        }
       }
     }
     __syncthreads();
@@ -419,7 +499,11 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
     for (unsigned i = tid; i < keep; i += kMergeThreads) a.run_keys[(size_t)q * a.k + i] = keys[i];
     if (tid == 0) {
       a.run_n[q] = keep;
-      if (keep == (unsigned)a.k) a.tau[q] = float_from_ord((unsigned)(keys[a.k - 1] >> 32));
+      if (keep == (unsigned)a.k) {
+        const float t = float_from_ord((unsigned)(keys[a.k - 1] >> 32));
+        a.tau[q] = t;
+        if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
+      }
       a.stat_candidates[q] += n_seen;
     }
     return;
@@ -434,7 +518,9 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
       keys[out++] = key;  // out <= i: in-place compaction is safe
     }
     a.run_n[q] = out;
-    a.tau[q] = out == (unsigned)a.k ? float_from_ord((unsigned)(keys[a.k - 1] >> 32)) : -__builtin_inff();
+    const float t = out == (unsigned)a.k ? float_from_ord((unsigned)(keys[a.k - 1] >> 32)) : -__builtin_inff();
+    a.tau[q] = t;
+    if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
     a.stat_candidates[q] += n_seen;
     s_n_keys = out;
   }
@@ -458,7 +544,10 @@ __global__ void prep_queries(const void* xq, int dtype, long long nq, long long 
     if (q < nq) v = dtype == PROQA_F16 ? (float)((const _Float16*)xq)[i] : ((const float*)xq)[i];
     const _Float16 hq = (_Float16)v;
     xq_pad[i] = hq;
-    if (inexact && (float)hq != v && v == v) atomicAdd(inexact, 1u);
+    if (inexact && (float)hq != v && v == v) {
+      atomicAdd(inexact, 1u);
+      if (__builtin_isinf((float)hq) && !__builtin_isinf(v)) atomicAdd(inexact + 1, 1u);
+    }
   }
   if (i < nq_pad) {
     // padded queries (and queries a paged search has already exhausted) never log
@@ -489,13 +578,17 @@ __global__ void finalize_topk(const unsigned long long* run_keys, const unsigned
 // after a page of a k > kPageK search: the last reported key bounds the next page; a query whose
 // page came back short has no more rows
 __global__ void advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
-                             unsigned long long* bound_keys, float* ub, unsigned char* done) {
+                             unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,
+                             float* ub_filter) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   if (run_n[q] == (unsigned)page_k && !done[q]) {
     const unsigned long long key = run_keys[q * page_k + page_k - 1];
     bound_keys[q] = key;
-    ub[q] = float_from_ord((unsigned)(key >> 32));
+    const float u = float_from_ord((unsigned)(key >> 32));
+    ub[q] = u;
+    // exact-float32 mode: the filter may only mask fp16 scores whose float32 score is surely above u
+    if (ub_filter) ub_filter[q] = u + margin[q] + __builtin_fabsf(u) * 0x1p-21f;
   } else {
     done[q] = 1;
   }
@@ -506,22 +599,100 @@ __global__ void advance_page(const unsigned long long* run_keys, const unsigned*
 // fp16 .npy to float32 before faiss; such arrays pass) unless the caller allows rounding
 __global__ void convert_rows_f32_to_f16(const float* src, _Float16* dst, long long n, unsigned* inexact) {
   const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  unsigned bad = 0;
+  unsigned bad = 0, big = 0;   // inexact[0]: values fp16 cannot hold exactly; inexact[1]: beyond the fp16 range
   if (i + 3 < n) {
     const f32x4 v = *(const f32x4*)(src + i);
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     f16x4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     *(f16x4*)(dst + i) = o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bad += ((float)o[e] != v[e] && v[e] == v[e]) ? 1u : 0u;
+    for (int e = 0; e < 4; ++e) {
+      bad += ((float)o[e] != v[e] && v[e] == v[e]) ? 1u : 0u;
+      big += (__builtin_isinf((float)o[e]) && !__builtin_isinf(v[e])) ? 1u : 0u;
+    }
   } else {
     for (long long j = i; j < n; ++j) {
       const _Float16 h = (_Float16)src[j];
       dst[j] = h;
       bad += ((float)h != src[j] && src[j] == src[j]) ? 1u : 0u;
+      big += (__builtin_isinf((float)h) && !__builtin_isinf(src[j])) ? 1u : 0u;
     }
   }
-  if (inexact && __any(bad != 0) && bad) atomicAdd(inexact, bad);
+  if (inexact && bad) atomicAdd(inexact, bad);
+  if (inexact && big) atomicAdd(inexact + 1, big);
+}
+
+// ---- exact-float32 mode helpers ----------------------------------------------------------
+__global__ void upconvert_rows_f16_to_f32(const _Float16* __restrict__ src, float* __restrict__ dst, long long n) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i + 7 < n) {
+    const f16x8 v = *(const f16x8*)(src + i);
+    f32x4 lo = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    f32x4 hi = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    *(f32x4*)(dst + i) = lo;
+    *(f32x4*)(dst + i + 4) = hi;
+  } else {
+    for (long long j = i; j < n; ++j) dst[j] = (float)src[j];
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// one wave per row: max over rows of the rounding-error norm and of the rounded row's norm (both are
+// non-negative floats, so their bit patterns order like unsigned integers)
+__global__ __launch_bounds__(256) void row_norm_stats(const float* __restrict__ xb32, const _Float16* __restrict__ xb16,
+                                                      long long n_rows, unsigned* __restrict__ norm_stats) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float x0 = xb32[row * kDim + 2 * lane], x1 = xb32[row * kDim + 2 * lane + 1];
+  const float h0 = (float)xb16[row * kDim + 2 * lane], h1 = (float)xb16[row * kDim + 2 * lane + 1];
+  const float d0 = x0 - h0, d1 = x1 - h1;
+  // rounded up a little: the bound must not be undercut by the rounding of these sums
+  const float err = __builtin_sqrtf(wave_sum(d0 * d0 + d1 * d1)) * (1.0f + 0x1p-10f);
+  const float nrm = __builtin_sqrtf(wave_sum(h0 * h0 + h1 * h1)) * (1.0f + 0x1p-10f);
+  if (lane == 0) {
+    atomicMax(norm_stats + 0, __float_as_uint(err));
+    atomicMax(norm_stats + 1, __float_as_uint(nrm));
+  }
+}
+
+// one wave per query: float32 copy, and margin[q] >= |q.x - fp16(q).fp16(x)| for every row x:
+//   |q.x - qh.xh| <= ||qh|| ||x - xh|| + ||q - qh|| ||xh|| + ||q - qh|| ||x - xh||   (Cauchy-Schwarz)
+// plus the fp32 accumulation error of the filter's MFMA sums (<= 128 * 2^-24 * ||qh|| ||xh||)
+__global__ __launch_bounds__(256) void query_margins(const void* __restrict__ xq, int dtype, long long nq, long long nq_pad,
+                                                     const unsigned* __restrict__ norm_stats, float* __restrict__ xq32,
+                                                     float* __restrict__ margin, const float* __restrict__ tau,
+                                                     float* __restrict__ tau_filter) {
+  const int lane = threadIdx.x & 63;
+  const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq_pad) return;
+  float v0 = 0.f, v1 = 0.f;
+  if (q < nq) {
+    const long long i = q * kDim + 2 * lane;
+    if (dtype == PROQA_F16) {
+      v0 = (float)((const _Float16*)xq)[i];
+      v1 = (float)((const _Float16*)xq)[i + 1];
+    } else {
+      v0 = ((const float*)xq)[i];
+      v1 = ((const float*)xq)[i + 1];
+    }
+  }
+  xq32[q * kDim + 2 * lane] = v0;
+  xq32[q * kDim + 2 * lane + 1] = v1;
+  const float h0 = (float)(_Float16)v0, h1 = (float)(_Float16)v1;
+  const float d0 = v0 - h0, d1 = v1 - h1;
+  const float nh = __builtin_sqrtf(wave_sum(h0 * h0 + h1 * h1)) * (1.0f + 0x1p-10f);
+  const float nd = __builtin_sqrtf(wave_sum(d0 * d0 + d1 * d1)) * (1.0f + 0x1p-10f);
+  if (lane == 0) {
+    const float E = __uint_as_float(norm_stats[0]), X = __uint_as_float(norm_stats[1]);
+    margin[q] = (nh * E + nd * X + nd * E) * (1.0f + 0x1p-10f) + 0x1p-15f * (nh + nd) * (X + E);
+    tau_filter[q] = tau[q];  // -inf (live) or +inf (padding / exhausted): unchanged by the margin
+  }
 }
 
 // Merge per-shard result lists (proqa_topk_merge_device): one workgroup per query sorts the
@@ -648,14 +819,42 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
 }
 
 hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
-                               unsigned long long* bound_keys, float* ub, unsigned char* done, hipStream_t st) {
+                               unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,
+                               float* ub_filter, hipStream_t st) {
   hipLaunchKernelGGL(advance_page, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, run_keys, run_n, nq, page_k,
-                     bound_keys, ub, done);
+                     bound_keys, ub, done, margin, ub_filter);
+  return hipGetLastError();
+}
+
+hipError_t launch_upconvert_f16_to_f32(const void* src, float* dst, long long n, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const long long nthreads = (n + 7) / 8;
+  hipLaunchKernelGGL(upconvert_rows_f16_to_f32, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st,
+                     (const _Float16*)src, dst, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_row_norm_stats(const float* xb32, const void* xb16, long long n_rows, unsigned* norm_stats,
+                                 hipStream_t st) {
+  if (n_rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(row_norm_stats, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, st, xb32,
+                     (const _Float16*)xb16, n_rows, norm_stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_query_margins(const void* xq, int dtype, long long nq, long long nq_pad, const unsigned* norm_stats,
+                                float* xq32, float* margin, const float* tau, float* tau_filter, hipStream_t st) {
+  if (nq_pad == 0) return hipSuccess;
+  hipLaunchKernelGGL(query_margins, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
+                     norm_stats, xq32, margin, tau, tau_filter);
   return hipGetLastError();
 }
 
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
-  hipLaunchKernelGGL(topk_merge, dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+  if (a.xq32)
+    hipLaunchKernelGGL(topk_merge<true>, dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL(topk_merge<false>, dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   return hipGetLastError();
 }
 

@@ -82,8 +82,9 @@ def convert_idx2id(idxs, mapping_path=DEFAULT_IDX_ID):
 def search(indexpath, query_embed, topk, chunk_rows=1 << 21, allow_rounding=False):
     """np.load + IndexFlatIP.add + search of the reference, on the GPU (index streamed from an mmap).
 
-    float32 .npy files (written without --fp16) are refused unless every value is fp16-representable
-    or allow_rounding is set: the index lives in HBM as fp16."""
+    fp16 .npy files (get_embed.py --fp16) are scanned as they are.  float32 files whose values fp16
+    cannot hold are searched in exact-float32 mode (float32 copies of the rows in HBM, fp16 scan +
+    exact re-scoring) unless allow_rounding asks for the rounded, faster variant."""
     from . import npy
     from .index import IndexFlatIP
     xq = npy.load(query_embed)
@@ -110,7 +111,7 @@ def build_parser():
     parser.add_argument("--idx-id-map", type=str, default=DEFAULT_IDX_ID,
                         help="idx_id.json (the reference reads ../pretrained_models/idx_id.json)")
     parser.add_argument("--allow-fp16-rounding", action="store_true",
-                        help="accept float32 embeddings that are not exactly representable in fp16 (rounded)")
+                        help="round float32 embeddings to fp16 instead of searching them in exact-float32 mode")
     return parser
 
 

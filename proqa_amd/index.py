@@ -142,9 +142,18 @@ class IndexFlatIP:
     def set_profiling(self, enable=True):
         _lib.check(self._lib.proqa_index_set_profiling(self._h, 1 if enable else 0))
 
+    @property
+    def exact_f32(self):
+        """True once a float32 row or query that fp16 cannot hold has switched the index to
+        exact-float32 mode (float32 copies of the rows, fp16 scan + exact re-scoring)."""
+        v = ctypes.c_int(0)
+        _lib.check(self._lib.proqa_index_is_exact_f32(self._h, ctypes.byref(v)))
+        return bool(v.value)
+
     def allow_rounding(self, allow=True):
-        """Accept float32 inputs that are not exactly representable in fp16 (they are rounded).  Off by
-        default: the reference searches float32, so silently rounding would change its results."""
+        """Round float32 inputs to fp16 instead of switching to exact-float32 mode (faster merge, half
+        the memory; results are then those of the rounded vectors).  Off by default: the reference
+        searches float32."""
         _lib.check(self._lib.proqa_index_allow_rounding(self._h, 1 if allow else 0))
 
     def configure(self, first_slab_rows=0, growth=0):

@@ -116,32 +116,151 @@ def test_f32_inputs_and_incremental_add(gpu_device):
     assert index.ntotal == 0
 
 
-def test_inexact_f32_is_refused_unless_allowed(gpu_device):
-    """The index stores fp16: float32 values that would change are an error, not a silent rounding."""
+def _f32_corpus(rng, n, scale=1.0):
+    """float32 rows fp16 cannot hold: integers up to 2500 (odd values above 2048 are not fp16 numbers) --
+    with small-integer-like queries every float64 partial sum is exact, so scores are order-independent."""
+    return (rng.integers(-2500, 2501, (n, 128)) * scale).astype(np.float32)
+
+
+def test_exact_float32_mode_matches_float64_oracle(gpu_device):
+    """float32 inputs that are not fp16 numbers are searched exactly: fp16 scan with an error-bounded
+    threshold + re-scoring from the float32 rows (never a silent rounding)."""
     import torch
     from proqa_amd.index import IndexFlatIP
     rng = np.random.default_rng(5)
-    xb = rng.standard_normal((700, 128)).astype(np.float32)       # not fp16-representable
-    xq = rng.standard_normal((9, 128)).astype(np.float32)
+    xb = _f32_corpus(rng, 30000)
+    xq = (rng.integers(-3, 4, (70, 128)) * (1.0 + 2.0 ** -12)).astype(np.float32)    # not fp16 numbers either
     index = IndexFlatIP(128)
-    with pytest.raises(RuntimeError, match="not exactly representable"):
+    index.add(xb[:10000].astype(np.float16).astype(np.float32))     # fp16-exact float32: still fp16 mode
+    assert not index.exact_f32
+    index.reset()
+    index.add(xb[:10000])                                            # host path, switches on the first piece
+    assert index.exact_f32 and index.ntotal == 10000
+    index.add(torch.from_numpy(xb[10000:20000]).to(gpu_device))      # device path
+    index.add(xb[20000:].astype(np.float16))                         # fp16 rows into an exact index
+    ref_rows = np.concatenate([xb[:20000], xb[20000:].astype(np.float16).astype(np.float32)])
+    for k in (1, 80, 300):
+        D, I = index.search(xq, k)
+        Do, Io = search_oracle.topk_ip_exact(xq, ref_rows, k)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
+    assert index.last_stats()["fallback_rounds"] == 0
+    # the rounded (fp16) answer differs: the exact mode is not a no-op on this data
+    Dr, Ir = search_oracle.topk_ip(xq.astype(np.float16), ref_rows.astype(np.float16), 80)
+    D, I = index.search(xq, 80)
+    assert (Ir != I).any()
+    # reset returns to fp16 mode; rounding on request gives exactly the rounded answer
+    index.reset()
+    assert not index.exact_f32
+    index.allow_rounding(True)
+    index.add(ref_rows)
+    assert not index.exact_f32
+    D, I = index.search(xq, 80)
+    np.testing.assert_array_equal(I, Ir)
+    np.testing.assert_array_equal(D, Dr)
+
+
+def test_exact_float32_mode_random_data_and_query_switch(gpu_device):
+    """Random float32: ids equal the float64-accumulated oracle; an fp16 index switches when a query needs it."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(6)
+    xb = rng.standard_normal((120000, 128)).astype(np.float32)
+    xq = rng.standard_normal((300, 128)).astype(np.float32)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    assert index.exact_f32
+    D, I = index.search(xq, 80)
+    Do, Io = search_oracle.topk_ip_exact(xq, xb, 80)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    # the float32-sgemm statement of the reference agrees to its own summation error
+    Ds, Is = search_oracle.topk_ip(xq, xb, 80)
+    assert (Is == I).mean() > 0.999
+    np.testing.assert_allclose(Ds, D, rtol=2e-6, atol=2e-5)
+    # fp16 rows, float32 queries that are not fp16 numbers: the index switches at search time
+    index2 = IndexFlatIP(128)
+    xb16 = xb[:50000].astype(np.float16)
+    index2.add(torch.from_numpy(xb16).to(gpu_device))
+    assert not index2.exact_f32
+    D2, I2 = index2.search(xq, 10)
+    assert index2.exact_f32
+    Do2, Io2 = search_oracle.topk_ip_exact(xq, xb16.astype(np.float32), 10)
+    np.testing.assert_array_equal(I2, Io2)
+    np.testing.assert_array_equal(D2, Do2)
+
+
+def test_exact_float32_mode_under_overflow_and_pages(gpu_device):
+    """Rows that differ only below fp16 resolution: every row is inside the error margin, the lane lists
+    overflow and the overflow-safe path must still order by the float32 values; plus k > 1024 (pages)."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(8)
+    n = 150000
+    xb = np.ones((n, 128), np.float32)
+    # two coordinates perturbed below half an fp16 ulp: EVERY row rounds to the same fp16 vector
+    xb[:, 0] = 1.0 + rng.integers(0, 2048, n).astype(np.float32) * 2.0 ** -23
+    xb[:, 1] = 1.0 + rng.integers(0, 2048, n).astype(np.float32) * 2.0 ** -23
+    xq = np.zeros((300, 128), np.float32)       # enough active lanes per wave to exhaust lists + spill
+    xq[:, 0] = rng.choice([1.0, 2.0, 0.5, 1.0 + 2.0 ** -12, 3.0], 300)
+    xq[:, 1] = rng.choice([1.0, 0.25, 1.5], 300)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    assert index.exact_f32
+    D, I = index.search(xq, 100)
+    Do, Io = search_oracle.topk_ip_exact(xq, xb, 100)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert index.last_stats()["fallback_rounds"] > 0
+    # pages: k = 2500 over a float32 corpus fp16 cannot hold
+    xb2 = _f32_corpus(rng, 9000)
+    xq2 = rng.integers(-3, 4, (6, 128)).astype(np.float32)
+    index.reset()
+    index.add(xb2)
+    D, I = index.search(xq2, 2500)
+    Do, Io = search_oracle.topk_ip_exact(xq2, xb2, 2500)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+
+
+def test_exact_float32_shards_and_npy_index(gpu_device, tmp_path):
+    """Exact-float32 mode through the two ways an index arrives: row shards merged on the GPU, and a
+    '<f4' .npy file through eval_retrieval.search (the reference upcasts whatever it loads to float32)."""
+    import torch
+    from proqa_amd import npy
+    from proqa_amd.eval_retrieval import search
+    from proqa_amd.index import IndexFlatIP, merge_topk_device
+    rng = np.random.default_rng(12)
+    xb = _f32_corpus(rng, 7000)
+    xq = rng.integers(-3, 4, (40, 128)).astype(np.float32)
+    Do, Io = search_oracle.topk_ip_exact(xq, xb, 80)
+    tq = torch.from_numpy(xq).to(gpu_device)
+    parts = []
+    for lo, hi in [(0, 3000), (3000, 7000)]:
+        ix = IndexFlatIP(128)
+        ix.add(torch.from_numpy(xb[lo:hi]).to(gpu_device))
+        assert ix.exact_f32
+        parts.append(ix.search_device(tq, 80, idx_offset=lo))
+    D, I = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do)
+    np.save(tmp_path / "index.npy", xb)
+    np.save(tmp_path / "query.npy", xq)
+    D, I = search(str(tmp_path / "index.npy"), str(tmp_path / "query.npy"), 80, chunk_rows=2048)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    Dr, Ir = search(str(tmp_path / "index.npy"), str(tmp_path / "query.npy"), 80, allow_rounding=True)
+    Dh, Ih = search_oracle.topk_ip(xq.astype(np.float16), xb.astype(np.float16), 80)
+    np.testing.assert_array_equal(Ir, Ih)
+
+
+def test_values_beyond_fp16_range_are_refused(gpu_device):
+    from proqa_amd.index import IndexFlatIP
+    xb = np.ones((300, 128), np.float32)
+    xb[7, 3] = 1.0e6
+    index = IndexFlatIP(128)
+    with pytest.raises(RuntimeError, match="exceed the fp16 range"):
         index.add(xb)
     assert index.ntotal == 0
-    with pytest.raises(RuntimeError, match="not exactly representable"):
-        index.add(torch.from_numpy(xb).to(gpu_device))
-    assert index.ntotal == 0
-    index.add(xb.astype(np.float16))
-    with pytest.raises(RuntimeError, match="not exactly representable"):
-        index.search(xq, 5)
-    nanq = xq.astype(np.float16).astype(np.float32)
-    index.search(nanq, 5)                                          # exact float32 queries are fine
-    index.reset()
-    index.allow_rounding(True)
-    index.add(xb)
-    D, I = index.search(xq, 5)
-    Do, Io = search_oracle.topk_ip(xq.astype(np.float16), xb.astype(np.float16), 5)
-    np.testing.assert_array_equal(I, Io)
-    np.testing.assert_allclose(D, Do, rtol=2e-6, atol=2e-5)      # fp32 summation order only
 
 
 def test_device_search_offsets_and_merge(gpu_device):
