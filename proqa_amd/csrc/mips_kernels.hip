@@ -690,7 +690,10 @@ __global__ __launch_bounds__(256) void query_margins(const void* __restrict__ xq
   const float nd = __builtin_sqrtf(wave_sum(d0 * d0 + d1 * d1)) * (1.0f + 0x1p-10f);
   if (lane == 0) {
     const float E = __uint_as_float(norm_stats[0]), X = __uint_as_float(norm_stats[1]);
-    margin[q] = (nh * E + nd * X + nd * E) * (1.0f + 0x1p-10f) + 0x1p-15f * (nh + nd) * (X + E);
+    // last term: should the matrix cores flush fp16 subnormal operands (|v| < 2^-14) to zero, each of
+    // the 128 products loses at most 2^-14 times the other factor: <= sqrt(128) 2^-14 (||q^|| + ||x^||)
+    margin[q] = (nh * E + nd * X + nd * E) * (1.0f + 0x1p-10f) + 0x1p-15f * (nh + nd) * (X + E) +
+                11.32f * 0x1p-14f * (nh + X);
     tau_filter[q] = tau[q];  // -inf (live) or +inf (padding / exhausted): unchanged by the margin
   }
 }
