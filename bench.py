@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--encode-batch", type=int, default=512)
     p.add_argument("--seq-len", type=int, default=128)
     p.add_argument("--skip-encode", action="store_true")
+    p.add_argument("--skip-float32", action="store_true", help="skip the exact-float32 index leg")
     p.add_argument("--skip-cpu", action="store_true")
     return p.parse_args()
 
@@ -116,6 +117,47 @@ def cpu_search_baseline(xb_sample, xq_sample, k, rows_total, cores):
     dt = time.perf_counter() - t0
     qps_sample = xq.shape[0] / dt
     return qps_sample * (xb.shape[0] / rows_total), dt, Do, Io
+
+
+def float32_leg(args, device, world, rank, lo, hi):
+    """The same search over the UNROUNDED float32 corpus/queries (an '<f4' index, eval_retrieval.py:99-104):
+    values fp16 cannot hold put the index in exact-float32 mode (fp16 scan + float32 re-scoring)."""
+    from proqa_amd.index import ShardedIndexFlatIP
+    n, nq, k = args.rows, args.queries, args.topk
+    sharded = ShardedIndexFlatIP(n)
+    g = torch.Generator(device=device)
+    c0, c1 = lo // GEN_CHUNK, (hi + GEN_CHUNK - 1) // GEN_CHUNK
+    for c in range(c0, c1):
+        g.manual_seed(1000 + c)
+        chunk = torch.randn((GEN_CHUNK, D), generator=g, device=device, dtype=torch.float32)
+        a, b = max(lo, c * GEN_CHUNK), min(hi, (c + 1) * GEN_CHUNK)
+        sharded.add_local(chunk[a - c * GEN_CHUNK:b - c * GEN_CHUNK].contiguous())
+    g.manual_seed(1)
+    xq = torch.randn((nq, D), generator=g, device=device, dtype=torch.float32)
+    result = {}
+
+    def step():
+        result["DI"] = sharded.search(xq, k)
+
+    steps = max(3, args.steps // 4)
+    dt = timed(step, steps, 1, world, device)
+    out = {"metric": "queries/sec top-%d over a float32 index (exact-float32 mode)" % k, "value": nq * steps / dt,
+           "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f16 scan + f32 rows, f64 re-scoring",
+           "exact_f32": bool(sharded.local_index.exact_f32), "fallback_rounds": sharded.local_index.last_stats()["fallback_rounds"]}
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        from oracle import search_oracle
+        ns, qs = min(GEN_CHUNK, hi - lo), 64        # float64-accumulated oracle on the first chunk of the same rows
+        from proqa_amd.index import IndexFlatIP
+        ix = IndexFlatIP(128)
+        g.manual_seed(1000)
+        rows = torch.randn((GEN_CHUNK, D), generator=g, device=device, dtype=torch.float32)[:ns].contiguous()
+        ix.add(rows)
+        Dg, Ig = ix.search_device(xq[:qs], k)
+        Do, Io = search_oracle.topk_ip_exact(xq[:qs].cpu().numpy(), rows.cpu().numpy(), k)
+        out["parity"] = {"sample": f"{qs} q x {ns} float32 rows vs the float64-accumulated oracle",
+                         "ids_identical": bool((Ig.cpu().numpy() == Io).all()),
+                         "scores_identical": bool((Dg.cpu().numpy() == Do).all())}
+    return out
 
 
 def encode_leg(args, device, world, rank):
@@ -315,8 +357,11 @@ def main():
     if world > 1:
         dist.barrier()
 
+    del sharded, xb
+    torch.cuda.empty_cache()
+    if not args.skip_float32:
+        line["float32_index"] = float32_leg(args, device, world, rank, lo, hi)
     if not args.skip_encode:
-        del sharded, xb
         torch.cuda.empty_cache()
         enc = encode_leg(args, device, world, rank)
         line["encode"] = enc
