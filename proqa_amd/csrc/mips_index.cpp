@@ -87,6 +87,12 @@ namespace {
 
 constexpr int kMaxRounds = 96;
 
+// developer switches, read once: PROQA_DEBUG_CAND prints the cumulative candidate count after every
+// round (adds a host sync per round), PROQA_DEBUG_ROUNDS prints per-round filter times when profiling
+bool debug_flag(const char* name) { return getenv(name) != nullptr; }
+const bool kDebugCand = debug_flag("PROQA_DEBUG_CAND");
+const bool kDebugRounds = debug_flag("PROQA_DEBUG_ROUNDS");
+
 int ensure_device(proqa_index* idx) {
   int dev = 0;
   PROQA_HIP(hipGetDevice(&dev));
@@ -378,7 +384,7 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
     if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, page_k, false, dense, bounded,
                            idx->overflow + r, st, f0, f1))
       return rc;
-    if (getenv("PROQA_DEBUG_CAND")) {
+    if (kDebugCand) {
       (void)hipStreamSynchronize(st);
       (void)hipMemcpy(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       unsigned long long c = 0;
@@ -428,7 +434,7 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
       sum += ms;
     }
     idx->stats.filter_ms = sum;
-    if (getenv("PROQA_DEBUG_ROUNDS")) {
+    if (kDebugRounds) {
       for (size_t r = 0; r < slabs.size(); ++r) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, idx->ev_filter[2 * r], idx->ev_filter[2 * r + 1]);

@@ -19,7 +19,6 @@ constexpr int kMaxSortKeys = 2048;  // running list + candidates of one query pe
 constexpr int kPageK = kMaxSortKeys / 2;  // results per page; k > kPageK is served page by page
 constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling
 constexpr int kSpillCap = 256;      // shared spill records per (chunk, wave)
-constexpr int kMaxListParts = 4096; // n_parts * k bound of proqa_topk_merge_device
 
 // One lane's 16-score accumulator column that beat its query's threshold.  The filter kernel
 // logs whole columns (one 80-byte store burst, no per-score work in the MFMA loop); the merge

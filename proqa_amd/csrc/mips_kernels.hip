@@ -861,13 +861,17 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   return hipGetLastError();
 }
 
+// developer switch, read once: PROQA_DEBUG_NOHIT keeps every threshold at +inf so that the filter never
+// logs a candidate (measures the pure scan)
+static const bool kDebugNoHit = getenv("PROQA_DEBUG_NOHIT") != nullptr;
+
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
                                bool reset_stat, unsigned* inexact, hipStream_t st) {
   const long long n = nq_pad * kDim;
   hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
                      (_Float16*)xq_pad, tau, run_n, stat, done, reset_stat ? 1 : 0, inexact,
-                     getenv("PROQA_DEBUG_NOHIT") ? 1 : 0);
+                     kDebugNoHit ? 1 : 0);
   return hipGetLastError();
 }
 
