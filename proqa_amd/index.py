@@ -258,7 +258,10 @@ class ShardedIndexFlatIP:
         n_i, n_d = I.numel() * 8, D.numel() * 4
         mine = torch.cat([I.contiguous().view(torch.uint8).reshape(-1), D.contiguous().view(torch.uint8).reshape(-1)])
         gathered = torch.empty((self.world_size, n_i + n_d), dtype=torch.uint8, device=D.device)
-        self.dist.all_gather(list(gathered.unbind(0)), mine, group=self.group)
+        if self.dist.get_backend(self.group) == "nccl":     # RCCL: one flat collective, no staging copies
+            self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        else:                                                # gloo (CPU tests, two ranks on one GPU)
+            self.dist.all_gather(list(gathered.unbind(0)), mine, group=self.group)
         I_all = gathered[:, :n_i].contiguous().view(torch.int64).reshape((self.world_size,) + tuple(I.shape))
         D_all = gathered[:, n_i:].contiguous().view(torch.float32).reshape((self.world_size,) + tuple(D.shape))
         return self._merge(D_all, I_all)
