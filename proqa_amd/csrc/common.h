@@ -44,4 +44,15 @@ inline T round_up(T a, T b) {
 // number of compute units of the current device (256 on MI355X); cached
 int device_cu_count();
 
+#if defined(__HIPCC__)
+// Barrier that publishes LDS-DMA'd data.  `global_load_lds` completion is tracked by vmcnt only, and
+// hipcc does NOT reliably drain vmcnt at __syncthreads() (observed: `s_waitcnt lgkmcnt(0); s_barrier`
+// inside a loop), so a stage could be read before its DMA had landed -- rare, data-dependent garbage.
+// Every barrier that makes a DMA'd LDS stage readable goes through this.
+__device__ __forceinline__ void dma_wait_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+#endif
+
 }  // namespace proqa

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
 
   issue_stage(0);
   for (int s = 0; s < nstages; ++s) {
-    __syncthreads();  // stage s landed (vmcnt 0), every wave left the other buffer
+    dma_wait_barrier();  // stage s landed (explicit vmcnt 0), every wave left the other buffer
     if (s + 1 < nstages) issue_stage(s + 1);
     const char* buf = lds + (s & 1) * kStageBytesKm;
 #pragma unroll

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "common.h"
 #include "mips_kernels.h"
 
 namespace proqa {
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
   int off0 = 0, off1 = kStageBytes, off2 = 2 * kStageBytes;
   issue_stage(0, off0);
   if (nstages > 1) issue_stage(1, off1);
-  __syncthreads();  // prologue only: both stages landed
+  dma_wait_barrier();  // prologue only: both stages landed
 
   f16x8 af[8];
 #pragma unroll
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 #pragma unroll
     for (int u = 0; u < kSubs; ++u) {
       if (u == 2) {
-        __syncthreads();
+        dma_wait_barrier();  // explicit vmcnt(0): this wave's pieces of DMA(s+1) have landed
         if (s + 2 < nstages) issue_stage(s + 2, off2);
       }
       // where the next unit's fragments live (next stage's buffer after the last unit)

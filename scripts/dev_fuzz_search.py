@@ -1,0 +1,68 @@
+"""Randomised parity fuzz of the HIP search against the NumPy oracles (dev; run on the MI355X).
+usage: python scripts/dev_fuzz_search.py [seconds] [seed]"""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from oracle import search_oracle
+from proqa_amd.index import IndexFlatIP, merge_topk_device
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+dev = torch.device("cuda", 0)
+t_end = time.time() + budget
+n_cases = 0
+while time.time() < t_end:
+    n = int(rng.choice([1, 7, 100, 129, 1000, 5000, 20000, 70000, 200000]))
+    nq = int(rng.choice([1, 3, 31, 32, 33, 200, 256, 257, 600]))
+    k = int(rng.choice([1, 2, 5, 80, 100, 640, 1024, 1025, 1500, 3000]))
+    kind = rng.choice(["int", "int_narrow", "sorted", "const", "f32_int", "f32_dense_band"])
+    shards = int(rng.choice([1, 1, 2, 3]))
+    if kind == "int":
+        xb = rng.integers(-4, 5, (n, 128)).astype(np.float16); xq = rng.integers(-4, 5, (nq, 128)).astype(np.float16)
+    elif kind == "int_narrow":                      # massive ties
+        xb = rng.integers(0, 2, (n, 128)).astype(np.float16); xq = rng.integers(0, 2, (nq, 128)).astype(np.float16)
+    elif kind == "sorted":                          # adversarial order: scores increase with the row index
+        xb = rng.integers(-1, 2, (n, 128)).astype(np.float16); xb[:, 0] = np.minimum(np.arange(n) // 7, 2000)
+        xq = rng.integers(0, 2, (nq, 128)).astype(np.float16); xq[:, 0] = 1
+    elif kind == "const":
+        xb = np.ones((n, 128), np.float16); xq = np.ones((nq, 128), np.float16)
+    elif kind == "f32_int":                         # exact-float32 mode
+        xb = rng.integers(-2500, 2501, (n, 128)).astype(np.float32); xq = rng.integers(-3, 4, (nq, 128)).astype(np.float32)
+    else:                                           # every row inside the fp16 error band
+        xb = np.ones((n, 128), np.float32); xb[:, 0] = 1 + rng.integers(0, 2048, n) * 2.0 ** -23
+        xb[:, 1] = 1 + rng.integers(0, 2048, n) * 2.0 ** -23
+        xq = np.zeros((nq, 128), np.float32); xq[:, 0] = rng.choice([1.0, 2.0, 0.5], nq); xq[:, 1] = 1
+    exact = xb.dtype == np.float32
+    if exact and n * nq > 3e7:
+        nq = max(1, int(3e7 // n))
+        xq = xq[:nq]
+    if n * nq * 8 > 2.5e9:
+        continue
+    oracle = search_oracle.topk_ip_exact if exact else search_oracle.topk_ip
+    Do, Io = oracle(xq, xb, k)
+    tq = torch.from_numpy(xq).to(dev)
+    bounds = np.linspace(0, n, shards + 1).astype(int)
+    parts = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ix = IndexFlatIP(128)
+        if hi > lo:
+            if rng.random() < 0.5:
+                ix.add(xb[lo:hi])
+            else:
+                ix.add(torch.from_numpy(xb[lo:hi]).to(dev))
+        parts.append(ix.search_device(tq, k, idx_offset=int(lo)))
+    if shards == 1:
+        D, I = parts[0]
+    else:
+        D, I = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    ok = (I == Io).all() and (D == Do).all()
+    n_cases += 1
+    if not ok:
+        bad = np.argwhere(I != Io)
+        print(f"MISMATCH n={n} nq={nq} k={k} kind={kind} shards={shards} seed={seed} case={n_cases}: first at {bad[:3].tolist()}")
+        print(I[bad[0][0]][:12], Io[bad[0][0]][:12], D[bad[0][0]][:6], Do[bad[0][0]][:6])
+        sys.exit(1)
+print(f"fuzz ok: {n_cases} cases in {budget:.0f} s (seed {seed})")

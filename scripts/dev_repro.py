@@ -1,0 +1,24 @@
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from oracle import search_oracle
+from proqa_amd.index import IndexFlatIP
+dev = torch.device("cuda", 0)
+bad = {"plain": 0, "sync": 0, "sleep": 0, "copy": 0}
+for seed in range(12):
+    rng = np.random.default_rng(seed)
+    n, nq, k = 200000, 3, 80
+    xb = rng.integers(-4, 5, (n, 128)).astype(np.float16); xq = rng.integers(-4, 5, (nq, 128)).astype(np.float16)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    for mode in bad:
+        ix = IndexFlatIP(128)
+        src = xb.copy() if mode == "copy" else xb
+        ix.add(src)
+        if mode == "sync":
+            torch.cuda.synchronize()
+        if mode == "sleep":
+            time.sleep(0.2)
+        D, I = ix.search(xq, k)
+        ok = (I == Io).all() and (D == Do).all()
+        bad[mode] += 0 if ok else 1
+print(bad)

@@ -1,4 +1,6 @@
 """Parity of the HIP exhaustive top-k search against the NumPy oracle (through the C ABI)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -251,6 +253,19 @@ def test_exact_float32_shards_and_npy_index(gpu_device, tmp_path):
     Dr, Ir = search(str(tmp_path / "index.npy"), str(tmp_path / "query.npy"), 80, allow_rounding=True)
     Dh, Ih = search_oracle.topk_ip(xq.astype(np.float16), xb.astype(np.float16), 80)
     np.testing.assert_array_equal(Ir, Ih)
+
+
+def test_randomised_parity_fuzz(gpu_device):
+    """25 s of scripts/dev_fuzz_search.py: random sizes / batch sizes / k (pages) / tie-heavy, adversarially
+    ordered and float32 corpora / host and device adds / shards, each bit-exact against the oracle.
+    (This fuzz is what exposed a missing vmcnt wait before the LDS-DMA barrier of the filter kernel:
+    cold-cache host uploads + small batches read a stage before it had landed.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_fuzz_search.py"), "25", "7"],
+                         capture_output=True, text=True, cwd=root, timeout=600)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_values_beyond_fp16_range_are_refused(gpu_device):
