@@ -294,7 +294,7 @@ class BertForRetriever:
                 if packed:
                     torch.index_select(h, 0, cu[:-1], out=dst)
                 else:
-                    dst.copy_(h.view(B, S, H)[:, 0])
+                    dst.copy_(h[:B * S].view(B, S, H)[:, 0])   # h may carry GEMM-tile padding rows
 
             if self.cls_only_last_layer:
                 # the pooler reads h[:, 0] only (retriever.py:41-42): the last layer needs K and V of every

@@ -318,3 +318,37 @@ def test_rejects_bad_inputs(gpu_device):
     empty = model.get_embed({"input_ids": torch.zeros((0, 4), dtype=torch.long, device=gpu_device),
                              "input_mask": torch.zeros((0, 4), dtype=torch.bool, device=gpu_device)}, True)["embed"]
     assert empty.shape == (0, 128)
+
+
+def test_ragged_full_length_batch(gpu_device):
+    """A last batch whose B*S is no multiple of the GEMM row tile, all sequences at full length (padded
+    layout): the [CLS] gather must skip the tile-padding rows of the workspace."""
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
+    import copy
+    cfg = copy.copy(BERT_BASE)
+    cfg.num_hidden_layers = 1
+    sd = {k: v.half().float() for k, v in random_state_dict(cfg, seed=2).items()}
+    model = BertForRetriever(cfg, device=gpu_device)
+    model.load_state_dict(sd)
+    rng = np.random.default_rng(1)
+    B, S = 39, 128                                   # 4992 rows -> 5120 with tile padding
+    ids = rng.integers(1000, 30522, (B, S))
+    mask = np.ones((B, S), bool)
+    batch = {"input_ids": torch.from_numpy(ids).to(gpu_device), "input_mask": torch.from_numpy(mask).to(gpu_device)}
+    ref = bert_oracle.get_embed({k: v.numpy() for k, v in sd.items()}, ids, mask, False, 1, 12)
+    for cls_only in (True, False):
+        model.cls_only_last_layer = cls_only
+        got = model.get_embed(batch, False)["embed"].float().cpu().numpy()
+        assert np.abs(got - ref).max() < 1e-2
+
+
+def test_randomised_encoder_fuzz(gpu_device):
+    """20 s of scripts/dev_fuzz_encoder.py: random model widths / depths / batch shapes / lengths, both
+    towers, packed and padded layouts, [CLS]-only and every-token last layer, against the NumPy oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_fuzz_encoder.py"), "20", "11"],
+                         capture_output=True, text=True, cwd=root, timeout=600)
+    assert out.returncode == 0 and "encoder fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
