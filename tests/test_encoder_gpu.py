@@ -323,10 +323,8 @@ def test_rejects_bad_inputs(gpu_device):
 def test_ragged_full_length_batch(gpu_device):
     """A last batch whose B*S is no multiple of the GEMM row tile, all sequences at full length (padded
     layout): the [CLS] gather must skip the tile-padding rows of the workspace."""
-    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
-    import copy
-    cfg = copy.copy(BERT_BASE)
-    cfg.num_hidden_layers = 1
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE, config_from_dict
+    cfg = config_from_dict(dict(BERT_BASE, num_hidden_layers=1))
     sd = {k: v.half().float() for k, v in random_state_dict(cfg, seed=2).items()}
     model = BertForRetriever(cfg, device=gpu_device)
     model.load_state_dict(sd)
