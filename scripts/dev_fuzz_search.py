@@ -9,13 +9,18 @@ from proqa_amd.index import IndexFlatIP, merge_topk_device
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+large = len(sys.argv) > 3 and sys.argv[3] == "large"     # fewer, bigger cases (multi-tile batches, millions of rows)
 rng = np.random.default_rng(seed)
 dev = torch.device("cuda", 0)
 t_end = time.time() + budget
 n_cases = 0
 while time.time() < t_end:
-    n = int(rng.choice([1, 7, 100, 129, 1000, 5000, 20000, 70000, 200000]))
-    nq = int(rng.choice([1, 3, 31, 32, 33, 200, 256, 257, 600]))
+    if large:
+        n = int(rng.choice([300000, 1000000, 2500000]))
+        nq = int(rng.choice([5, 250, 513, 1100, 2100]))
+    else:
+        n = int(rng.choice([1, 7, 100, 129, 1000, 5000, 20000, 70000, 200000]))
+        nq = int(rng.choice([1, 3, 31, 32, 33, 200, 256, 257, 600]))
     k = int(rng.choice([1, 2, 5, 80, 100, 640, 1024, 1025, 1500, 3000]))
     kind = rng.choice(["int", "int_narrow", "sorted", "const", "f32_int", "f32_dense_band"])
     shards = int(rng.choice([1, 1, 2, 3]))
@@ -35,10 +40,10 @@ while time.time() < t_end:
         xb[:, 1] = 1 + rng.integers(0, 2048, n) * 2.0 ** -23
         xq = np.zeros((nq, 128), np.float32); xq[:, 0] = rng.choice([1.0, 2.0, 0.5], nq); xq[:, 1] = 1
     exact = xb.dtype == np.float32
-    if exact and n * nq > 3e7:
-        nq = max(1, int(3e7 // n))
+    if exact and n * nq > (3e8 if large else 3e7):
+        nq = max(1, int((3e8 if large else 3e7) // n))
         xq = xq[:nq]
-    if n * nq * 8 > 2.5e9:
+    if not large and n * nq * 8 > 2.5e9:
         continue
     oracle = search_oracle.topk_ip_exact if exact else search_oracle.topk_ip
     Do, Io = oracle(xq, xb, k)
