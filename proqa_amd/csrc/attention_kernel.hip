@@ -205,30 +205,37 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
   int len = cu_seqlens ? cu_seqlens[b + 1] - cu_seqlens[b] : (seq_lens ? seq_lens[b] : seq_len);
   len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
 
-  float qv[kHeadDim];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
+  // 8 lanes per key: lane (g = lane>>3, c = lane&7) owns the 16-byte piece c of keys g, g+8, ... so that a
+  // wave-instruction reads 8 whole 128-byte rows
+  const int g = lane >> 3, c = lane & 7;
+  float qv[8];
+  {
     const f16x8 q8 = *(const f16x8*)(base + c * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[c * 8 + e] = (float)q8[e];
+    for (int e = 0; e < 8; ++e) qv[e] = (float)q8[e];
   }
   float m = -__builtin_inff();
-  for (int key = lane; key < len; key += 64) {
-    const _Float16* kr = base + key * row_stride + hidden;
+  for (int key0 = 0; key0 < len; key0 += 8) {
+    const int key = key0 + g;
     float acc = 0.f;
+    if (key < len) {
+      const f16x8 k8 = *(const f16x8*)(base + key * row_stride + hidden + c * 8);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const f16x8 k8 = *(const f16x8*)(kr + c * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc += qv[c * 8 + e] * (float)k8[e];
+      for (int e = 0; e < 8; ++e) acc += qv[e] * (float)k8[e];
     }
+    acc += __shfl_xor(acc, 4, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 1, 64);
     acc *= 0.125f;
-    p_lds[key] = acc;
-    m = __builtin_fmaxf(m, acc);
+    if (key < len) {
+      if (c == 0) p_lds[key] = acc;
+      m = __builtin_fmaxf(m, acc);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, off, 64));
   float l = 0.f;
+  // same wave wrote p_lds: LDS ops of a wave complete in order
   for (int key = lane; key < len; key += 64) {
     const float p = __expf(p_lds[key] - m);
     p_lds[key] = p;
@@ -236,11 +243,30 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
-  // same wave wrote p_lds: LDS ops of a wave complete in order
-  float o = 0.f;
-  const _Float16* vcol = base + 2 * hidden + lane;
-  for (int key = 0; key < len; ++key) o += p_lds[key] * (float)vcol[key * row_stride];
-  ctx_cls[(long long)b * hidden + head * kHeadDim + lane] = (_Float16)(o / l);
+  // P.V with the same lane->(key group, piece) map: 8 partial outputs per dim, reduced over the groups
+  float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int key0 = 0; key0 < len; key0 += 8) {
+    const int key = key0 + g;
+    if (key < len) {
+      const float p = p_lds[key];
+      const f16x8 v8 = *(const f16x8*)(base + key * row_stride + 2 * hidden + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] += p * (float)v8[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    o8[e] += __shfl_xor(o8[e], 8, 64);
+    o8[e] += __shfl_xor(o8[e], 16, 64);
+    o8[e] += __shfl_xor(o8[e], 32, 64);
+  }
+  if (g == 0) {
+    const float inv = 1.0f / l;
+    f16x8 out8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out8[e] = (_Float16)(o8[e] * inv);
+    *(f16x8*)(ctx_cls + (long long)b * hidden + head * kHeadDim + c * 8) = out8;
+  }
 }
 
 }  // namespace
