@@ -21,6 +21,8 @@ while time.time() < t_end:
     else:
         n = int(rng.choice([1, 7, 100, 129, 1000, 5000, 20000, 70000, 200000]))
         nq = int(rng.choice([1, 3, 31, 32, 33, 200, 256, 257, 600]))
+        if n <= 5000 and rng.random() < 0.05:
+            nq = 17000                                  # more than one library call per search (QUERY_BATCH)
     k = int(rng.choice([1, 2, 5, 80, 100, 640, 1024, 1025, 1500, 3000]))
     kind = rng.choice(["int", "int_narrow", "sorted", "const", "f32_int", "f32_dense_band"])
     shards = int(rng.choice([1, 1, 2, 3]))
