@@ -1,0 +1,54 @@
+"""Per-question retrieval of the reference's OnlineSampler, on the exact GPU index.
+
+/root/reference/qa/online_sampler.py builds `faiss.IndexIVFFlat(quantizer, 128, 100)` with
+`nprobe = 20` over `para_embed` (:75-79) and, for one question at a time, encodes the question
+with the query tower, searches k = 5000 (training, :113) or k = eval_k (:274), maps rows to
+paragraph ids through `index2paraid` and gathers `para_embed[I]` (:116-117, :277).  Its own
+commented-out alternative is the exact `IndexFlatIP` (:80-82).
+
+`OnlineRetriever` is that retrieval step on `proqa_amd.index.IndexFlatIP`: exact instead of
+approximate (a superset in quality of the IVF probe; 1.2 ms per question over 18M rows), same
+outputs.  The sampler's span matching / batching is training code and is not rebuilt here.
+No CPU path.
+"""
+import numpy as np
+import torch
+
+from .index import IndexFlatIP
+
+
+class OnlineRetriever:
+    def __init__(self, para_embed, index2paraid=None, device=None):
+        """para_embed: [N,128] float16/float32 array (the np.load'ed index, qa/train_retrieve_qa.py:115);
+        index2paraid: the idx_id.json mapping {"<row>": paragraph id} or None."""
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        para_embed = np.ascontiguousarray(para_embed)
+        self.index = IndexFlatIP(128, capacity=para_embed.shape[0])
+        step = 1 << 21
+        for r0 in range(0, para_embed.shape[0], step):
+            self.index.add(para_embed[r0:r0 + step])
+        self.para_embed = para_embed
+        self.index2paraid = index2paraid
+
+    @torch.no_grad()
+    def embed_question(self, retriever, tokenizer, question, max_query_length):
+        """q_embed of online_sampler.py:106-111 with proqa_amd's BertForRetriever (query tower)."""
+        ids = torch.tensor([tokenizer.encode(question, max_length=max_query_length, truncation=True)],
+                           dtype=torch.int64, device=self.device)
+        mask = torch.ones_like(ids, dtype=torch.bool)
+        return retriever.get_embed({"input_ids": ids, "input_mask": mask}, True)["embed"]
+
+    def retrieve(self, q_embed, k=5000):
+        """q_embed [1,128] (numpy or CUDA tensor) -> (para_embed_idx int64 [k], para ids or None, para_embeds [k,128]),
+        the three values the sampler derives from `self.index.search(q_embed, k)`."""
+        if isinstance(q_embed, torch.Tensor):
+            _, I = self.index.search_device(q_embed.reshape(1, -1).to(self.device), k)
+            I = I.cpu().numpy()
+        else:
+            _, I = self.index.search(np.asarray(q_embed).reshape(1, -1), k)
+        para_embed_idx = I.reshape(-1)
+        para_embed_idx = para_embed_idx[para_embed_idx >= 0]         # fewer than k rows in the index
+        para_idx = None
+        if self.index2paraid is not None:
+            para_idx = [self.index2paraid[str(int(i))] for i in para_embed_idx]
+        return para_embed_idx, para_idx, self.para_embed[para_embed_idx]

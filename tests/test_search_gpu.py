@@ -434,3 +434,22 @@ def test_randomised_shapes_against_oracle(gpu_device):
         Do, Io = search_oracle.topk_ip(xq, xb_all, k)
         np.testing.assert_array_equal(I, Io, err_msg=f"trial {trial}: n={len(xb_all)} nq={nq} k={k}")
         np.testing.assert_array_equal(D, Do)
+
+
+def test_online_retriever_is_the_exact_search(gpu_device):
+    """qa/online_sampler.py's per-question retrieval (k = 5000) on the exact index."""
+    import torch
+    from proqa_amd.online_retriever import OnlineRetriever
+    rng = np.random.default_rng(21)
+    xb = _int_corpus(rng, 9000)
+    idmap = {str(i): f"doc-{i}" for i in range(len(xb))}
+    r = OnlineRetriever(xb, idmap, device=gpu_device)
+    q = _int_corpus(rng, 1)
+    Do, Io = search_oracle.topk_ip(q, xb, 5000)
+    for q_in in (q, torch.from_numpy(q).to(gpu_device)):
+        idx, ids, emb = r.retrieve(q_in, 5000)
+        np.testing.assert_array_equal(idx, Io[0])
+        assert ids[:3] == [f"doc-{i}" for i in Io[0][:3]] and len(ids) == 5000
+        np.testing.assert_array_equal(emb, xb[Io[0]])
+    idx, ids, emb = r.retrieve(q, 20000)                      # more than the index holds
+    assert len(idx) == 9000 and emb.shape == (9000, 128)
