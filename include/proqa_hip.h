@@ -127,6 +127,50 @@ int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev
  * PyTorch-ROCm (hipBLASLt).  All tensors fp16 row-major in HBM, fp32 statistics.
  * ---------------------------------------------------------------------------------- */
 
+/* ------------------------------------------------------------------------------------
+ * Encoder: BertForRetriever.get_embed (retrieval/retriever.py:33-43 + transformers BertModel)
+ * as one call: embeddings -> n_layers x {QKV, attention, output dense + LN, FFN + LN} ->
+ * pooler (tanh dense on h[:,0]) -> Linear(hidden, 128).
+ * All weights are device pointers to fp16, dense weights row-major [out, in] (the layout of the
+ * reference checkpoint, cast to fp16); qkv_w / qkv_b are the query|key|value weights stacked
+ * along `out` ([3*hidden, hidden] / [3*hidden]).  The caller owns the weights and keeps them
+ * alive while the encoder exists.  The dense layers are rocBLAS GEMMs (fp32 accumulate).
+ * ------------------------------------------------------------------------------------ */
+typedef struct proqa_bert_layer {
+  const void *qkv_w, *qkv_b;      /* [3*hidden, hidden], [3*hidden] */
+  const void *ao_w, *ao_b;        /* attention.output.dense */
+  const void *ln1_g, *ln1_b;      /* attention.output.LayerNorm */
+  const void *ff1_w, *ff1_b;      /* intermediate.dense  [intermediate, hidden] */
+  const void *ff2_w, *ff2_b;      /* output.dense        [hidden, intermediate] */
+  const void *ln2_g, *ln2_b;      /* output.LayerNorm */
+} proqa_bert_layer;
+
+typedef struct proqa_bert_weights {
+  int32_t hidden, n_layers, n_heads, intermediate, max_position;
+  int64_t vocab;
+  float layer_norm_eps;
+  const void *word_emb, *pos_emb, *type_emb;   /* type_emb: row 0 (token_type_ids are never passed) */
+  const void *emb_ln_g, *emb_ln_b;
+  const proqa_bert_layer* layers;              /* n_layers entries (copied by create) */
+  const void *pool_w, *pool_b;                 /* pooler.dense */
+  const void *proj_w, *proj_b;                 /* proj_q / proj_c: [128, hidden], [128] */
+} proqa_bert_weights;
+
+typedef struct proqa_encoder proqa_encoder;
+
+#define PROQA_ENC_CLS_ONLY_LAST 1  /* last layer: attention output / dense blocks / LayerNorms for the [CLS] rows only */
+#define PROQA_ENC_PACKED 2         /* evaluate the valid tokens only (needs n_valid_tokens) */
+
+int proqa_encoder_create(const proqa_bert_weights* w, proqa_encoder** out);
+int proqa_encoder_free(proqa_encoder* enc);
+/* ids_dev: [batch, seq_len] int64, right-padded (retrieval/datasets.py:29-45); seq_lens_dev: [batch]
+ * int32 valid lengths (>= 1); n_valid_tokens: their sum if the host knows it, else -1 (then the
+ * padded layout is evaluated whatever the flags say); out: [batch, 128] of out_dtype.
+ * Asynchronous on `stream`; not re-entrant per handle. */
+int proqa_encoder_forward(proqa_encoder* enc, const int64_t* ids_dev, const int32_t* seq_lens_dev, int batch,
+                          int seq_len, int64_t n_valid_tokens, int flags, void* out, int out_dtype, void* stream);
+
+/* The kernels the encoder is made of, individually (tests, other drivers). */
 /* out[b,s,:] = LayerNorm(word[ids[b,s]] + pos[s] + type[0]) , eps = 1e-12
  * (BertEmbeddings; token_type_ids are never passed by the reference => row 0) */
 int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_len, int hidden,

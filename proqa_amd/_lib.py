@@ -36,6 +36,27 @@ class SearchStats(ctypes.Structure):
                 ("candidates", ctypes.c_int64), ("filter_ms", c_float), ("total_ms", c_float)]
 
 
+class BertLayer(ctypes.Structure):
+    """proqa_bert_layer: device fp16 pointers of one encoder layer."""
+    _fields_ = [(n, c_void_p) for n in ("qkv_w", "qkv_b", "ao_w", "ao_b", "ln1_g", "ln1_b", "ff1_w", "ff1_b",
+                                        "ff2_w", "ff2_b", "ln2_g", "ln2_b")]
+
+
+class BertWeights(ctypes.Structure):
+    """proqa_bert_weights"""
+    _fields_ = [("hidden", ctypes.c_int32), ("n_layers", ctypes.c_int32), ("n_heads", ctypes.c_int32),
+                ("intermediate", ctypes.c_int32), ("max_position", ctypes.c_int32), ("vocab", c_int64),
+                ("layer_norm_eps", c_float),
+                ("word_emb", c_void_p), ("pos_emb", c_void_p), ("type_emb", c_void_p),
+                ("emb_ln_g", c_void_p), ("emb_ln_b", c_void_p),
+                ("layers", ctypes.POINTER(BertLayer)),
+                ("pool_w", c_void_p), ("pool_b", c_void_p), ("proj_w", c_void_p), ("proj_b", c_void_p)]
+
+
+ENC_CLS_ONLY_LAST = 1
+ENC_PACKED = 2
+
+
 class NpyInfo(ctypes.Structure):
     _fields_ = [("rows", c_int64), ("cols", c_int64), ("dtype", ctypes.c_int32),
                 ("data_offset", c_int64)]
@@ -63,6 +84,10 @@ SIGNATURES = {
     "proqa_index_configure": (c_int, [c_void_p, c_int, c_int]),
     "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p]),
+    "proqa_encoder_create": (c_int, [ctypes.POINTER(BertWeights), ctypes.POINTER(c_void_p)]),
+    "proqa_encoder_free": (c_int, [c_void_p]),
+    "proqa_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_int,
+                                      c_void_p]),
     "proqa_embed_layernorm_f16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                           c_void_p, c_void_p]),
@@ -96,28 +121,32 @@ _lib = None
 
 
 def _promote_hip_runtime():
-    """Make ONE HIP runtime's symbols global before libproqa_hip.so is opened.
+    """Make ONE HIP runtime's (and its rocBLAS') symbols global before libproqa_hip.so is opened.
 
-    libproqa_hip.so carries no DT_NEEDED on libamdhip64 (see proqa_amd/build.py).  When torch is
+    libproqa_hip.so carries no DT_NEEDED on libamdhip64 / librocblas (see proqa_amd/build.py).  When torch is
     importable its bundled runtime is the one that owns every tensor we are handed, so that copy
     is promoted; otherwise the system ROCm runtime is used.
     """
-    candidates = []
+    dirs = []
     try:
-        import torch  # noqa: F401  (loads its libamdhip64.so)
-        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        import torch  # noqa: F401  (loads its libamdhip64.so / librocblas.so)
+        dirs.append(os.path.join(os.path.dirname(torch.__file__), "lib"))
     except Exception:
         pass
-    candidates += ["libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"]
+    dirs += ["", "/opt/rocm/lib"]
     errors = []
-    for cand in candidates:
-        if os.path.isabs(cand) and not os.path.exists(cand):
+    for d in dirs:
+        hip = os.path.join(d, "libamdhip64.so") if d else "libamdhip64.so"
+        if d and not os.path.exists(hip):
             continue
         try:
-            return ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+            handle = ctypes.CDLL(hip, mode=ctypes.RTLD_GLOBAL)
+            # the encoder's GEMMs: the rocBLAS that belongs to THIS runtime (same directory)
+            ctypes.CDLL(os.path.join(d, "librocblas.so") if d else "librocblas.so", mode=ctypes.RTLD_GLOBAL)
+            return handle
         except OSError as e:  # pragma: no cover - depends on the machine
-            errors.append(f"{cand}: {e}")
-    raise RuntimeError("no HIP runtime (libamdhip64.so) could be loaded: " + "; ".join(errors))
+            errors.append(f"{hip}: {e}")
+    raise RuntimeError("no HIP runtime (libamdhip64.so + librocblas.so) could be loaded: " + "; ".join(errors))
 
 
 def load():

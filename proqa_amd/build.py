@@ -22,6 +22,7 @@ SOURCES = [
     "mips_kernels.hip",
     "encoder_kernels.hip",
     "attention_kernel.hip",
+    "encoder.cpp",
     "kmeans_kernels.hip",
 ]
 

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "attention.h"
 #include "common.h"
 
 namespace proqa {
@@ -39,7 +40,19 @@ constexpr int kOutStride = kHeadDim + 8;
 
 // Token layout: padded ([B, seq_len] rows, cu_seqlens == nullptr, seq_lens = valid keys per sequence) or
 // packed (cu_seqlens[b] = first token row of sequence b, no padding rows exist; seq_len = longest sequence).
+// qkv_bias (nullable): the [3*hidden] bias of the fused Q|K|V projection, added here when the GEMM that
+// produced qkv had no bias epilogue (proqa_encoder_forward: rocBLAS) -- in fp32, rounded once to fp16.
+__device__ __forceinline__ f16x8 add_bias8(f16x8 v, const _Float16* __restrict__ bias) {
+  if (bias) {
+    const f16x8 b = *(const f16x8*)bias;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)b[e]);
+  }
+  return v;
+}
+
 __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict__ qkv,
+                                                     const _Float16* __restrict__ qkv_bias,
                                                      const int* __restrict__ seq_lens,
                                                      const int* __restrict__ cu_seqlens, int seq_len,
                                                      int n_heads, _Float16* __restrict__ ctx) {
@@ -61,6 +74,9 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
   const int n_ktiles = (len + 31) >> 5;
   const int rows_avail = cu_seqlens ? len : seq_len;   // token rows of this sequence that exist in memory
+  const _Float16* bias_q = qkv_bias ? qkv_bias + head * kHeadDim : nullptr;
+  const _Float16* bias_k = qkv_bias ? qkv_bias + hidden + head * kHeadDim : nullptr;
+  const _Float16* bias_v = qkv_bias ? qkv_bias + 2 * hidden + head * kHeadDim : nullptr;
 
   const int tid = threadIdx.x;
   // stage K and V rows [0, n_ktiles*32): 8 lanes cover one 128-byte row
@@ -69,8 +85,8 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
     f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
     if (row < rows_avail) {
       const _Float16* src = base + row * row_stride + c * 8;
-      kv = *(const f16x8*)(src + hidden);
-      vv = *(const f16x8*)(src + 2 * hidden);
+      kv = add_bias8(*(const f16x8*)(src + hidden), bias_k ? bias_k + c * 8 : nullptr);
+      vv = add_bias8(*(const f16x8*)(src + 2 * hidden), bias_v ? bias_v + c * 8 : nullptr);
     }
     *(f16x8*)(k_lds + row * kKStride + c * 8) = kv;
 #pragma unroll
@@ -115,7 +131,9 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[j] = q < rows_avail ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) : z;
+      qf[j] = q < rows_avail ? add_bias8(*(const f16x8*)(base + q * row_stride + (2 * j + half) * 8),
+                                         bias_q ? bias_q + (2 * j + half) * 8 : nullptr)
+                             : z;
     }
     float m = -__builtin_inff();
     float l = 0.f;
@@ -188,6 +206,7 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
 // q.K^T (fp32), the softmax is a wave reduction, then lanes own the 64 output dims for P.V with the
 // probabilities broadcast from LDS.  Streams K and V once: B*S*2*128 B per head, HBM-bound.
 __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restrict__ qkv,
+                                                         const _Float16* __restrict__ qkv_bias,
                                                          const int* __restrict__ seq_lens,
                                                          const int* __restrict__ cu_seqlens, int seq_len,
                                                          int n_heads, int n_pairs, _Float16* __restrict__ ctx_cls) {
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
   const int g = lane >> 3, c = lane & 7;
   float qv[8];
   {
-    const f16x8 q8 = *(const f16x8*)(base + c * 8);
+    const f16x8 q8 = add_bias8(*(const f16x8*)(base + c * 8), qkv_bias ? qkv_bias + head * kHeadDim + c * 8 : nullptr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] = (float)q8[e];
   }
@@ -219,7 +238,8 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
     const int key = key0 + g;
     float acc = 0.f;
     if (key < len) {
-      const f16x8 k8 = *(const f16x8*)(base + key * row_stride + hidden + c * 8);
+      const f16x8 k8 = add_bias8(*(const f16x8*)(base + key * row_stride + hidden + c * 8),
+                                 qkv_bias ? qkv_bias + hidden + head * kHeadDim + c * 8 : nullptr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc += qv[e] * (float)k8[e];
     }
@@ -249,7 +269,8 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
     const int key = key0 + g;
     if (key < len) {
       const float p = p_lds[key];
-      const f16x8 v8 = *(const f16x8*)(base + key * row_stride + 2 * hidden + c * 8);
+      const f16x8 v8 = add_bias8(*(const f16x8*)(base + key * row_stride + 2 * hidden + c * 8),
+                                 qkv_bias ? qkv_bias + 2 * hidden + head * kHeadDim + c * 8 : nullptr);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o8[e] += p * (float)v8[e];
     }
@@ -276,8 +297,12 @@ using namespace proqa;
 
 namespace {
 
-int launch_attention(const void* qkv, const int32_t* seq_lens_dev, const int32_t* cu_seqlens_dev, int batch,
-                     int seq_len, int n_heads, void* ctx_out, void* stream) {
+}  // namespace
+
+namespace proqa {
+
+int launch_attention(const void* qkv, const void* qkv_bias, const int32_t* seq_lens_dev, const int32_t* cu_seqlens_dev,
+                     int batch, int seq_len, int n_heads, void* ctx_out, void* stream) {
   if (!qkv || !ctx_out) return fail(PROQA_EINVAL, "attention: NULL argument");
   if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention: bad sizes");
   const int s_pad = (seq_len + 31) & ~31;
@@ -289,14 +314,15 @@ int launch_attention(const void* qkv, const int32_t* seq_lens_dev, const int32_t
     PROQA_HIP(hipFuncSetAttribute((const void*)attention_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   hipLaunchKernelGGL(attention_fwd, dim3((unsigned)batch * n_heads), dim3(256), lds, as_stream(stream),
-                     (const _Float16*)qkv, (const int*)seq_lens_dev, (const int*)cu_seqlens_dev, seq_len, n_heads,
-                     (_Float16*)ctx_out);
+                     (const _Float16*)qkv, (const _Float16*)qkv_bias, (const int*)seq_lens_dev,
+                     (const int*)cu_seqlens_dev, seq_len, n_heads, (_Float16*)ctx_out);
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
 }
 
-int launch_attention_cls(const void* qkv, const int32_t* seq_lens_dev, const int32_t* cu_seqlens_dev, int batch,
-                         int seq_len, int n_heads, void* ctx_cls_out, void* stream) {
+int launch_attention_cls(const void* qkv, const void* qkv_bias, const int32_t* seq_lens_dev,
+                         const int32_t* cu_seqlens_dev, int batch, int seq_len, int n_heads, void* ctx_cls_out,
+                         void* stream) {
   if (!qkv || !ctx_cls_out) return fail(PROQA_EINVAL, "attention_cls: NULL argument");
   if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention_cls: bad sizes");
   const size_t lds = (size_t)4 * seq_len * sizeof(float);
@@ -304,32 +330,32 @@ int launch_attention_cls(const void* qkv, const int32_t* seq_lens_dev, const int
   if (batch == 0) return PROQA_OK;
   const int n_pairs = batch * n_heads;
   hipLaunchKernelGGL(attention_cls_fwd, dim3((unsigned)((n_pairs + 3) / 4)), dim3(256), lds, as_stream(stream),
-                     (const _Float16*)qkv, (const int*)seq_lens_dev, (const int*)cu_seqlens_dev, seq_len, n_heads,
-                     n_pairs, (_Float16*)ctx_cls_out);
+                     (const _Float16*)qkv, (const _Float16*)qkv_bias, (const int*)seq_lens_dev,
+                     (const int*)cu_seqlens_dev, seq_len, n_heads, n_pairs, (_Float16*)ctx_cls_out);
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
 }
 
-}  // namespace
+}  // namespace proqa
 
 extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
                                    int n_heads, void* ctx_out, void* stream) {
-  return launch_attention(qkv, seq_lens_dev, nullptr, batch, seq_len, n_heads, ctx_out, stream);
+  return launch_attention(qkv, nullptr, seq_lens_dev, nullptr, batch, seq_len, n_heads, ctx_out, stream);
 }
 
 extern "C" int proqa_attention_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens_dev, int batch,
                                           int max_seq_len, int n_heads, void* ctx_packed_out, void* stream) {
   if (!cu_seqlens_dev) return fail(PROQA_EINVAL, "attention_varlen: NULL cu_seqlens");
-  return launch_attention(qkv_packed, nullptr, cu_seqlens_dev, batch, max_seq_len, n_heads, ctx_packed_out, stream);
+  return launch_attention(qkv_packed, nullptr, nullptr, cu_seqlens_dev, batch, max_seq_len, n_heads, ctx_packed_out, stream);
 }
 
 extern "C" int proqa_attention_cls_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
                                        int n_heads, void* ctx_cls_out, void* stream) {
-  return launch_attention_cls(qkv, seq_lens_dev, nullptr, batch, seq_len, n_heads, ctx_cls_out, stream);
+  return launch_attention_cls(qkv, nullptr, seq_lens_dev, nullptr, batch, seq_len, n_heads, ctx_cls_out, stream);
 }
 
 extern "C" int proqa_attention_cls_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens_dev, int batch,
                                               int max_seq_len, int n_heads, void* ctx_cls_out, void* stream) {
   if (!cu_seqlens_dev) return fail(PROQA_EINVAL, "attention_cls_varlen: NULL cu_seqlens");
-  return launch_attention_cls(qkv_packed, nullptr, cu_seqlens_dev, batch, max_seq_len, n_heads, ctx_cls_out, stream);
+  return launch_attention_cls(qkv_packed, nullptr, nullptr, cu_seqlens_dev, batch, max_seq_len, n_heads, ctx_cls_out, stream);
 }

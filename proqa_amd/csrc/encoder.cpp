@@ -1,0 +1,225 @@
+// BertForRetriever.get_embed behind the C ABI (proqa_encoder_* in proqa_hip.h): the whole tower --
+// embeddings, N encoder layers, pooler, projection -- driven from C++ on caller-owned fp16 weights.
+// Replaces /root/reference/retrieval/retriever.py:33-43 (+ transformers BertModel).  The dense layers are
+// rocBLAS GEMMs (rocblas_gemm_ex, fp16 in / fp32 accumulate; the library resolves them against the
+// rocBLAS of the process, see proqa_amd/_lib.py); everything else is the HIP kernels of this library.
+#include <rocblas/rocblas.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "attention.h"
+#include "common.h"
+
+using namespace proqa;
+
+namespace {
+
+constexpr int kRowTile = 256;  // token rows handed to the GEMMs are a multiple of the macro-tile (when large)
+
+struct Workspace {
+  void* base = nullptr;
+  size_t bytes = 0;
+  int64_t rows = 0;   // token rows it was sized for
+  int batch = 0;
+  _Float16 *h = nullptr, *h1 = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ff = nullptr;
+  _Float16 *c_ctx = nullptr, *c_res = nullptr, *c_tmp = nullptr, *c_h1 = nullptr, *c_ff = nullptr, *c_h = nullptr,
+           *pooled = nullptr;
+  int32_t* cu = nullptr;
+};
+
+}  // namespace
+
+struct proqa_encoder {
+  proqa_bert_weights w;
+  std::vector<proqa_bert_layer> layers;
+  rocblas_handle blas = nullptr;
+  Workspace ws;
+  int device = 0;
+};
+
+namespace {
+
+int blas_fail(rocblas_status s, const char* what) {
+  return fail(PROQA_EHIP, "%s failed: rocblas status %d", what, (int)s);
+}
+#define PROQA_BLAS(call)                                   \
+  do {                                                     \
+    rocblas_status _s = (call);                            \
+    if (_s != rocblas_status_success) return blas_fail(_s, #call); \
+  } while (0)
+
+// out[M,N] = x[M,K] . w[N,K]^T, row-major fp16, fp32 accumulate.  Column-major view: out'[N,M] = w'^T x'.
+int gemm_tn(proqa_encoder* e, const _Float16* x, const void* w, _Float16* out, int64_t M, int N, int K) {
+  if (M == 0) return PROQA_OK;
+  const float alpha = 1.0f, beta = 0.0f;
+  PROQA_BLAS(rocblas_gemm_ex(e->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)M, K, &alpha, w,
+                             rocblas_datatype_f16_r, K, x, rocblas_datatype_f16_r, K, &beta, out, rocblas_datatype_f16_r,
+                             N, out, rocblas_datatype_f16_r, N, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0));
+  return PROQA_OK;
+}
+
+int ensure_workspace(proqa_encoder* e, int batch, int64_t rows) {
+  Workspace& ws = e->ws;
+  if (rows <= ws.rows && batch <= ws.batch) return PROQA_OK;
+  rows = std::max(rows, ws.rows);
+  batch = std::max(batch, ws.batch);
+  const int H = e->w.hidden, I = e->w.intermediate;
+  auto al = [](size_t b) { return round_up<size_t>(b, 256); };
+  const size_t tok = (size_t)rows, bt = (size_t)batch;
+  const size_t sizes[] = {al(tok * H * 2),     al(tok * H * 2), al(tok * 3 * H * 2), al(tok * H * 2), al(tok * H * 2),
+                          al(tok * I * 2),     al(bt * H * 2),  al(bt * H * 2),      al(bt * H * 2),  al(bt * H * 2),
+                          al(bt * I * 2),      al(bt * H * 2),  al(bt * H * 2),      al((bt + 1) * 4)};
+  size_t total = 0;
+  for (size_t s : sizes) total += s;
+  if (ws.base) PROQA_HIP(hipFree(ws.base));
+  ws = Workspace();
+  hipError_t err = hipMalloc(&ws.base, total);
+  if (err != hipSuccess) return fail(PROQA_ENOMEM, "encoder workspace of %zu B: %s", total, hipGetErrorString(err));
+  // rows past the last token are only ever GEMM/element-wise padding: start them at zero (finite)
+  PROQA_HIP(hipMemset(ws.base, 0, total));
+  char* p = (char*)ws.base;
+  _Float16** slots[] = {&ws.h, &ws.h1, &ws.qkv, &ws.ctx, &ws.tmp, &ws.ff, &ws.c_ctx, &ws.c_res, &ws.c_tmp, &ws.c_h1,
+                        &ws.c_ff, &ws.c_h, &ws.pooled};
+  for (int i = 0; i < 13; ++i) {
+    *slots[i] = (_Float16*)p;
+    p += sizes[i];
+  }
+  ws.cu = (int32_t*)p;
+  ws.bytes = total;
+  ws.rows = rows;
+  ws.batch = batch;
+  return PROQA_OK;
+}
+
+}  // namespace
+
+namespace proqa {
+// encoder_kernels.hip
+int launch_cu_seqlens(const int32_t* seq_lens_dev, int batch, int32_t* cu_out, void* stream);
+int launch_gather_rows(const void* src, int64_t src_row_stride_elems, const int32_t* row_index_dev, int64_t fixed_stride_rows,
+                       int n_rows, int cols, void* dst, void* stream);
+}  // namespace proqa
+
+extern "C" {
+
+int proqa_encoder_create(const proqa_bert_weights* w, proqa_encoder** out) {
+  if (!w || !out) return fail(PROQA_EINVAL, "encoder_create: NULL argument");
+  *out = nullptr;
+  if (w->hidden <= 0 || w->n_heads <= 0 || w->hidden != w->n_heads * 64)
+    return fail(PROQA_EINVAL, "encoder_create: hidden=%d must be n_heads*64 (head_dim 64)", w->hidden);
+  if (w->n_layers <= 0 || w->intermediate <= 0 || w->intermediate % 8 || w->vocab <= 0 || w->max_position <= 0 || !w->layers)
+    return fail(PROQA_EINVAL, "encoder_create: bad model geometry");
+  const void* need[] = {w->word_emb, w->pos_emb, w->type_emb, w->emb_ln_g, w->emb_ln_b, w->pool_w, w->pool_b, w->proj_w, w->proj_b};
+  for (const void* p : need)
+    if (!p) return fail(PROQA_EINVAL, "encoder_create: NULL weight pointer");
+  for (int l = 0; l < w->n_layers; ++l) {
+    const proqa_bert_layer& L = w->layers[l];
+    const void* lp[] = {L.qkv_w, L.qkv_b, L.ao_w, L.ao_b, L.ln1_g, L.ln1_b, L.ff1_w, L.ff1_b, L.ff2_w, L.ff2_b, L.ln2_g, L.ln2_b};
+    for (const void* p : lp)
+      if (!p) return fail(PROQA_EINVAL, "encoder_create: NULL weight pointer in layer %d", l);
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PROQA_ENOGPU, "encoder_create: no HIP device visible");
+  proqa_encoder* e = new (std::nothrow) proqa_encoder();
+  if (!e) return fail(PROQA_ENOMEM, "encoder_create: out of host memory");
+  e->w = *w;
+  e->layers.assign(w->layers, w->layers + w->n_layers);
+  e->w.layers = e->layers.data();
+  PROQA_HIP(hipGetDevice(&e->device));
+  rocblas_status s = rocblas_create_handle(&e->blas);
+  if (s != rocblas_status_success) {
+    delete e;
+    return blas_fail(s, "rocblas_create_handle");
+  }
+  *out = e;
+  return PROQA_OK;
+}
+
+int proqa_encoder_free(proqa_encoder* e) {
+  if (!e) return PROQA_OK;
+  if (e->ws.base) (void)hipFree(e->ws.base);
+  if (e->blas) (void)rocblas_destroy_handle(e->blas);
+  delete e;
+  return PROQA_OK;
+}
+
+int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_t* seq_lens_dev, int batch, int seq_len,
+                          int64_t n_valid_tokens, int flags, void* out, int out_dtype, void* stream) {
+  if (!e || (batch > 0 && (!ids_dev || !seq_lens_dev || !out))) return fail(PROQA_EINVAL, "encoder_forward: NULL argument");
+  if (batch < 0 || seq_len <= 0) return fail(PROQA_EINVAL, "encoder_forward: bad sizes");
+  if (seq_len > e->w.max_position)
+    return fail(PROQA_EINVAL, "encoder_forward: sequence length %d exceeds max_position_embeddings %d", seq_len,
+                e->w.max_position);
+  if (out_dtype != PROQA_F16 && out_dtype != PROQA_F32) return fail(PROQA_EINVAL, "encoder_forward: bad out dtype");
+  if (batch == 0) return PROQA_OK;
+  const proqa_bert_weights& w = e->w;
+  const int H = w.hidden, I = w.intermediate, NH = w.n_heads;
+  const float eps = w.layer_norm_eps;
+  const int64_t n_padded = (int64_t)batch * seq_len;
+  if (n_valid_tokens > n_padded) return fail(PROQA_EINVAL, "encoder_forward: n_valid_tokens exceeds batch*seq_len");
+  const bool packed = (flags & PROQA_ENC_PACKED) && n_valid_tokens > 0 && n_valid_tokens < n_padded;
+  const bool cls_only = (flags & PROQA_ENC_CLS_ONLY_LAST) != 0;
+  if (int rc = ensure_workspace(e, batch, round_up<int64_t>(n_padded, kRowTile))) return rc;
+  Workspace& ws = e->ws;
+  hipStream_t st = as_stream(stream);
+  PROQA_BLAS(rocblas_set_stream(e->blas, st));
+
+  int64_t n = n_padded;
+  const int32_t* cu = nullptr;
+  if (packed) {
+    n = n_valid_tokens;
+    if (int rc = launch_cu_seqlens(seq_lens_dev, batch, ws.cu, stream)) return rc;
+    cu = ws.cu;
+    if (int rc = proqa_embed_layernorm_varlen_f16(ids_dev, cu, batch, seq_len, H, w.word_emb, w.vocab, w.pos_emb, w.type_emb,
+                                                  w.emb_ln_g, w.emb_ln_b, eps, ws.h, stream))
+      return rc;
+  } else {
+    if (int rc = proqa_embed_layernorm_f16(ids_dev, n, seq_len, H, w.word_emb, w.vocab, w.pos_emb, w.type_emb, w.emb_ln_g,
+                                           w.emb_ln_b, eps, ws.h, stream))
+      return rc;
+  }
+  // rows handed to the dense layers: the tokens, rounded up to the GEMM tile for large batches (the extra rows
+  // hold finite stale values nothing reads back; small batches stay small)
+  const int64_t rows = n > 8 * kRowTile ? round_up<int64_t>(n, kRowTile) : n;
+  const int32_t* lens = packed ? nullptr : seq_lens_dev;
+  _Float16 *h = ws.h, *h1 = ws.h1;
+  const int n_full = cls_only ? w.n_layers - 1 : w.n_layers;
+  for (int l = 0; l < n_full; ++l) {
+    const proqa_bert_layer& L = w.layers[l];
+    if (int rc = gemm_tn(e, h, L.qkv_w, ws.qkv, rows, 3 * H, H)) return rc;                       // fused Q|K|V projection
+    if (int rc = launch_attention(ws.qkv, L.qkv_b, lens, cu, batch, seq_len, NH, ws.ctx, stream)) return rc;
+    if (int rc = gemm_tn(e, ws.ctx, L.ao_w, ws.tmp, rows, H, H)) return rc;
+    if (int rc = proqa_bias_residual_layernorm_f16(ws.tmp, L.ao_b, h, L.ln1_g, L.ln1_b, eps, rows, H, h1, stream)) return rc;
+    if (int rc = gemm_tn(e, h1, L.ff1_w, ws.ff, rows, I, H)) return rc;
+    if (int rc = proqa_bias_gelu_f16(ws.ff, L.ff1_b, rows, I, stream)) return rc;
+    if (int rc = gemm_tn(e, ws.ff, L.ff2_w, ws.tmp, rows, H, I)) return rc;
+    if (int rc = proqa_bias_residual_layernorm_f16(ws.tmp, L.ff2_b, h1, L.ln2_g, L.ln2_b, eps, rows, H, h, stream)) return rc;
+  }
+  // h[:, 0] of every sequence -> dst [batch, H]
+  auto cls_rows = [&](_Float16* dst) {
+    return launch_gather_rows(h, H, cu, seq_len, batch, H, dst, stream);
+  };
+  if (cls_only) {
+    // the pooler reads h[:, 0] only (retriever.py:41-42): the last layer needs K and V of every token but the
+    // attention output, both dense blocks and LayerNorms for the [CLS] rows alone
+    const proqa_bert_layer& L = w.layers[w.n_layers - 1];
+    if (int rc = gemm_tn(e, h, L.qkv_w, ws.qkv, rows, 3 * H, H)) return rc;
+    if (int rc = launch_attention_cls(ws.qkv, L.qkv_b, lens, cu, batch, seq_len, NH, ws.c_ctx, stream)) return rc;
+    if (int rc = cls_rows(ws.c_res)) return rc;
+    if (int rc = gemm_tn(e, ws.c_ctx, L.ao_w, ws.c_tmp, batch, H, H)) return rc;
+    if (int rc = proqa_bias_residual_layernorm_f16(ws.c_tmp, L.ao_b, ws.c_res, L.ln1_g, L.ln1_b, eps, batch, H, ws.c_h1, stream))
+      return rc;
+    if (int rc = gemm_tn(e, ws.c_h1, L.ff1_w, ws.c_ff, batch, I, H)) return rc;
+    if (int rc = proqa_bias_gelu_f16(ws.c_ff, L.ff1_b, batch, I, stream)) return rc;
+    if (int rc = gemm_tn(e, ws.c_ff, L.ff2_w, ws.c_tmp, batch, H, I)) return rc;
+    if (int rc = proqa_bias_residual_layernorm_f16(ws.c_tmp, L.ff2_b, ws.c_h1, L.ln2_g, L.ln2_b, eps, batch, H, ws.c_h, stream))
+      return rc;
+  } else {
+    if (int rc = cls_rows(ws.c_h)) return rc;
+  }
+  return proqa_pool_project_f16(ws.c_h, batch, 1, H, w.pool_w, w.pool_b, w.proj_w, w.proj_b, ws.pooled, out, out_dtype, stream);
+}
+
+}  // extern "C"

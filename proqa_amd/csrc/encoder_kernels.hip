@@ -198,6 +198,61 @@ __global__ __launch_bounds__(256) void cls_dense_mfma(const _Float16* __restrict
 
 using namespace proqa;
 
+// ---- helpers of the C++ encoder driver (encoder.cpp) ---------------------------------------
+namespace proqa {
+namespace {
+
+// cu[0] = 0, cu[b+1] = cu[b] + clamp(lens[b], 1, ...): exclusive prefix of the sequence lengths (one block)
+__global__ __launch_bounds__(256) void cu_seqlens_kernel(const int* __restrict__ lens, int batch, int* __restrict__ cu) {
+  __shared__ int part[256];
+  const int tid = threadIdx.x;
+  const int per = (batch + 255) / 256;
+  const int b0 = tid * per, b1 = b0 + per < batch ? b0 + per : batch;
+  int sum = 0;
+  for (int b = b0; b < b1; ++b) sum += lens[b] < 1 ? 1 : lens[b];
+  part[tid] = sum;
+  __syncthreads();
+  int base = 0;
+  for (int t = 0; t < tid; ++t) base += part[t];
+  if (tid == 0) cu[0] = 0;
+  for (int b = b0; b < b1; ++b) {
+    base += lens[b] < 1 ? 1 : lens[b];
+    cu[b + 1] = base;
+  }
+}
+
+// dst[r] = row (index ? index[r] : r * fixed_stride_rows) of src; cols a multiple of 8 (16-byte pieces)
+__global__ void gather_rows_kernel(const _Float16* __restrict__ src, long long row_stride, const int* __restrict__ index,
+                                   long long fixed_stride_rows, int n_rows, int chunks_per_row, _Float16* __restrict__ dst) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n_rows * chunks_per_row) return;
+  const int r = (int)(t / chunks_per_row), c = (int)(t - (long long)r * chunks_per_row);
+  const long long row = index ? (long long)index[r] : (long long)r * fixed_stride_rows;
+  *(f16x8*)(dst + (long long)r * chunks_per_row * 8 + c * 8) = *(const f16x8*)(src + row * row_stride + c * 8);
+}
+
+}  // namespace
+
+int launch_cu_seqlens(const int32_t* seq_lens_dev, int batch, int32_t* cu_out, void* stream) {
+  hipLaunchKernelGGL(cu_seqlens_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const int*)seq_lens_dev, batch,
+                     (int*)cu_out);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+int launch_gather_rows(const void* src, int64_t src_row_stride_elems, const int32_t* row_index_dev, int64_t fixed_stride_rows,
+                       int n_rows, int cols, void* dst, void* stream) {
+  if (n_rows == 0) return PROQA_OK;
+  const long long n = (long long)n_rows * (cols / 8);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                     (const _Float16*)src, (long long)src_row_stride_elems, (const int*)row_index_dev,
+                     (long long)fixed_stride_rows, n_rows, cols / 8, (_Float16*)dst);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+}  // namespace proqa
+
 extern "C" {
 
 static int launch_embed_layernorm(const int64_t* ids_dev, int64_t n_tokens, const int32_t* cu_seqlens_dev, int seq_len,

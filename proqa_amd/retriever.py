@@ -6,13 +6,15 @@ Mirrors /root/reference/retrieval/retriever.py (BertForRetriever :10-20, get_emb
         -> {'embed': Tensor[B,128]}
 
 Each tower is BertModel (embeddings, N x BertLayer, pooler) followed by Linear(hidden, 128) on
-the pooled [CLS] vector.  Here the dense projections run as PyTorch-ROCm fp16 GEMMs (hipBLASLt)
-and everything between them is a hand-written HIP kernel called through the C ABI of
-libproqa_hip.so: embedding gather+LayerNorm, MFMA attention with the key-padding mask,
-bias+GELU(erf), bias+residual+LayerNorm, and the fused pooler(tanh)+projection head.
+the pooled [CLS] vector.  The whole tower runs inside libproqa_hip.so (`proqa_encoder_forward`):
+the dense projections as rocBLAS fp16 GEMMs with fp32 accumulation, everything between them as
+hand-written HIP kernels -- embedding gather+LayerNorm, MFMA attention with the key-padding mask,
+bias+GELU(erf), bias+residual+LayerNorm, and the fused pooler(tanh)+projection head.  PyTorch only
+owns the weight / activation tensors whose device pointers cross the C ABI.
 Weights are held in fp16 (the reference runs apex AMP O1 / .half() for --fp16); accumulation,
 softmax and LayerNorm statistics are fp32.  There is no CPU path.
 """
+import ctypes
 import re
 from types import SimpleNamespace
 
@@ -52,9 +54,6 @@ def tower_keys(prefix, n_layers):
     return keys
 
 
-ROW_TILE = 256   # token rows handed to the dense layers are a multiple of this (hipBLASLt macro-tile)
-
-
 class _Tower:
     """fp16 device weights of one BERT tower, laid out for the kernels (fused QKV, [out,in] GEMM operands)."""
 
@@ -89,6 +88,38 @@ class _Tower:
         self.pool_b = w(f"{prefix}.pooler.dense.bias")
         self.proj_w = w(f"{proj_prefix}.weight")           # [128, H]
         self.proj_b = w(f"{proj_prefix}.bias")
+        self._handle = None
+        self._create_encoder(cfg, device)
+
+    def _create_encoder(self, cfg, device):
+        """proqa_encoder_create over these tensors' device pointers (the tensors stay owned here)."""
+        lib = _lib.load()
+        layers = (_lib.BertLayer * len(self.layers))()
+        for dst, L in zip(layers, self.layers):
+            for name, _ in _lib.BertLayer._fields_:
+                setattr(dst, name, getattr(L, name).data_ptr())
+        bw = _lib.BertWeights(hidden=cfg.hidden_size, n_layers=len(self.layers), n_heads=cfg.num_attention_heads,
+                              intermediate=cfg.intermediate_size, max_position=cfg.max_position_embeddings,
+                              vocab=self.word.shape[0], layer_norm_eps=float(cfg.layer_norm_eps),
+                              word_emb=self.word.data_ptr(), pos_emb=self.pos.data_ptr(), type_emb=self.type0.data_ptr(),
+                              emb_ln_g=self.emb_g.data_ptr(), emb_ln_b=self.emb_b.data_ptr(), layers=layers,
+                              pool_w=self.pool_w.data_ptr(), pool_b=self.pool_b.data_ptr(),
+                              proj_w=self.proj_w.data_ptr(), proj_b=self.proj_b.data_ptr())
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.proqa_encoder_create(ctypes.byref(bw), ctypes.byref(handle)))
+        self._handle = handle
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            _lib.load().proqa_encoder_free(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class BertForRetriever:
@@ -111,7 +142,6 @@ class BertForRetriever:
         self.cls_only_last_layer = True
         # evaluate valid tokens only (packed layout) whenever the lengths are known on the host
         self.pack_tokens = True
-        self._ws = {}
 
     # -- reference-compatible surface -----------------------------------------------------
     def state_dict_keys(self):
@@ -178,34 +208,9 @@ class BertForRetriever:
         return {"embed": emb}
 
     # -- implementation -------------------------------------------------------------------
-    def _buffers(self, B, S):
-        # one workspace per (shape, stream): batches in flight on different streams never share buffers
-        key = (B, S, torch.cuda.current_stream().cuda_stream)
-        ws = self._ws.get(key)
-        if ws is None:
-            H, I = self.config.hidden_size, self.config.intermediate_size
-            dev, f16 = self.device, torch.float16
-            # token rows are rounded up to the GEMM tile (ROW_TILE): the dense layers always see a multiple
-            # of it; rows past the last token hold zeros / stale finite values that nothing reads back
-            n = -(-B * S // ROW_TILE) * ROW_TILE
-            ws = SimpleNamespace(
-                h=torch.zeros((n, H), dtype=f16, device=dev), h1=torch.zeros((n, H), dtype=f16, device=dev),
-                qkv=torch.zeros((n, 3 * H), dtype=f16, device=dev), ctx=torch.zeros((n, H), dtype=f16, device=dev),
-                tmp=torch.zeros((n, H), dtype=f16, device=dev), ff=torch.zeros((n, I), dtype=f16, device=dev),
-                pooled=torch.empty((B, H), dtype=f16, device=dev),
-                # [CLS]-row buffers of the last layer
-                c_ctx=torch.empty((B, H), dtype=f16, device=dev), c_res=torch.empty((B, H), dtype=f16, device=dev),
-                c_tmp=torch.empty((B, H), dtype=f16, device=dev), c_h1=torch.empty((B, H), dtype=f16, device=dev),
-                c_ff=torch.empty((B, I), dtype=f16, device=dev), c_h=torch.empty((B, H), dtype=f16, device=dev),
-                cu=torch.zeros((B + 1,), dtype=torch.int32, device=dev))     # packed-layout sequence offsets
-            if len(self._ws) > 8:
-                self._ws.clear()
-            self._ws[key] = ws
-        return ws
-
     @torch.no_grad()
     def encode(self, input_ids, input_mask, is_query_embed, check_mask=True, seq_lens_host=None):
-        """[B,S] ids + right-padded bool mask -> [B,128] embeddings.
+        """[B,S] ids + right-padded bool mask -> [B,128] embeddings (proqa_encoder_forward).
 
         Padding is not computed when the sequence lengths are known on the host: tokens are packed
         back to back ([T, hidden], T = sum of lengths) for every per-token operator, the embedding
@@ -218,19 +223,16 @@ class BertForRetriever:
             raise RuntimeError("get_embed expects CUDA tensors (the reference feeds move_to_cuda(batch))")
         tw = self.towers[bool(is_query_embed)]
         cfg = self.config
-        lib, chk = self._lib, _lib.check
         B, S = input_ids.shape
         if S > cfg.max_position_embeddings:
             raise ValueError(f"sequence length {S} exceeds max_position_embeddings {cfg.max_position_embeddings}")
-        H, I, NH = cfg.hidden_size, cfg.intermediate_size, cfg.num_attention_heads
-        eps = float(cfg.layer_norm_eps)
         out = torch.empty((B, EMBED_DIM), dtype=self.out_dtype, device=self.device)
         if B == 0:
             return out
         ids = input_ids.contiguous().to(torch.int64)
         mask = input_mask.to(torch.bool)
         lens = mask.sum(dim=1).to(torch.int32).contiguous()
-        n_valid = None
+        n_valid = -1
         if seq_lens_host is not None:
             n_valid = int(sum(int(v) for v in seq_lens_host))
         if check_mask:
@@ -239,86 +241,14 @@ class BertForRetriever:
             probe = torch.stack([bad.to(torch.int64), lens.sum(dtype=torch.int64)]).cpu()   # one host round trip
             if bool(probe[0]):
                 raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
-            if n_valid is not None and n_valid != int(probe[1]):
+            if n_valid >= 0 and n_valid != int(probe[1]):
                 raise ValueError("seq_lens_host does not match input_mask")
             n_valid = int(probe[1])
-        n = B * S
-        packed = self.pack_tokens and n_valid is not None and 0 < n_valid < n
-        ws = self._buffers(B, S)
+        flags = (_lib.ENC_CLS_ONLY_LAST if self.cls_only_last_layer else 0) | (_lib.ENC_PACKED if self.pack_tokens else 0)
         with torch.cuda.device(self.device):
-            st = _lib.current_stream_ptr()
-            if packed:
-                n = n_valid
-                cu = ws.cu                                       # cu[0] stays 0
-                torch.cumsum(lens, 0, dtype=torch.int32, out=cu[1:])
-                cu_ptr = cu.data_ptr()
-                chk(lib.proqa_embed_layernorm_varlen_f16(ids.data_ptr(), cu_ptr, B, S, H, tw.word.data_ptr(),
-                                                         tw.word.shape[0], tw.pos.data_ptr(), tw.type0.data_ptr(),
-                                                         tw.emb_g.data_ptr(), tw.emb_b.data_ptr(), eps,
-                                                         ws.h.data_ptr(), st))
-            else:
-                chk(lib.proqa_embed_layernorm_f16(ids.data_ptr(), n, S, H, tw.word.data_ptr(), tw.word.shape[0],
-                                                  tw.pos.data_ptr(), tw.type0.data_ptr(), tw.emb_g.data_ptr(),
-                                                  tw.emb_b.data_ptr(), eps, ws.h.data_ptr(), st))
-            # row-prefix views of the workspaces: B*S (padded) or the number of valid tokens (packed), rounded
-            # up to the GEMM tile so that hipBLASLt stays on its full-tile kernels for ragged batches
-            if n > 8 * ROW_TILE:                      # small batches: nothing to gain, keep them small
-                n = -(-n // ROW_TILE) * ROW_TILE
-            h, h1, qkv, ctx, tmp, ff = ws.h[:n], ws.h1[:n], ws.qkv[:n], ws.ctx[:n], ws.tmp[:n], ws.ff[:n]
-
-            def attention(cls_only, dst):
-                if packed:
-                    fn = lib.proqa_attention_cls_varlen_f16 if cls_only else lib.proqa_attention_varlen_f16
-                    chk(fn(qkv.data_ptr(), cu_ptr, B, S, NH, dst.data_ptr(), st))
-                else:
-                    fn = lib.proqa_attention_cls_f16 if cls_only else lib.proqa_attention_f16
-                    chk(fn(qkv.data_ptr(), lens.data_ptr(), B, S, NH, dst.data_ptr(), st))
-
-            full_layers = tw.layers[:-1] if self.cls_only_last_layer else tw.layers
-            for L in full_layers:
-                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=qkv)                          # fused Q|K|V projection
-                attention(False, ctx)
-                torch.mm(ctx, L.ao_w.t(), out=tmp)
-                chk(lib.proqa_bias_residual_layernorm_f16(tmp.data_ptr(), L.ao_b.data_ptr(), h.data_ptr(),
-                                                          L.ln1_g.data_ptr(), L.ln1_b.data_ptr(), eps, n, H,
-                                                          h1.data_ptr(), st))
-                torch.mm(h1, L.ff1_w.t(), out=ff)
-                chk(lib.proqa_bias_gelu_f16(ff.data_ptr(), L.ff1_b.data_ptr(), n, I, st))
-                torch.mm(ff, L.ff2_w.t(), out=tmp)
-                chk(lib.proqa_bias_residual_layernorm_f16(tmp.data_ptr(), L.ff2_b.data_ptr(), h1.data_ptr(),
-                                                          L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, n, H,
-                                                          h.data_ptr(), st))
-
-            def cls_rows(dst):
-                # h[:, 0] of every sequence -> dst [B, H]
-                if packed:
-                    torch.index_select(h, 0, cu[:-1], out=dst)
-                else:
-                    dst.copy_(h[:B * S].view(B, S, H)[:, 0])   # h may carry GEMM-tile padding rows
-
-            if self.cls_only_last_layer:
-                # the pooler reads h[:, 0] only (retriever.py:41-42): the last layer needs K and V of every
-                # token but the attention output, both dense blocks and LayerNorms for the [CLS] rows alone
-                L = tw.layers[-1]
-                torch.addmm(L.qkv_b, h, L.qkv_w.t(), out=qkv)
-                attention(True, ws.c_ctx)
-                cls_rows(ws.c_res)
-                torch.mm(ws.c_ctx, L.ao_w.t(), out=ws.c_tmp)
-                chk(lib.proqa_bias_residual_layernorm_f16(ws.c_tmp.data_ptr(), L.ao_b.data_ptr(), ws.c_res.data_ptr(),
-                                                          L.ln1_g.data_ptr(), L.ln1_b.data_ptr(), eps, B, H,
-                                                          ws.c_h1.data_ptr(), st))
-                torch.mm(ws.c_h1, L.ff1_w.t(), out=ws.c_ff)
-                chk(lib.proqa_bias_gelu_f16(ws.c_ff.data_ptr(), L.ff1_b.data_ptr(), B, I, st))
-                torch.mm(ws.c_ff, L.ff2_w.t(), out=ws.c_tmp)
-                chk(lib.proqa_bias_residual_layernorm_f16(ws.c_tmp.data_ptr(), L.ff2_b.data_ptr(), ws.c_h1.data_ptr(),
-                                                          L.ln2_g.data_ptr(), L.ln2_b.data_ptr(), eps, B, H,
-                                                          ws.c_h.data_ptr(), st))
-            else:
-                cls_rows(ws.c_h)
-            chk(lib.proqa_pool_project_f16(ws.c_h.data_ptr(), B, 1, H, tw.pool_w.data_ptr(), tw.pool_b.data_ptr(),
-                                           tw.proj_w.data_ptr(), tw.proj_b.data_ptr(), ws.pooled.data_ptr(),
-                                           out.data_ptr(),
-                                           PROQA_F16 if self.out_dtype == torch.float16 else PROQA_F32, st))
+            _lib.check(self._lib.proqa_encoder_forward(
+                tw._handle, ids.data_ptr(), lens.data_ptr(), B, S, n_valid, flags, out.data_ptr(),
+                PROQA_F16 if self.out_dtype == torch.float16 else PROQA_F32, _lib.current_stream_ptr()))
         return out
 
 
