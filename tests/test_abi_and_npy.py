@@ -45,6 +45,22 @@ def test_error_reporting_without_compute():
         _lib.check(rc)
 
 
+def test_encoder_abi_rejects_bad_models_without_a_gpu():
+    """proqa_encoder_create validates the weight table before touching the device."""
+    import ctypes
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.proqa_encoder_create(None, ctypes.byref(h)) == -1 and b"NULL argument" in lib.proqa_last_error()
+    bw = _lib.BertWeights(hidden=100, n_layers=1, n_heads=2, intermediate=64, max_position=8, vocab=10,
+                          layer_norm_eps=1e-12)
+    assert lib.proqa_encoder_create(ctypes.byref(bw), ctypes.byref(h)) == -1
+    assert b"head_dim 64" in lib.proqa_last_error()
+    bw.hidden = 128
+    assert lib.proqa_encoder_create(ctypes.byref(bw), ctypes.byref(h)) == -1      # no layer table / NULL weights
+    assert not h.value
+    assert lib.proqa_encoder_free(None) == 0
+
+
 def test_npy_reader_matches_numpy_files():
     for name, dtype in [("npy_f2.npy", np.float16), ("npy_f4.npy", np.float32)]:
         path = os.path.join(GOLDEN, name)
