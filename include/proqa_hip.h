@@ -210,6 +210,14 @@ int proqa_attention_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens
                                int max_seq_len, int n_heads, void* ctx_packed_out, void* stream);
 int proqa_attention_cls_varlen_f16(const void* qkv_packed, const int32_t* cu_seqlens_dev, int batch,
                                    int max_seq_len, int n_heads, void* ctx_cls_out, void* stream);
+/* general form of the four entry points above, with the bias of the fused Q|K|V projection folded in
+ * (qkv_bias [3*hidden] fp16 or NULL): the query bias is added to the query fragments, the key bias is
+ * dropped (it shifts all scores of a query by the same amount: softmax-invariant), the value bias is
+ * added to the output (probabilities sum to 1).  Exactly one of seq_lens_dev (padded layout) and
+ * cu_seqlens_dev (packed layout) is non-NULL; cls_only selects the [batch, hidden] row-0 output. */
+int proqa_attention_ex_f16(const void* qkv, const void* qkv_bias, const int32_t* seq_lens_dev,
+                           const int32_t* cu_seqlens_dev, int batch, int seq_len, int n_heads, int cls_only,
+                           void* out, void* stream);
 
 /* x = gelu_erf(x + bias) in place, x [rows, cols] (BertIntermediate, hidden_act='gelu') */
 int proqa_bias_gelu_f16(void* x, const void* bias, int64_t rows, int cols, void* stream);

@@ -41,13 +41,10 @@ constexpr int kOutStride = kHeadDim + 8;
 // Token layout: padded ([B, seq_len] rows, cu_seqlens == nullptr, seq_lens = valid keys per sequence) or
 // packed (cu_seqlens[b] = first token row of sequence b, no padding rows exist; seq_len = longest sequence).
 // qkv_bias (nullable): the [3*hidden] bias of the fused Q|K|V projection, added here when the GEMM that
-// produced qkv had no bias epilogue (proqa_encoder_forward: rocBLAS) -- in fp32, rounded once to fp16.
+// produced qkv had no bias epilogue (proqa_encoder_forward: rocBLAS).  Packed fp16 adds: the sum of two
+// fp16 values rounded once to fp16 is exactly what an fp32 add followed by a conversion gives.
 __device__ __forceinline__ f16x8 add_bias8(f16x8 v, const _Float16* __restrict__ bias) {
-  if (bias) {
-    const f16x8 b = *(const f16x8*)bias;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (_Float16)((float)v[e] + (float)b[e]);
-  }
+  if (bias) v = v + *(const f16x8*)bias;
   return v;
 }
 
@@ -75,18 +72,22 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   const int n_ktiles = (len + 31) >> 5;
   const int rows_avail = cu_seqlens ? len : seq_len;   // token rows of this sequence that exist in memory
   const _Float16* bias_q = qkv_bias ? qkv_bias + head * kHeadDim : nullptr;
-  const _Float16* bias_k = qkv_bias ? qkv_bias + hidden + head * kHeadDim : nullptr;
   const _Float16* bias_v = qkv_bias ? qkv_bias + 2 * hidden + head * kHeadDim : nullptr;
 
   const int tid = threadIdx.x;
-  // stage K and V rows [0, n_ktiles*32): 8 lanes cover one 128-byte row
+  // stage K and V rows [0, n_ktiles*32): 8 lanes cover one 128-byte row.
+  // The projection bias (qkv_bias) costs nothing here: (q+bq).(k+bk) = (q+bq).k + (q+bq).bk, and the second
+  // term is the same for every key of a query, so the softmax ignores it -- the key bias is dropped; the
+  // probabilities sum to 1, so sum_j p_j (v_j + bv) = sum_j p_j v_j + bv -- the value bias is added to the
+  // finished output; only the query bias is added to the (register-resident) query fragments.
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = tid; i < n_ktiles * 32 * 8; i += 256) {
     const int row = i >> 3, c = i & 7;
-    f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+    f16x8 kv = zero8, vv = zero8;
     if (row < rows_avail) {
       const _Float16* src = base + row * row_stride + c * 8;
-      kv = add_bias8(*(const f16x8*)(src + hidden), bias_k ? bias_k + c * 8 : nullptr);
-      vv = add_bias8(*(const f16x8*)(src + 2 * hidden), bias_v ? bias_v + c * 8 : nullptr);
+      kv = *(const f16x8*)(src + hidden);
+      vv = *(const f16x8*)(src + 2 * hidden);
     }
     *(f16x8*)(k_lds + row * kKStride + c * 8) = kv;
 #pragma unroll
@@ -99,6 +100,9 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   const int li = lane & 31;
   const int half = lane >> 5;
   const int n_qblocks = (rows_avail + 31) >> 5;
+
+  // value bias of the 16-byte output piece this lane stores (piece = lane & 7 in write_out)
+  const f16x8 bv8 = bias_v ? *(const f16x8*)(bias_v + (lane & 7) * 8) : zero8;
 
   auto write_out = [&](int qb, const f32x16& o0, const f32x16& o1, float l) {
     const float inv = 1.0f / l;
@@ -118,12 +122,15 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), piece = lane & 7;   // 8 lanes x 16 B = one 128-byte row
       const int qq = qb * 32 + row;
-      const f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8);
+      const f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8) + bv8;
       if (qq < rows_avail)
         *(f16x8*)(ctx + (tok0 + qq) * hidden + head * kHeadDim + piece * 8) = v;
     }
   };
 
+  f16x8 bq8[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) bq8[j] = bias_q ? *(const f16x8*)(bias_q + (2 * j + half) * 8) : zero8;
   for (int qb = wave; qb < n_qblocks; qb += 4) {
     const int q = qb * 32 + li;
     // Q fragments (MFMA B operand): 16-byte pieces 2j+half of the lane's query row
@@ -131,9 +138,7 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[j] = q < rows_avail ? add_bias8(*(const f16x8*)(base + q * row_stride + (2 * j + half) * 8),
-                                         bias_q ? bias_q + (2 * j + half) * 8 : nullptr)
-                             : z;
+      qf[j] = q < rows_avail ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) + bq8[j] : z;
     }
     float m = -__builtin_inff();
     float l = 0.f;
@@ -358,4 +363,13 @@ extern "C" int proqa_attention_cls_varlen_f16(const void* qkv_packed, const int3
                                               int max_seq_len, int n_heads, void* ctx_cls_out, void* stream) {
   if (!cu_seqlens_dev) return fail(PROQA_EINVAL, "attention_cls_varlen: NULL cu_seqlens");
   return launch_attention_cls(qkv_packed, nullptr, nullptr, cu_seqlens_dev, batch, max_seq_len, n_heads, ctx_cls_out, stream);
+}
+
+extern "C" int proqa_attention_ex_f16(const void* qkv, const void* qkv_bias, const int32_t* seq_lens_dev,
+                                      const int32_t* cu_seqlens_dev, int batch, int seq_len, int n_heads, int cls_only,
+                                      void* out, void* stream) {
+  if ((seq_lens_dev != nullptr) == (cu_seqlens_dev != nullptr))
+    return fail(PROQA_EINVAL, "attention_ex: pass exactly one of seq_lens (padded layout) and cu_seqlens (packed layout)");
+  return cls_only ? launch_attention_cls(qkv, qkv_bias, seq_lens_dev, cu_seqlens_dev, batch, seq_len, n_heads, out, stream)
+                  : launch_attention(qkv, qkv_bias, seq_lens_dev, cu_seqlens_dev, batch, seq_len, n_heads, out, stream);
 }

@@ -205,6 +205,40 @@ def test_attention_packed_layout(lib, gpu_device, B, S, NH):
     close(cls, ref[:, 0], rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("packed", [False, True])
+def test_attention_with_projection_bias(lib, gpu_device, packed):
+    """qkv_bias folded into the kernel (query bias added, key bias dropped, value bias on the output)
+    equals attention on qkv + bias, for the full and the [CLS]-only kernels, both layouts."""
+    from proqa_amd import _lib
+    rng = np.random.default_rng(77)
+    B, S, NH = 5, 96, 3
+    H = NH * 64
+    lens = np.array([96, 1, 40, 77, 13], np.int32)
+    bias = (0.5 * rng.standard_normal(3 * H)).astype(np.float16)
+    padded = np.zeros((B, S, 3 * H), np.float16)
+    for b in range(B):
+        padded[b, :lens[b]] = rng.standard_normal((lens[b], 3 * H)).astype(np.float16)
+    ref = attention_ref((padded.astype(np.float32) + bias.astype(np.float32)).astype(np.float16).reshape(B * S, -1),
+                        lens, B, S, NH)
+    tb = dev16(bias, gpu_device)
+    if packed:
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        tq = dev16(np.concatenate([padded[b, :lens[b]] for b in range(B)]), gpu_device)
+        tl, tcu, T = None, torch.from_numpy(cu).to(gpu_device), int(cu[-1])
+    else:
+        tq, tl, tcu, T = dev16(padded.reshape(B * S, -1), gpu_device), torch.from_numpy(lens).to(gpu_device), None, B * S
+    out = torch.empty((T, H), dtype=torch.float16, device=gpu_device)
+    cls = torch.empty((B, H), dtype=torch.float16, device=gpu_device)
+    for cls_only, dst in ((0, out), (1, cls)):
+        _lib.check(lib.proqa_attention_ex_f16(tq.data_ptr(), tb.data_ptr(), tl.data_ptr() if tl is not None else None,
+                                              tcu.data_ptr() if tcu is not None else None, B, S, NH, cls_only,
+                                              dst.data_ptr(), stream()))
+    for b in range(B):
+        rows = out[cu[b]:cu[b + 1]] if packed else out.view(B, S, H)[b, :lens[b]]
+        close(rows, ref[b, :lens[b]], rtol=4e-3, atol=4e-3)
+    close(cls, ref[:, 0], rtol=4e-3, atol=4e-3)
+
+
 def test_embed_layernorm_packed_layout(lib, gpu_device):
     from proqa_amd import _lib
     rng = np.random.default_rng(4)
