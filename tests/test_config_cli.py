@@ -38,3 +38,22 @@ def test_main_argument_errors_need_no_gpu():
         get_embed.main(["--do_predict", "--accumulate_gradients", "0"])
     with pytest.raises(SystemExit):
         get_embed.main(["--bogus"])
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """oracle/ is test infrastructure: nothing under proqa_amd/ (or the root CLI shims) may import it, and
+    nothing shipped may read /root/reference at run time."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, f) for f in ("get_embed.py", "eval_retrieval.py", "group_paras.py")]
+    for d, _, names in os.walk(os.path.join(root, "proqa_amd")):
+        files += [os.path.join(d, n) for n in names if n.endswith((".py", ".cpp", ".hip", ".h"))]
+    for path in files:
+        text = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), path
+        code = "\n".join(line.split("#")[0] for line in text.splitlines()) if path.endswith(".py") else ""
+        assert "open('/root/reference" not in code and 'open("/root/reference' not in code, path
+        assert "sys.path.insert(0, '/root/reference" not in code and 'sys.path.insert(0, "/root/reference' not in code, path
+    for path in (os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")):
+        assert "/root/reference" not in open(path).read(), path
