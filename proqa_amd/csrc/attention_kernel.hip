@@ -60,6 +60,11 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   const int vt_stride = s_pad + kVtPad;
   // per-wave output staging tile (aliasing it onto the K rows behind a barrier was measured slower)
   _Float16* out_lds = vt_lds + kHeadDim * vt_stride + (threadIdx.x >> 6) * 32 * kOutStride;
+  // [query bias (8 pieces of 16 B) | value bias (8 pieces)] of this head, zeros without a bias, kept in the 16
+  // padding bytes at the end of K rows 0..15 (never read by the fragment loads): neither registers nor
+  // dependent global loads sit on the short per-workgroup critical path, and the LDS footprint -- which
+  // decides 3 vs 2 workgroups per CU at S = 128 -- does not grow.  Piece t lives at bias_piece(t).
+  auto bias_piece = [&](int t) { return k_lds + t * kKStride + kHeadDim; };
 
   const int b = blockIdx.x / n_heads;
   const int head = blockIdx.x - b * n_heads;
@@ -81,6 +86,10 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   // probabilities sum to 1, so sum_j p_j (v_j + bv) = sum_j p_j v_j + bv -- the value bias is added to the
   // finished output; only the query bias is added to the (register-resident) query fragments.
   const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (tid < 16) {
+    const _Float16* src = tid < 8 ? bias_q : bias_v;
+    *(f16x8*)bias_piece(tid) = src ? *(const f16x8*)(src + (tid & 7) * 8) : zero8;
+  }
   for (int i = tid; i < n_ktiles * 32 * 8; i += 256) {
     const int row = i >> 3, c = i & 7;
     f16x8 kv = zero8, vv = zero8;
@@ -101,9 +110,6 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   const int half = lane >> 5;
   const int n_qblocks = (rows_avail + 31) >> 5;
 
-  // value bias of the 16-byte output piece this lane stores (piece = lane & 7 in write_out)
-  const f16x8 bv8 = bias_v ? *(const f16x8*)(bias_v + (lane & 7) * 8) : zero8;
-
   auto write_out = [&](int qb, const f32x16& o0, const f32x16& o1, float l) {
     const float inv = 1.0f / l;
 #pragma unroll
@@ -122,15 +128,12 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
     for (int it = 0; it < 4; ++it) {
       const int row = it * 8 + (lane >> 3), piece = lane & 7;   // 8 lanes x 16 B = one 128-byte row
       const int qq = qb * 32 + row;
-      const f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8) + bv8;
+      const f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8) + *(const f16x8*)bias_piece(8 + piece);
       if (qq < rows_avail)
         *(f16x8*)(ctx + (tok0 + qq) * hidden + head * kHeadDim + piece * 8) = v;
     }
   };
 
-  f16x8 bq8[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) bq8[j] = bias_q ? *(const f16x8*)(bias_q + (2 * j + half) * 8) : zero8;
   for (int qb = wave; qb < n_qblocks; qb += 4) {
     const int q = qb * 32 + li;
     // Q fragments (MFMA B operand): 16-byte pieces 2j+half of the lane's query row
@@ -138,8 +141,12 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[j] = q < rows_avail ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) + bq8[j] : z;
+      qf[j] = q < rows_avail ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) : z;
     }
+    // query bias: a separate, unconditional pass (the four global loads above stay back to back; rows past
+    // the sequence get bias-only fragments whose outputs are never stored)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[j] = qf[j] + *(const f16x8*)bias_piece(2 * j + half);
     float m = -__builtin_inff();
     float l = 0.f;
     f32x16 o0 = {0}, o1 = {0};
