@@ -173,7 +173,7 @@ def encode_leg(args, device, world, rank):
     mask = torch.ones((B, S), dtype=torch.bool, device=device)
     batch = {"input_ids": ids, "input_mask": mask}
     outs = []
-    # same stream discipline as proqa_amd.get_embed.predict: ONE compute stream (concurrent hipBLASLt
+    # same stream discipline as proqa_amd.get_embed.predict: ONE compute stream (concurrent
     # stream-K GEMMs on two streams deadlock on ragged batch sizes; see N_STREAMS there)
     n_streams = int(os.environ.get("PROQA_ENCODE_STREAMS", "1"))
     streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
@@ -204,7 +204,7 @@ def encode_leg(args, device, world, rank):
                      "frac": tf / PEAK_MFMA_F16_TFLOPS, "traffic": None,
                      "gflop_per_passage_executed": executed, "gflop_per_passage_reference": ENCODE_GFLOP_PER_PASSAGE,
                      "note": "flops executed per step / step time (the last layer is evaluated on the [CLS] rows "
-                             "only); the dense-layer GEMMs are hipBLASLt"},
+                             "only); the dense-layer GEMMs are rocBLAS calls made by libproqa_hip.so"},
     }
     # variable-length variant: lengths ~ U[32, S], right-padded as em_collate does;
     # the lengths are known on the host (predict() takes them from the collated batch), padding is skipped

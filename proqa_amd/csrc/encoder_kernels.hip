@@ -1,7 +1,7 @@
 // Non-GEMM kernels of the BERT tower behind BertForRetriever.get_embed
 // (/root/reference/retrieval/retriever.py:33-43; the arithmetic is transformers' BertModel:
 // embeddings -> 12 x {self-attention, output dense+LN, FFN} -> pooler, then proj_{q,c}).
-// The dense 768x768 / 768x3072 projections stay on PyTorch-ROCm (hipBLASLt); everything
+// The dense 768x768 / 768x3072 projections are rocBLAS GEMMs issued by encoder.cpp; everything
 // between them is here.  Activations are fp16 in HBM, statistics fp32.
 //
 // All row-wise kernels use one wave64 per row with 16-byte (8 x fp16) accesses per lane: at

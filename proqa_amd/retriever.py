@@ -72,7 +72,7 @@ class _Tower:
             p = f"{prefix}.encoder.layer.{i}"
             qkv_w = torch.cat([w(f"{p}.attention.self.{n}.weight") for n in ("query", "key", "value")], 0)
             qkv_b = torch.cat([w(f"{p}.attention.self.{n}.bias") for n in ("query", "key", "value")], 0)
-            # weights stay in nn.Linear's [out, in] layout: x @ W.t() is hipBLASLt's "TN" GEMM, measured
+            # weights stay in nn.Linear's [out, in] layout: x @ W.t() is the BLAS "TN" GEMM, measured
             # 12-19 % faster at these shapes than the pre-transposed "NN" form (scripts/dev_gemm_timing.py)
             self.layers.append(SimpleNamespace(
                 qkv_w=qkv_w.contiguous(), qkv_b=qkv_b.contiguous(),                 # [3H, H]
