@@ -237,6 +237,30 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
     }
   };
 
+  // A wave none of whose queries can log (padding beyond nq, queries a paged search has exhausted: threshold
+  // +inf) only helps streaming the corpus: it issues its share of every stage's DMA and meets the barriers,
+  // but runs no MFMA / LDS-read / test work.  With <= 32 real queries 7 of the 8 waves are such waves and
+  // the launch becomes a pure HBM stream instead of an MFMA-bound scan of padding.
+  bool wave_live = false;
+#pragma unroll
+  for (int blk = 0; blk < QW; ++blk) wave_live = wave_live || (tau[blk] < __builtin_inff());
+  wave_live = __any(wave_live);
+  if (!wave_live) {
+    for (int s = 0; s < nstages; ++s) {
+      dma_wait_barrier();
+      if (s + 2 < nstages) issue_stage(s + 2, off2);
+      const int t = off0;
+      off0 = off1;
+      off1 = off2;
+      off2 = t;
+    }
+#pragma unroll
+    for (int blk = 0; blk < QW; ++blk)
+      a.store.lane_cnt[lane_list_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
+    if (lane == 0) a.store.spill_cnt[wave_slot] = 0u;
+    return;
+  }
+
   for (int s = 0; s < nstages; ++s) {
 #pragma unroll
     for (int u = 0; u < kSubs; ++u) {
