@@ -453,3 +453,27 @@ def test_online_retriever_is_the_exact_search(gpu_device):
         np.testing.assert_array_equal(emb, xb[Io[0]])
     idx, ids, emb = r.retrieve(q, 20000)                      # more than the index holds
     assert len(idx) == 9000 and emb.shape == (9000, 128)
+
+
+def test_integration_md_ctypes_stub_runs(gpu_device):
+    """The C-ABI binding printed in INTEGRATION.md section 3 is executed verbatim (in a fresh process, from
+    the repo root) and must return the oracle's result."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"## 3\..*?```python\n(.*?)```", md, re.S).group(1)
+    prog = block + '''
+import numpy as np, sys
+sys.path.insert(0, ".")
+from oracle import search_oracle
+rng = np.random.default_rng(0)
+xb = rng.integers(-4, 5, (3000, 128)).astype(np.float16); xq = rng.integers(-4, 5, (17, 128)).astype(np.float16)
+D, I = search(xb, xq, 80)
+Do, Io = search_oracle.topk_ip(xq, xb, 80)
+assert (I == Io).all() and (D == Do).all()
+print("stub ok")
+'''
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0 and "stub ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
