@@ -166,6 +166,8 @@ def encode_leg(args, device, world, rank):
     sd = random_state_dict(BERT_BASE, seed=0)
     model = BertForRetriever(BERT_BASE, device=device)
     model.load_state_dict(sd)
+    if os.environ.get("PROQA_TUNE_GEMM"):          # opt-in rocBLAS solution tuning (off in the default run)
+        model.tune_gemms(True)
     g = torch.Generator(device=device)
     g.manual_seed(rank)
     ids = torch.randint(1000, 30522, (B, S), generator=g, device=device, dtype=torch.int64)

@@ -163,6 +163,10 @@ typedef struct proqa_encoder proqa_encoder;
 
 int proqa_encoder_create(const proqa_bert_weights* w, proqa_encoder** out);
 int proqa_encoder_free(proqa_encoder* enc);
+/* opt-in (off by default): the first forward that meets a large GEMM shape times every rocBLAS solution for
+ * it on the real operands (~0.3 s per shape) and keeps the winner if an interleaved re-match confirms >= 2 %;
+ * same arithmetic (fp16 in, fp32 accumulate), possibly another summation order. */
+int proqa_encoder_set_gemm_tuning(proqa_encoder* enc, int enable);
 /* ids_dev: [batch, seq_len] int64, right-padded (retrieval/datasets.py:29-45); seq_lens_dev: [batch]
  * int32 valid lengths (>= 1); n_valid_tokens: their sum if the host knows it, else -1 (then the
  * padded layout is evaluated whatever the flags say); out: [batch, 128] of out_dtype.

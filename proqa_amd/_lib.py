@@ -86,6 +86,7 @@ SIGNATURES = {
                                         c_void_p, c_void_p]),
     "proqa_encoder_create": (c_int, [ctypes.POINTER(BertWeights), ctypes.POINTER(c_void_p)]),
     "proqa_encoder_free": (c_int, [c_void_p]),
+    "proqa_encoder_set_gemm_tuning": (c_int, [c_void_p, c_int]),
     "proqa_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p]),
     "proqa_embed_layernorm_f16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64,

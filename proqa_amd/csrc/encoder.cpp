@@ -3,10 +3,14 @@
 // Replaces /root/reference/retrieval/retriever.py:33-43 (+ transformers BertModel).  The dense layers are
 // rocBLAS GEMMs (rocblas_gemm_ex, fp16 in / fp32 accumulate; the library resolves them against the
 // rocBLAS of the process, see proqa_amd/_lib.py); everything else is the HIP kernels of this library.
+#define ROCBLAS_BETA_FEATURES_API   // rocblas_gemm_ex_get_solutions (opt-in tuning only)
 #include <rocblas/rocblas.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <map>
 #include <new>
+#include <tuple>
 #include <vector>
 
 #include "attention.h"
@@ -16,6 +20,7 @@ using namespace proqa;
 
 namespace {
 
+constexpr size_t kMaxTunedShapes = 32;
 constexpr int kRowTile = 256;  // token rows handed to the GEMMs are a multiple of the macro-tile (when large)
 
 struct Workspace {
@@ -37,6 +42,9 @@ struct proqa_encoder {
   rocblas_handle blas = nullptr;
   Workspace ws;
   int device = 0;
+  // opt-in GEMM solution tuning (proqa_encoder_set_gemm_tuning): shape -> rocBLAS solution index (0 = default)
+  bool tune = false;
+  std::map<std::tuple<int64_t, int, int>, int> solution;
 };
 
 namespace {
@@ -51,12 +59,88 @@ int blas_fail(rocblas_status s, const char* what) {
   } while (0)
 
 // out[M,N] = x[M,K] . w[N,K]^T, row-major fp16, fp32 accumulate.  Column-major view: out'[N,M] = w'^T x'.
-int gemm_tn(proqa_encoder* e, const _Float16* x, const void* w, _Float16* out, int64_t M, int N, int K) {
-  if (M == 0) return PROQA_OK;
+rocblas_status gemm_call(proqa_encoder* e, const _Float16* x, const void* w, _Float16* out, int64_t M, int N, int K,
+                         int solution) {
   const float alpha = 1.0f, beta = 0.0f;
-  PROQA_BLAS(rocblas_gemm_ex(e->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)M, K, &alpha, w,
-                             rocblas_datatype_f16_r, K, x, rocblas_datatype_f16_r, K, &beta, out, rocblas_datatype_f16_r,
-                             N, out, rocblas_datatype_f16_r, N, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0));
+  return rocblas_gemm_ex(e->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)M, K, &alpha, w,
+                         rocblas_datatype_f16_r, K, x, rocblas_datatype_f16_r, K, &beta, out, rocblas_datatype_f16_r, N, out,
+                         rocblas_datatype_f16_r, N, rocblas_datatype_f32_r,
+                         solution ? rocblas_gemm_algo_solution_index : rocblas_gemm_algo_standard, solution, 0);
+}
+
+// Median-of-`reps` time (ms) of `calls` back-to-back launches of one solution on the encoder's stream.
+float time_solution(proqa_encoder* e, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const _Float16* x, const void* w,
+                    _Float16* out, int64_t M, int N, int K, int solution, int reps, int calls) {
+  std::vector<float> t;
+  for (int r = 0; r < reps; ++r) {
+    (void)hipEventRecord(e0, st);
+    for (int c = 0; c < calls; ++c)
+      if (gemm_call(e, x, w, out, M, N, K, solution) != rocblas_status_success) return 1e30f;
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    t.push_back(ms / calls);
+  }
+  std::sort(t.begin(), t.end());
+  return t[t.size() / 2];
+}
+
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wdeprecated-declarations"   // the solution-listing call is a rocBLAS "beta" API
+// Opt-in: the first time a large shape is seen, every solution rocBLAS lists for it is timed on the real operands
+// (the output buffer is overwritten by the real call afterwards) and the winner replaces the library's default
+// only if an interleaved re-match confirms >= 2 % (measurement noise is of that order).
+int tune_shape(proqa_encoder* e, hipStream_t st, const _Float16* x, const void* w, _Float16* out, int64_t M, int N, int K) {
+  const float alpha = 1.0f, beta = 0.0f;
+  rocblas_int n = 0;
+  if (rocblas_gemm_ex_get_solutions(e->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)M, K, &alpha,
+                                    w, rocblas_datatype_f16_r, K, x, rocblas_datatype_f16_r, K, &beta, out,
+                                    rocblas_datatype_f16_r, N, out, rocblas_datatype_f16_r, N, rocblas_datatype_f32_r,
+                                    rocblas_gemm_algo_solution_index, 0, nullptr, &n) != rocblas_status_success || n <= 0)
+    return 0;
+  std::vector<rocblas_int> sols(n);
+  if (rocblas_gemm_ex_get_solutions(e->blas, rocblas_operation_transpose, rocblas_operation_none, N, (rocblas_int)M, K, &alpha,
+                                    w, rocblas_datatype_f16_r, K, x, rocblas_datatype_f16_r, K, &beta, out,
+                                    rocblas_datatype_f16_r, N, out, rocblas_datatype_f16_r, N, rocblas_datatype_f32_r,
+                                    rocblas_gemm_algo_solution_index, 0, sols.data(), &n) != rocblas_status_success)
+    return 0;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0;
+  int best = 0;
+  float best_ms = 1e30f;
+  for (rocblas_int s : sols) {
+    const float ms = time_solution(e, st, e0, e1, x, w, out, M, N, K, s, 3, 4);
+    if (ms < best_ms) {
+      best_ms = ms;
+      best = s;
+    }
+  }
+  // re-match against the default, interleaved
+  float d = 0.f, b = 0.f;
+  for (int r = 0; r < 5 && best; ++r) {
+    d += time_solution(e, st, e0, e1, x, w, out, M, N, K, 0, 1, 8);
+    b += time_solution(e, st, e0, e1, x, w, out, M, N, K, best, 1, 8);
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return (best && b < 0.98f * d) ? best : 0;
+}
+#pragma clang diagnostic pop
+
+int gemm_tn(proqa_encoder* e, const _Float16* x, const void* w, _Float16* out, int64_t M, int N, int K, hipStream_t st) {
+  if (M == 0) return PROQA_OK;
+  int solution = 0;
+  if (e->tune && M >= 4096) {
+    const auto key = std::make_tuple(M, N, K);
+    auto it = e->solution.find(key);
+    // at most kMaxTunedShapes shapes are tuned per encoder (~0.3-1 s each): corpora with ever-changing packed
+    // row counts fall back to the library's default once the budget is spent
+    if (it == e->solution.end() && e->solution.size() < kMaxTunedShapes)
+      it = e->solution.emplace(key, tune_shape(e, st, x, w, out, M, N, K)).first;
+    solution = it == e->solution.end() ? 0 : it->second;
+  }
+  PROQA_BLAS(gemm_call(e, x, w, out, M, N, K, solution));
   return PROQA_OK;
 }
 
@@ -137,6 +221,12 @@ int proqa_encoder_create(const proqa_bert_weights* w, proqa_encoder** out) {
   return PROQA_OK;
 }
 
+int proqa_encoder_set_gemm_tuning(proqa_encoder* e, int enable) {
+  if (!e) return fail(PROQA_EINVAL, "encoder_set_gemm_tuning: NULL handle");
+  e->tune = enable != 0;
+  return PROQA_OK;
+}
+
 int proqa_encoder_free(proqa_encoder* e) {
   if (!e) return PROQA_OK;
   if (e->ws.base) (void)hipFree(e->ws.base);
@@ -188,13 +278,13 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
   const int n_full = cls_only ? w.n_layers - 1 : w.n_layers;
   for (int l = 0; l < n_full; ++l) {
     const proqa_bert_layer& L = w.layers[l];
-    if (int rc = gemm_tn(e, h, L.qkv_w, ws.qkv, rows, 3 * H, H)) return rc;                       // fused Q|K|V projection
+    if (int rc = gemm_tn(e, h, L.qkv_w, ws.qkv, rows, 3 * H, H, st)) return rc;                       // fused Q|K|V projection
     if (int rc = launch_attention(ws.qkv, L.qkv_b, lens, cu, batch, seq_len, NH, ws.ctx, stream)) return rc;
-    if (int rc = gemm_tn(e, ws.ctx, L.ao_w, ws.tmp, rows, H, H)) return rc;
+    if (int rc = gemm_tn(e, ws.ctx, L.ao_w, ws.tmp, rows, H, H, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.tmp, L.ao_b, h, L.ln1_g, L.ln1_b, eps, rows, H, h1, stream)) return rc;
-    if (int rc = gemm_tn(e, h1, L.ff1_w, ws.ff, rows, I, H)) return rc;
+    if (int rc = gemm_tn(e, h1, L.ff1_w, ws.ff, rows, I, H, st)) return rc;
     if (int rc = proqa_bias_gelu_f16(ws.ff, L.ff1_b, rows, I, stream)) return rc;
-    if (int rc = gemm_tn(e, ws.ff, L.ff2_w, ws.tmp, rows, H, I)) return rc;
+    if (int rc = gemm_tn(e, ws.ff, L.ff2_w, ws.tmp, rows, H, I, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.tmp, L.ff2_b, h1, L.ln2_g, L.ln2_b, eps, rows, H, h, stream)) return rc;
   }
   // h[:, 0] of every sequence -> dst [batch, H]
@@ -205,15 +295,15 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
     // the pooler reads h[:, 0] only (retriever.py:41-42): the last layer needs K and V of every token but the
     // attention output, both dense blocks and LayerNorms for the [CLS] rows alone
     const proqa_bert_layer& L = w.layers[w.n_layers - 1];
-    if (int rc = gemm_tn(e, h, L.qkv_w, ws.qkv, rows, 3 * H, H)) return rc;
+    if (int rc = gemm_tn(e, h, L.qkv_w, ws.qkv, rows, 3 * H, H, st)) return rc;
     if (int rc = launch_attention_cls(ws.qkv, L.qkv_b, lens, cu, batch, seq_len, NH, ws.c_ctx, stream)) return rc;
     if (int rc = cls_rows(ws.c_res)) return rc;
-    if (int rc = gemm_tn(e, ws.c_ctx, L.ao_w, ws.c_tmp, batch, H, H)) return rc;
+    if (int rc = gemm_tn(e, ws.c_ctx, L.ao_w, ws.c_tmp, batch, H, H, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.c_tmp, L.ao_b, ws.c_res, L.ln1_g, L.ln1_b, eps, batch, H, ws.c_h1, stream))
       return rc;
-    if (int rc = gemm_tn(e, ws.c_h1, L.ff1_w, ws.c_ff, batch, I, H)) return rc;
+    if (int rc = gemm_tn(e, ws.c_h1, L.ff1_w, ws.c_ff, batch, I, H, st)) return rc;
     if (int rc = proqa_bias_gelu_f16(ws.c_ff, L.ff1_b, batch, I, stream)) return rc;
-    if (int rc = gemm_tn(e, ws.c_ff, L.ff2_w, ws.c_tmp, batch, H, I)) return rc;
+    if (int rc = gemm_tn(e, ws.c_ff, L.ff2_w, ws.c_tmp, batch, H, I, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.c_tmp, L.ff2_b, ws.c_h1, L.ln2_g, L.ln2_b, eps, batch, H, ws.c_h, stream))
       return rc;
   } else {

@@ -168,6 +168,13 @@ class BertForRetriever:
         }
         return self
 
+    def tune_gemms(self, enable=True):
+        """Opt-in: let each tower pick, per large GEMM shape, the fastest rocBLAS solution (timed at the first
+        forward that meets the shape; proqa_encoder_set_gemm_tuning).  ~2 % on bert-base batches of 512 x 128."""
+        for tw in self.towers.values():
+            _lib.check(self._lib.proqa_encoder_set_gemm_tuning(tw._handle, 1 if enable else 0))
+        return self
+
     def to(self, device):
         device = torch.device(device)
         if device.type != "cuda":

@@ -384,3 +384,21 @@ def test_randomised_encoder_fuzz(gpu_device):
     out = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_fuzz_encoder.py"), "20", "11"],
                          capture_output=True, text=True, cwd=root, timeout=600)
     assert out.returncode == 0 and "encoder fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_gemm_tuning_keeps_the_numbers(gpu_device):
+    """Opt-in rocBLAS solution tuning changes at most the summation order of the dense layers."""
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE, config_from_dict
+    cfg = config_from_dict(dict(BERT_BASE, num_hidden_layers=2))
+    sd = {k: v.half().float() for k, v in random_state_dict(cfg, seed=5).items()}
+    model = BertForRetriever(cfg, device=gpu_device)
+    model.load_state_dict(sd)
+    rng = np.random.default_rng(2)
+    ids = torch.from_numpy(rng.integers(1000, 30522, (64, 128))).to(gpu_device)        # 8192 rows: tuned shapes
+    batch = {"input_ids": ids, "input_mask": torch.ones_like(ids, dtype=torch.bool)}
+    base = model.get_embed(batch, False)["embed"].float().cpu().numpy()
+    model.tune_gemms(True)
+    tuned = model.get_embed(batch, False)["embed"].float().cpu().numpy()
+    again = model.get_embed(batch, False)["embed"].float().cpu().numpy()
+    assert np.abs(tuned - base).max() < 3e-3
+    np.testing.assert_array_equal(tuned, again)
