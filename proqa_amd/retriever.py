@@ -238,10 +238,11 @@ class BertForRetriever:
             return out
         ids = input_ids.contiguous().to(torch.int64)
         mask = input_mask.to(torch.bool)
-        lens = mask.sum(dim=1).to(torch.int32).contiguous()
+        # a row without any valid token is evaluated as its first (padding) token, like the kernels' own clamp
+        lens = mask.sum(dim=1).clamp_(min=1).to(torch.int32).contiguous()
         n_valid = -1
         if seq_lens_host is not None:
-            n_valid = int(sum(int(v) for v in seq_lens_host))
+            n_valid = int(sum(max(int(v), 1) for v in seq_lens_host))
         if check_mask:
             # em_collate pads on the right: the mask of every row is a prefix of ones
             bad = (mask[:, 1:] & ~mask[:, :-1]).any() if S > 1 else torch.zeros((), dtype=torch.bool, device=mask.device)

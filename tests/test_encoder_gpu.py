@@ -402,3 +402,23 @@ def test_gemm_tuning_keeps_the_numbers(gpu_device):
     again = model.get_embed(batch, False)["embed"].float().cpu().numpy()
     assert np.abs(tuned - base).max() < 3e-3
     np.testing.assert_array_equal(tuned, again)
+
+
+def test_row_without_valid_tokens_does_not_disturb_the_batch(gpu_device):
+    """An all-padding row (mask all False) is evaluated as one token in both layouts; the other rows of the
+    batch are unaffected and everything stays finite."""
+    from proqa_amd.retriever import BertForRetriever
+    z, sd, cfg = load_golden()
+    model = BertForRetriever(cfg, device=gpu_device)
+    model.load_state_dict(sd)
+    ids = torch.from_numpy(z["input_ids"]).to(gpu_device).clone()
+    mask = torch.from_numpy(z["input_mask"]).to(gpu_device).clone()
+    ref = model.get_embed({"input_ids": ids, "input_mask": mask}, False)["embed"].float().cpu().numpy()
+    mask[5] = False
+    ids[5] = 0
+    for packed in (True, False):
+        model.pack_tokens = packed
+        out = model.get_embed({"input_ids": ids, "input_mask": mask}, False)["embed"].float().cpu().numpy()
+        assert np.isfinite(out).all()
+        keep = [i for i in range(len(out)) if i != 5]
+        assert np.abs(out[keep] - ref[keep]).max() < 2e-3
