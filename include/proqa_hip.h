@@ -16,6 +16,9 @@
  *   - the caller allocates every output; the library never frees caller memory.
  *   - handles are not re-entrant: one host thread per handle at a time.
  *   - one process drives one GPU (the current HIP device at handle creation).
+ *   - the library has no DT_NEEDED entries for the HIP runtime and rocBLAS (the encoder's dense layers):
+ *     the host process loads the pair it already uses with RTLD_GLOBAL before dlopen'ing this library
+ *     (INTEGRATION.md section 3), so that device pointers and streams belong to one runtime.
  */
 #ifndef PROQA_HIP_H
 #define PROQA_HIP_H
@@ -58,7 +61,8 @@ int proqa_device_info(int* n_devices, char* arch_name, size_t arch_name_len);
  * at retrieval/eval_retrieval.py:102-104 (also retrieval/trec_process.py:74-76).
  * Results: scores descending; exact ties ordered by ascending row index (FAISS leaves the
  * tie order unspecified); if fewer than k rows exist the tail is I = -1, D = -FLT_MAX.
- * Rows are stored in HBM as fp16 (the --fp16 index format); scores accumulate in fp32.
+ * Rows are stored in HBM as fp16 (the --fp16 index format); scores accumulate in fp32.  float32 data
+ * that fp16 cannot hold is searched exactly (see proqa_index_add).
  * ---------------------------------------------------------------------------------- */
 typedef struct proqa_index proqa_index;
 
