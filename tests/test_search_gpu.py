@@ -477,3 +477,23 @@ print("stub ok")
 '''
     out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, cwd=root, timeout=300)
     assert out.returncode == 0 and "stub ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_exact_mode_switch_in_a_later_upload_piece(gpu_device):
+    """Host uploads go in pieces of 2^20 rows: the first piece is fp16-exact, the switch to exact-float32 mode
+    happens in the second piece, and the rows of the first piece must get their float32 copies too."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(31)
+    n = (1 << 20) + 70000
+    xb = rng.integers(-4, 5, (n, 128)).astype(np.float32)
+    xb[(1 << 20) + 123:, 0] = 2049.0                       # not an fp16 number
+    xb[: 1 << 20, 0] = rng.integers(-2000, 2001, 1 << 20)   # fp16-exact, large enough to compete
+    xq = rng.integers(-3, 4, (9, 128)).astype(np.float32)
+    xq[:, 0] = 1.0
+    index = IndexFlatIP(128)
+    index.add(xb)
+    assert index.exact_f32 and index.ntotal == n
+    D, I = index.search(xq, 50)
+    Do, Io = search_oracle.topk_ip_exact(xq, xb, 50)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
