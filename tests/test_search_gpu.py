@@ -497,3 +497,23 @@ def test_exact_mode_switch_in_a_later_upload_piece(gpu_device):
     Do, Io = search_oracle.topk_ip_exact(xq, xb, 50)
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
+
+
+def test_exact_mode_on_an_adopted_shard(gpu_device):
+    """An adopted (caller-owned, fp16) shard searched with float32 queries fp16 cannot hold: the index builds
+    its float32 copies next to the adopted rows."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(33)
+    xb = _int_corpus(rng, 20000)
+    xq = (rng.integers(-3, 4, (12, 128)) * (1.0 + 2.0 ** -12)).astype(np.float32)
+    t = torch.from_numpy(xb).to(gpu_device)
+    index = IndexFlatIP(128)
+    index.adopt_device(t)
+    D, I = index.search(xq, 80)
+    assert index.exact_f32
+    Do, Io = search_oracle.topk_ip_exact(xq, xb.astype(np.float32), 80)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    index.reset()
+    assert index.ntotal == 0 and not index.exact_f32
