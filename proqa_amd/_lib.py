@@ -159,9 +159,14 @@ def load():
         if _lib is not None:
             return _lib
         if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -m proqa_amd.build` "
-                "(or __graft_entry__.build()); proqa_amd has no CPU fallback")
+            # not a fallback: the same hipcc build __graft_entry__.build() runs, for a checkout that was never built
+            try:
+                from . import build as _build
+                _build.build()
+            except Exception as e:
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing and could not be built ({e}): build it with `python -m proqa_amd.build` "
+                    "(or __graft_entry__.build()); proqa_amd has no CPU fallback") from e
         _promote_hip_runtime()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
