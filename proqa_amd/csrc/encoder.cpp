@@ -249,7 +249,10 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
   const float eps = w.layer_norm_eps;
   const int64_t n_padded = (int64_t)batch * seq_len;
   if (n_valid_tokens > n_padded) return fail(PROQA_EINVAL, "encoder_forward: n_valid_tokens exceeds batch*seq_len");
-  const bool packed = (flags & PROQA_ENC_PACKED) && n_valid_tokens > 0 && n_valid_tokens < n_padded;
+  // pack only when at least 10 % of the rows are padding: the BLAS default pick is erratic in the row count
+  // (scripts/dev_gemm_vs_m.py, up to -15 % per flop on unlucky ragged M), so a nearly full batch is better
+  // off at its regular padded shape
+  const bool packed = (flags & PROQA_ENC_PACKED) && n_valid_tokens > 0 && n_valid_tokens * 10 < n_padded * 9;
   const bool cls_only = (flags & PROQA_ENC_CLS_ONLY_LAST) != 0;
   if (int rc = ensure_workspace(e, batch, round_up<int64_t>(n_padded, kRowTile))) return rc;
   Workspace& ws = e->ws;
