@@ -312,10 +312,9 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 // ---------------------------------------------------------------------------------------
 // merge kernel: one workgroup per query
 // ---------------------------------------------------------------------------------------
-// keys[] collects {survivors of this round} then {running list} and is sorted bitonically in LDS
-// (a rank-select — count the larger keys — was measured slower: its O(n^2) compares are VALU-bound
-// with 8 workgroups resident per CU).  Overflow-safe rounds (inclusive threshold, rows may repeat)
-// additionally drop adjacent duplicates.
+// keys[] collects {survivors of this round} then {running list}; the workgroup sorts them in registers
+// (sort_keys_desc).  Overflow-safe rounds (inclusive threshold, rows may repeat) additionally drop
+// adjacent duplicates.
 // exact-float32 mode: the fp16 filter must log every row whose float32 score can exceed the exact
 // threshold t: it tests against t - margin (margin bounds |float32 score - fp16 score| for this
 // query over all rows), lowered by a few ulps for the rounding of the subtraction itself
@@ -370,13 +369,82 @@ __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, b
   keep_scores_regs(buf, q, inclusive, bound, ex, keys, n_keys);
 }
 
+// Bitonic sort (descending) of 256*NK packed keys held NK per thread by a 256-thread workgroup; key (tid, j) is
+// element tid*NK + j of the sequence.  Strides below NK are compare-exchanges between a thread's own registers,
+// strides below 64*NK are lane shuffles inside a wave; only the two widest strides cross waves and go through
+// LDS (`xchg`, 256*NK keys), i.e. three barrier pairs per sort instead of one barrier per stage.
+template <int NK>
+__device__ __forceinline__ void sort_keys_desc(unsigned long long (&v)[NK], unsigned long long* xchg, int tid) {
+  constexpr unsigned P = (unsigned)kMergeThreads * NK;
+  for (unsigned size = 2; size <= P; size <<= 1) {
+    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride >= (unsigned)NK) {
+        // partner key (tid ^ m, j): all keys of a thread share the block direction (size > stride >= NK)
+        const unsigned m = stride / NK;
+        const bool desc = (((unsigned)tid * NK) & size) == 0;
+        const bool keep_max = (((unsigned)tid & m) == 0) == desc;
+        if (m >= 64u) {
+#pragma unroll
+          for (int j = 0; j < NK; ++j) xchg[j * kMergeThreads + tid] = v[j];
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < NK; ++j) {
+            const unsigned long long o = xchg[j * kMergeThreads + (tid ^ m)];
+            v[j] = ((v[j] < o) == keep_max) ? o : v[j];
+          }
+          __syncthreads();
+        } else {
+#pragma unroll
+          for (int j = 0; j < NK; ++j) {
+            const unsigned long long o = __shfl_xor(v[j], (int)m, 64);
+            v[j] = ((v[j] < o) == keep_max) ? o : v[j];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = NK / 2; s >= 1; s >>= 1) {
+          if (stride == (unsigned)s) {
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+              if ((j & s) == 0) {
+                const bool desc = ((((unsigned)tid * NK) + j) & size) == 0;
+                const unsigned long long x = v[j], y = v[j + s];
+                const bool sw = (x < y) == desc;
+                v[j] = sw ? y : x;
+                v[j + s] = sw ? x : y;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Sort keys[0, total) (LDS, total <= 256*NK; the tail is padded with 0, which is below every real key) and
+// leave the sorted sequence in registers: v[j] = element tid*NK + j.  keys[] doubles as the exchange buffer.
+template <int NK>
+__device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsigned long long* keys, unsigned total,
+                                              int tid) {
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const unsigned i = j * kMergeThreads + tid;   // any assignment will do: it is a sort
+    v[j] = i < total ? keys[i] : 0ull;
+  }
+  __syncthreads();   // keys[] is free for the exchanges from here on
+  sort_keys_desc<NK>(v, keys, tid);
+}
+
 // EXACT = exact-float32 mode (own instantiation: its LDS list and registers stay out of the fp16 kernel)
 template <bool EXACT>
-__global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
+__global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(MergeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[kMaxSortKeys];
-  __shared__ unsigned short s_lane_cnt[512];   // per (chunk, half) list length of this query
-  __shared__ unsigned short s_spill_cnt[256];  // per chunk: records in the spill log of q's wave slot
-  __shared__ unsigned s_n_keys;
+  // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
+  // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
+  constexpr unsigned kWorkCap = 1024;
+  __shared__ unsigned short s_work[kWorkCap];
+  __shared__ unsigned s_n_keys, s_n_work;
+  static_assert(kLaneCap <= 16, "work item packing");
   const unsigned q = blockIdx.x;
   const int tid = threadIdx.x;
   const CandidateStore& st = a.store;
@@ -397,6 +465,10 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   const bool inclusive = a.inclusive != 0;
   const unsigned long long bound = a.bound_keys ? a.bound_keys[q] : ~0ull;
 
+  // the running list is needed last: fetch its first 256 keys (all of it for the usual k) first
+  const unsigned nrun = a.run_n[q];
+  const unsigned long long run_pref = (unsigned)tid < nrun ? a.run_keys[(size_t)q * a.k + tid] : 0ull;
+
   // the wave slot that owns q in every chunk
   const unsigned tile_q = kFilterWaves * a.qw * 32;
   const unsigned qt = q / tile_q;
@@ -405,38 +477,66 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   if (tid == 0) s_n_keys = 0;
 
   for (unsigned base = 0; base < n_lists; base += 512) {
-    // first-level loads, all independent: list lengths of this query (chunk-major, half-minor:
-    // adjacent words of one chunk) and the spill counters of the same chunks
+    if (tid == 0) s_n_work = 0;
+    __syncthreads();
+    // list lengths of this query (chunk-major, half-minor; two lists per thread) and the spill counter of
+    // one chunk per thread: three independent loads, then one work item per logged record
     const unsigned n_here = (n_lists - base) < 512u ? (n_lists - base) : 512u;
-    for (unsigned t = tid; t < n_here; t += kMergeThreads) {
+    size_t li[2];
+    unsigned cnt[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned t = (unsigned)tid + e * kMergeThreads;
       const unsigned l = base + t;
-      s_lane_cnt[t] = (unsigned short)st.lane_cnt[lane_list_index(st, l >> 1, q, (int)(l & 1))];
+      li[e] = lane_list_index(st, l >> 1, q, (int)(l & 1));
+      cnt[e] = t < n_here ? st.lane_cnt[li[e]] : 0u;
     }
-    for (unsigned t = tid; t < (n_here >> 1); t += kMergeThreads) {
-      const unsigned c = (base >> 1) + t;
-      s_spill_cnt[t] = (unsigned short)st.spill_cnt[(c * st.n_qtiles + qt) * kFilterWaves + wave];
+    const unsigned spill_slot0 = ((base >> 1) * st.n_qtiles + qt) * kFilterWaves + wave;   // chunk base/2
+    const unsigned spill_stride = st.n_qtiles * kFilterWaves;                              // per chunk
+    const unsigned n_spill = (unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_slot0 + (unsigned)tid * spill_stride] : 0u;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (cnt[e]) {
+        const unsigned t = (unsigned)tid + e * kMergeThreads;
+        const unsigned pos = atomicAdd(&s_n_work, cnt[e]);   // LDS
+        for (unsigned s = 0; s < cnt[e]; ++s) {
+          if (pos + s < kWorkCap)
+            s_work[pos + s] = (unsigned short)((t << 4) | s);
+          else
+            keep_scores(st.lane_log + li[e] * kLaneCap + s, q, inclusive, bound, ex, keys, &s_n_keys);
+        }
+      }
+    }
+    // spill logs of q's wave slot (usually all empty): a wave walks the non-empty chunks its lanes found
+    {
+      const int lane = tid & 63;
+      unsigned long long live = __ballot(n_spill != 0);
+      while (live) {
+        const int src = __builtin_ctzll(live);
+        live &= live - 1;
+        const unsigned n_s = (unsigned)__shfl((int)n_spill, src, 64);
+        const size_t slot_s = spill_slot0 + (size_t)((tid & ~63) + src) * spill_stride;
+        for (unsigned i = lane; i < n_s; i += 64)
+          keep_scores(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys);
+      }
     }
     __syncthreads();
-    // one thread per (list, slot) pair: every record is fetched with five independent 16-byte loads
-    for (unsigned p = tid; p < n_here * kLaneCap; p += kMergeThreads) {
-      const unsigned t = p / kLaneCap, slot = p - t * kLaneCap;
-      if (slot < s_lane_cnt[t]) {
-        const unsigned l = base + t;
-        const WaveRecord* rec = st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * kLaneCap + slot;
-        keep_scores(rec, q, inclusive, bound, ex, keys, &s_n_keys);
-      }
-    }
-    // spill logs of the wave slot (usually all empty): one wave per non-empty chunk
-    {
-      const int lane = tid & 63, w = tid >> 6;
-      for (unsigned t = w; t < (n_here >> 1); t += kMergeThreads / 64) {
-        const unsigned n = s_spill_cnt[t];
-        if (n == 0) continue;
-        const unsigned c = (base >> 1) + t;
-        const size_t slot = (size_t)(c * st.n_qtiles + qt) * kFilterWaves + wave;
-        for (unsigned i = lane; i < n; i += 64)
-          keep_scores(st.spill_log + slot * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys);
-      }
+    const unsigned n_work = s_n_work < kWorkCap ? s_n_work : kWorkCap;
+    // two records per thread in flight
+    for (unsigned w0 = tid; w0 < n_work; w0 += 2 * kMergeThreads) {
+      const unsigned w1 = w0 + kMergeThreads;
+      const bool two = w1 < n_work;
+      const unsigned i0 = s_work[w0], i1 = two ? s_work[w1] : i0;
+      const unsigned l0 = base + (i0 >> 4), l1 = base + (i1 >> 4);
+      const uint4* r0 = (const uint4*)(st.lane_log + lane_list_index(st, l0 >> 1, q, (int)(l0 & 1)) * kLaneCap + (i0 & 15u));
+      const uint4* r1 = (const uint4*)(st.lane_log + lane_list_index(st, l1 >> 1, q, (int)(l1 & 1)) * kLaneCap + (i1 & 15u));
+      uint4 b0[5], b1[5];
+#pragma unroll
+      for (int g = 0; g < 5; ++g) b0[g] = r0[g];
+#pragma unroll
+      for (int g = 0; g < 5; ++g) b1[g] = r1[g];
+      keep_scores_regs(b0, q, inclusive, bound, ex, keys, &s_n_keys);
+      if (two) keep_scores_regs(b1, q, inclusive, bound, ex, keys, &s_n_keys);
     }
     __syncthreads();
   }
@@ -488,51 +588,60 @@ __global__ __launch_bounds__(kMergeThreads) void topk_merge(MergeArgs a) {
   const unsigned n_seen = s_n_keys;
   if (n_seen == 0) return;  // nothing passed the threshold this round: list and threshold stand
   unsigned n_cand = n_seen;
-  const unsigned nrun = a.run_n[q];
   if (n_cand + nrun > (unsigned)kMaxSortKeys) {  // more survivors than one LDS pass holds
     if (tid == 0) *a.overflow = 1u;
     n_cand = kMaxSortKeys - nrun;
   }
-  for (unsigned i = tid; i < nrun; i += kMergeThreads) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
+  if ((unsigned)tid < nrun) keys[n_cand + tid] = run_pref;
+  for (unsigned i = kMergeThreads + tid; i < nrun; i += kMergeThreads) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
   const unsigned total = n_cand + nrun;
   __syncthreads();
 
-  // sort descending (bitonic, in LDS); forward rounds keep the first k keys as they are, inclusive
-  // rounds (rows re-scanned by the overflow-safe path may already be in the running list) drop
-  // exact duplicates first
-  unsigned P = 2;
-  while (P < total) P <<= 1;
-  for (unsigned i = total + tid; i < P; i += kMergeThreads) keys[i] = 0ull;  // below every real key
-  __syncthreads();
-  for (unsigned size = 2; size <= P; size <<= 1) {
-    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-      for (unsigned i = tid; i < (P >> 1); i += kMergeThreads) {
-        const unsigned lo = 2 * i - (i & (stride - 1));
-        const unsigned hi = lo + stride;
-        const bool desc = (lo & size) == 0;
-        const unsigned long long x = keys[lo], y = keys[hi];
-        if ((x < y) == desc) {
-          keys[lo] = y;
-          keys[hi] = x;
+  // sort descending; forward rounds keep the first k keys as they are, inclusive rounds (rows re-scanned
+  // by the overflow-safe path may already be in the running list) drop exact duplicates first
+  auto finish = [&](auto& v) {
+    constexpr int NK = sizeof(v) / sizeof(v[0]);
+    load_and_sort<NK>(v, keys, total, tid);
+    if (!inclusive) {
+      const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        const unsigned i = (unsigned)tid * NK + j;
+        if (i < keep) a.run_keys[(size_t)q * a.k + i] = v[j];
+        if (i + 1 == (unsigned)a.k && keep == (unsigned)a.k) {
+          const float t = float_from_ord((unsigned)(v[j] >> 32));
+          a.tau[q] = t;
+          if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
         }
       }
-      __syncthreads();
-    }
-  }
-  if (!inclusive) {
-    const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
-    for (unsigned i = tid; i < keep; i += kMergeThreads) a.run_keys[(size_t)q * a.k + i] = keys[i];
-    if (tid == 0) {
-      a.run_n[q] = keep;
-      if (keep == (unsigned)a.k) {
-        const float t = float_from_ord((unsigned)(keys[a.k - 1] >> 32));
-        a.tau[q] = t;
-        if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
+      if (tid == 0) {
+        a.run_n[q] = keep;
+        a.stat_candidates[q] += n_seen;
       }
-      a.stat_candidates[q] += n_seen;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        const unsigned i = (unsigned)tid * NK + j;
+        if (i < total) keys[i] = v[j];
+      }
     }
-    return;
+  };
+  if (total <= 1u * kMergeThreads) {
+    unsigned long long v[1];
+    finish(v);
+  } else if (total <= 2u * kMergeThreads) {
+    unsigned long long v[2];
+    finish(v);
+  } else if (total <= 4u * kMergeThreads) {
+    unsigned long long v[4];
+    finish(v);
+  } else {
+    static_assert(kMaxSortKeys == 8 * kMergeThreads, "largest sort");
+    unsigned long long v[8];
+    finish(v);
   }
+  if (!inclusive) return;
+  __syncthreads();
   if (tid == 0) {  // rare path, serial
     unsigned out = 0;
     unsigned long long prev = 0ull;
@@ -727,48 +836,33 @@ __global__ __launch_bounds__(256) void query_margins(const void* __restrict__ xq
 // n_parts*k gathered entries.  Parts must be in ascending shard order (rank order of a
 // row-sharded corpus): then, for equal scores, gathered position order == global id order,
 // so the position doubles as the tie-break and the 64-bit ids ride along by lookup.
+template <int NK>
 __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __restrict__ D_parts,
                                                             const long long* __restrict__ I_parts,
                                                             int n_parts, long long nq, int k,
                                                             float* __restrict__ D, long long* __restrict__ I) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // max(256, pow2 >= n_parts*k) keys
   const long long q = blockIdx.x;
   const int tid = threadIdx.x;
   const unsigned total = (unsigned)n_parts * (unsigned)k;
-  unsigned P = 2;
-  while (P < total) P <<= 1;
-  for (unsigned i = tid; i < P; i += kMergeThreads) {
-    unsigned long long key = 0ull;
-    if (i < total) {
-      const unsigned p = i / k, j = i - p * k;
-      const size_t src = ((size_t)p * nq + q) * k + j;
-      if (I_parts[src] >= 0) key = pack_key(D_parts[src], i);
-    }
-    keys[i] = key;
+  for (unsigned i = tid; i < total; i += kMergeThreads) {
+    const unsigned p = i / k, j = i - p * k;
+    const size_t src = ((size_t)p * nq + q) * k + j;
+    keys[i] = I_parts[src] >= 0 ? pack_key(D_parts[src], i) : 0ull;
   }
   __syncthreads();
-  for (unsigned size = 2; size <= P; size <<= 1) {
-    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-      for (unsigned i = tid; i < (P >> 1); i += kMergeThreads) {
-        const unsigned lo = 2 * i - (i & (stride - 1));
-        const unsigned hi = lo + stride;
-        const bool desc = (lo & size) == 0;
-        const unsigned long long x = keys[lo], y = keys[hi];
-        if ((x < y) == desc) {
-          keys[lo] = y;
-          keys[hi] = x;
-        }
-      }
-      __syncthreads();
-    }
-  }
-  for (unsigned j = tid; j < (unsigned)k; j += kMergeThreads) {
-    const unsigned long long key = j < P ? keys[j] : 0ull;
+  unsigned long long v[NK];
+  load_and_sort<NK>(v, keys, total, tid);
+#pragma unroll
+  for (int jj = 0; jj < NK; ++jj) {
+    const unsigned j = (unsigned)tid * NK + jj;
+    if (j >= (unsigned)k) continue;
+    const unsigned long long key = v[jj];
     if (key != 0ull) {
       const unsigned pos = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-      const unsigned p = pos / k, jj = pos - p * k;
+      const unsigned p = pos / k, sj = pos - p * k;
       D[q * k + j] = float_from_ord((unsigned)(key >> 32));
-      I[q * k + j] = I_parts[((size_t)p * nq + q) * k + jj];
+      I[q * k + j] = I_parts[((size_t)p * nq + q) * k + sj];
     } else {
       D[q * k + j] = -3.4028234663852886e38f;
       I[q * k + j] = -1;
@@ -915,16 +1009,31 @@ hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, in
   if (nq == 0) return hipSuccess;
   const long long per_q = (long long)n_parts * k;
   if (per_q <= kMaxMergeListKeys) {
-    unsigned P = 2;
+    unsigned P = kMergeThreads;
     while (P < (unsigned)per_q) P <<= 1;
-    if ((size_t)P * 8 > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)merge_lists, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(P * 8));
-      if (e != hipSuccess) return e;
+    const size_t lds = (size_t)P * 8;
+    hipError_t e = hipSuccess;
+#define PROQA_MERGE_CASE(NK)                                                                                        \
+  case NK:                                                                                                          \
+    if (lds > 64 * 1024)                                                                                            \
+      e = hipFuncSetAttribute((const void*)merge_lists<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+    if (e == hipSuccess)                                                                                            \
+      hipLaunchKernelGGL(merge_lists<NK>, dim3((unsigned)nq), dim3(kMergeThreads), lds, st, D_parts, I_parts,       \
+                         n_parts, nq, k, D, I);                                                                     \
+    break;
+    switch (P / kMergeThreads) {
+      PROQA_MERGE_CASE(1)
+      PROQA_MERGE_CASE(2)
+      PROQA_MERGE_CASE(4)
+      PROQA_MERGE_CASE(8)
+      PROQA_MERGE_CASE(16)
+      PROQA_MERGE_CASE(32)
+      PROQA_MERGE_CASE(64)
+      default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(merge_lists, dim3((unsigned)nq), dim3(kMergeThreads), (size_t)P * 8, st, D_parts,
-                       I_parts, n_parts, nq, k, D, I);
-    return hipGetLastError();
+#undef PROQA_MERGE_CASE
+    static_assert(kMaxMergeListKeys == 64 * kMergeThreads, "largest list merge");
+    return e != hipSuccess ? e : hipGetLastError();
   }
   // segmented radix sort in HBM, in query chunks of <= 2^27 keys (1 GiB per key buffer)
   const long long chunk_q = std::max<long long>(1, std::min<long long>(nq, (1ll << 27) / per_q));
