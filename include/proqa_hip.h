@@ -116,6 +116,10 @@ int proqa_index_set_profiling(proqa_index* idx, int enable);
 /* tuning knobs of the round schedule (0 keeps the default): rows of the first slab (scanned with
  * threshold -inf) and the growth factor of the following slabs */
 int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth);
+/* rows whose exact top-k a search takes from a dense score matrix (two launches) before the threshold rounds start;
+ * a multiple of 32 up to 8192, 0 disables it.  Used for k <= rows/4 (at most 256) on indexes of >= 4*rows rows;
+ * the result never depends on it.  Default 4096. */
+int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
  * (the layout an RCCL all-gather of per-rank [nq, k] produces).  Same ordering rule.  Up to

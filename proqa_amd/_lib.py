@@ -82,6 +82,7 @@ SIGNATURES = {
     "proqa_index_last_stats": (c_int, [c_void_p, ctypes.POINTER(SearchStats)]),
     "proqa_index_set_profiling": (c_int, [c_void_p, c_int]),
     "proqa_index_configure": (c_int, [c_void_p, c_int, c_int]),
+    "proqa_index_configure_bootstrap": (c_int, [c_void_p, c_int]),
     "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p]),
     "proqa_encoder_create": (c_int, [ctypes.POINTER(BertWeights), ctypes.POINTER(c_void_p)]),

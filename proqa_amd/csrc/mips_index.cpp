@@ -76,6 +76,10 @@ struct proqa_index {
   bool profile = false;
   bool allow_rounding = false;             // accept fp32 inputs that are not exactly representable in fp16
   unsigned* inexact = nullptr;             // device counters: {not exact in fp16, beyond the fp16 range}
+  // bootstrap (see mips_kernels.hip): score matrix of the first rows, [ws_nq_pad, boot_stride] floats
+  float* boot_scores = nullptr;
+  size_t boot_floats = 0;
+  int bootstrap_rows = 4096;               // 0 disables it
   // tuning
   int first_slab_rows = 256;
   int growth = 0;                          // 0 = automatic (see growth_for)
@@ -272,10 +276,12 @@ double growth_for(int k, int configured, int qw) {
   return std::min<double>(g, kCandidateBudget / k);
 }
 
-std::vector<Slab> plan_slabs(long long n, int first, double growth) {
+// `start` > 0: rows [0, start) were covered by the bootstrap
+std::vector<Slab> plan_slabs(long long n, int first, double growth, long long start = 0) {
   std::vector<Slab> out;
-  long long seen = 0;
-  long long next = std::min<long long>(n, round_up<long long>(first, kStageRows));
+  long long seen = start;
+  long long next = start > 0 ? std::max<long long>(kStageRows, round_up<long long>((long long)(start * growth), kStageRows))
+                             : std::min<long long>(n, round_up<long long>(first, kStageRows));
   while (seen < n) {
     long long r1 = std::min(n, seen + next);
     // do not leave a tiny tail for an extra round
@@ -369,12 +375,33 @@ struct PageOut {
 };
 
 int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
-                const PageOut& out, hipStream_t st, int* fallback_out) {
+                const PageOut& out, hipStream_t st, int* fallback_out, bool use_bootstrap, bool* bootstrap_overflow) {
   PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
+  // Bootstrap: exact top-k of the first rows in two launches instead of the first three or four (dense) rounds.
+  // Not for pages after the first (bounded), exact-float32 mode (its scores are re-computed from float32 rows),
+  // k beyond the select kernel's bound, or an index too small to need it.
+  long long boot = 0;
+  if (use_bootstrap && idx->bootstrap_rows > 0 && !bounded && !idx->exact && page_k <= kBootstrapMaxK &&
+      page_k <= idx->bootstrap_rows / 4 && idx->n >= 4ll * idx->bootstrap_rows)
+    boot = std::min<long long>(idx->bootstrap_rows, kBootstrapMaxRows);
   // every row of the first slab is a candidate (threshold -inf): it must fit one merge pass
   const int first = std::min<int>(idx->first_slab_rows, (kMaxSortKeys - page_k) / kStageRows * kStageRows);
-  std::vector<Slab> slabs = plan_slabs(idx->n, first, growth_for(page_k, idx->growth, qw));
-  if ((int)slabs.size() > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
+  std::vector<Slab> slabs = plan_slabs(idx->n, first, growth_for(page_k, idx->growth, qw), boot);
+  if ((int)slabs.size() + 2 > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
+  if (boot) {
+    const size_t need = (size_t)idx->ws_nq_pad * round_up<long long>(boot, 32);
+    if (need > idx->boot_floats) {
+      PROQA_HIP(hipStreamSynchronize(st));
+      if (idx->boot_scores) PROQA_HIP(hipFree(idx->boot_scores));
+      idx->boot_scores = nullptr;
+      idx->boot_floats = 0;
+      PROQA_HIP(hipMalloc((void**)&idx->boot_scores, need * sizeof(float)));
+      idx->boot_floats = need;
+    }
+    // its overflow word is the last-but-one (the last belongs to the overflow-safe re-scans)
+    PROQA_HIP(launch_bootstrap(idx->xb, idx->xq_pad, (int)boot, (unsigned)nq_pad, page_k, idx->boot_scores, idx->run_keys,
+                               idx->run_n, idx->tau, idx->stat_dev, idx->overflow + kMaxRounds - 2, st));
+  }
   const bool prof = idx->profile && !bounded;  // the per-round brackets describe the first page
   for (size_t r = 0; r < slabs.size(); ++r) {
     hipEvent_t f0 = prof ? idx->ev_filter[2 * r] : nullptr;
@@ -403,6 +430,10 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
   PROQA_HIP(hipEventRecord(idx->ev[1], st));
   PROQA_HIP(hipStreamSynchronize(st));
 
+  if (boot && idx->overflow_host[kMaxRounds - 2]) {   // adversarial order: the caller repeats the page without it
+    *bootstrap_overflow = true;
+    return PROQA_OK;
+  }
   const int fallback_before = *fallback_out;
   for (size_t r = 0; r < slabs.size(); ++r) {
     if (!idx->overflow_host[r]) continue;
@@ -486,7 +517,16 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
       PROQA_HIP(launch_query_margins(xq_dev, dtype, nq, idx->ws_nq_pad, idx->norm_stats, idx->xq32, idx->margin,
                                      idx->tau, idx->tau_filter, st));
     const PageOut out{D_dev, (long long*)I_dev, idx_offset, k, p * kPageK};
-    if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, out, st, &fallback)) return rc;
+    bool boot_overflow = false;
+    if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, out, st, &fallback, true, &boot_overflow)) return rc;
+    if (boot_overflow) {
+      // the per-query state is rebuilt from scratch (p == 0 here: later pages never bootstrap)
+      PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
+                                    nullptr, true, nullptr, st));
+      ++fallback;
+      if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, false, out, st, &fallback, false, &boot_overflow))
+        return rc;
+    }
     if (p + 1 < n_pages)
       PROQA_HIP(launch_advance_page(idx->run_keys, idx->run_n, nq, page_k, idx->bound_keys, idx->ub, idx->done,
                                     idx->exact ? idx->margin : nullptr, idx->exact ? idx->ub_filter : nullptr, st));
@@ -541,6 +581,7 @@ int proqa_index_free(proqa_index* idx) {
   if (idx->overflow_host) (void)hipHostFree(idx->overflow_host);
   if (idx->stat_host) (void)hipHostFree(idx->stat_host);
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
+  if (idx->boot_scores) (void)hipFree(idx->boot_scores);
   if (idx->stage_pinned) (void)hipHostFree(idx->stage_pinned);
   for (auto& e : idx->ev)
     if (e) (void)hipEventDestroy(e);
@@ -573,6 +614,15 @@ int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth) {
   if (first_slab_rows < 0 || growth < 0) return fail(PROQA_EINVAL, "index_configure: negative argument");
   if (first_slab_rows) idx->first_slab_rows = first_slab_rows;
   if (growth) idx->growth = growth;
+  return PROQA_OK;
+}
+
+int proqa_index_configure_bootstrap(proqa_index* idx, int rows) {
+  if (!idx) return fail(PROQA_EINVAL, "index_configure_bootstrap: NULL handle");
+  if (rows < 0 || rows > kBootstrapMaxRows || rows % 32)
+    return fail(PROQA_EINVAL, "index_configure_bootstrap: rows=%d (0 disables; a multiple of 32 up to %d)", rows,
+                kBootstrapMaxRows);
+  idx->bootstrap_rows = rows;
   return PROQA_OK;
 }
 

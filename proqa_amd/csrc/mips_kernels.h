@@ -18,6 +18,8 @@ constexpr int kMaxMergeListKeys = 16384;
 constexpr int kMaxSortKeys = 2048;  // running list + candidates of one query per merge (LDS)
 constexpr int kPageK = kMaxSortKeys / 2;  // results per page; k > kPageK is served page by page
 constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling
+constexpr int kBootstrapMaxRows = 8192;  // rows the bootstrap can cover (32 keys per thread)
+constexpr int kBootstrapMaxK = 256;       // its bound is the k-th of 256 thread maxima
 constexpr int kSpillCap = 256;      // shared spill records per (chunk, wave)
 
 // One lane's 16-score accumulator column that beat its query's threshold.  The filter kernel
@@ -86,6 +88,11 @@ hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigne
                                unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,
                                float* ub_filter, hipStream_t st);
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st);
+// exact top-k of rows [0, n_rows) (n_rows <= kBootstrapMaxRows, k <= kBootstrapMaxK) for every query: run_keys / run_n /
+// tau as the geometric rounds would leave them after those rows.  scores: [nq_pad, round_up(n_rows, 32)] floats
+hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,
+                            unsigned long long* run_keys, unsigned* run_n, float* tau, unsigned long long* stat,
+                            unsigned* overflow, hipStream_t st);
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
                                bool reset_stat, unsigned* inexact, hipStream_t st);

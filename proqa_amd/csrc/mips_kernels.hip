@@ -369,6 +369,19 @@ __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, b
   keep_scores_regs(buf, q, inclusive, bound, ex, keys, n_keys);
 }
 
+// Append the lanes' items (pred lanes only) to an LDS array: one LDS atomic per wave, ranks by mbcnt.
+template <typename T>
+__device__ __forceinline__ void wave_append(bool pred, T item, T* arr, unsigned* counter, unsigned cap) {
+  const unsigned long long mask = __ballot(pred);
+  if (!mask) return;   // wave-uniform
+  unsigned base = 0;
+  if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, (unsigned)__builtin_popcountll(mask));   // LDS
+  base = (unsigned)__shfl((int)base, 0, 64);
+  const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  if (pred && pos < cap) arr[pos] = item;
+}
+
 // Bitonic sort (descending) of 256*NK packed keys held NK per thread by a 256-thread workgroup; key (tid, j) is
 // element tid*NK + j of the sequence.  Strides below NK are compare-exchanges between a thread's own registers,
 // strides below 64*NK are lane shuffles inside a wave; only the two widest strides cross waves and go through
@@ -661,6 +674,149 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
   __syncthreads();
   const unsigned keep = s_n_keys;
   for (unsigned i = tid; i < keep; i += kMergeThreads) a.run_keys[(size_t)q * a.k + i] = keys[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// bootstrap: exact top-k of the first R0 corpus rows in two launches
+// ---------------------------------------------------------------------------------------
+// The geometric rounds start from k rows: their first three or four launches see a few thousand rows but
+// log almost every score (threshold -inf or still loose), and a dense launch is bound by its scattered
+// record stores, not by its arithmetic.  The bootstrap replaces them: bootstrap_scores writes the score matrix of
+// rows [0, R0) as coalesced rows S[q][0..R0), bootstrap_select picks every query's top-k from its row.
+//
+// bootstrap_scores: one wave per 32 rows x 32 queries.  Same MFMA, operand roles and k-step order as
+// mips_filter_f16 (rows = A, queries = B, piece 2j+half at step j), so a row's score has the same bits whichever
+// kernel produced it (a shard's first rows are bootstrap rows, the same rows deep inside a bigger index are not).
+// The accumulator tile is transposed through LDS so that S is written in 128-byte runs.
+constexpr int kBootWaves = 4;
+constexpr int kBootTilesPerWave = 4;   // row tiles a wave computes with the same resident query fragments
+__global__ __launch_bounds__(kBootWaves * 64) void bootstrap_scores(const char* __restrict__ xb, const void* __restrict__ xq,
+                                                                    int n_rows, int s_stride, float* __restrict__ S) {
+  __shared__ float tile[kBootWaves][32][33];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, half = lane >> 5;
+  const unsigned q0 = blockIdx.y * 32;
+  const char* bp = (const char*)xq + (size_t)(q0 + li) * kRowBytes;
+  f16x8 qf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qf[j] = *(const f16x8*)(bp + (2 * j + half) * 16);
+#pragma unroll 1
+  for (int t = 0; t < kBootTilesPerWave; ++t) {
+    const int row0 = ((blockIdx.x * kBootTilesPerWave + t) * kBootWaves + wave) * 32;
+    if (row0 >= n_rows) break;   // wave-uniform; no workgroup barrier below: the LDS tile is private to the wave
+    const int arow = row0 + li < n_rows ? row0 + li : n_rows - 1;
+    const char* ap = xb + (size_t)arow * kRowBytes;
+    f16x8 af[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(ap + (2 * j + half) * 16);
+    f32x16 acc = {0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[j], acc, 0, 0, 0);
+    // lane (li, half) holds query li, rows (r&3) + 8*(r>>2) + 4*half; LDS operations of one wave execute in
+    // program order, so the transposed reads below see the writes of the other lanes
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[wave][li][(r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qq = 2 * i + half;
+      if (row0 + li < n_rows) S[(size_t)(q0 + qq) * s_stride + row0 + li] = tile[wave][qq][li];
+    }
+  }
+}
+
+// bootstrap_select: one workgroup per query over S[q][0, n_rows).  Thread t packs the keys of elements
+// t, t+256, ... and keeps the largest; the k-th largest of the 256 thread maxima bounds the k-th best key from
+// below (k threads hold a key at least that large), so only the keys >= that bound -- usually between k and 3k
+// of them -- are collected and sorted.  More than kMaxSortKeys survivors (an adversarial order) raise the
+// overflow flag; the host then repeats the page without the bootstrap.
+template <int E>   // keys per thread: n_rows <= 256 E
+__global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* __restrict__ S, int n_rows, int s_stride,
+                                                                  int k, unsigned long long* __restrict__ run_keys,
+                                                                  unsigned* __restrict__ run_n, float* __restrict__ tau,
+                                                                  unsigned long long* __restrict__ stat_candidates,
+                                                                  unsigned* __restrict__ overflow) {
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[kMaxSortKeys];
+  __shared__ unsigned long long s_bound;
+  __shared__ unsigned s_n_keys;
+  const unsigned q = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (tau[q] == __builtin_inff()) return;   // padding query: its state stays empty
+  const float* row = S + (size_t)q * s_stride;
+  unsigned long long mine[E];
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = e * kMergeThreads + tid;
+    const float sc = i < n_rows ? row[i] : -__builtin_inff();
+    mine[e] = sc > -__builtin_inff() ? pack_key(sc, (unsigned)i) : 0ull;   // like the filter: -inf / NaN never qualify
+    best = mine[e] > best ? mine[e] : best;
+  }
+  if (tid == 0) s_n_keys = 0;
+  unsigned long long bound = 1ull;   // fewer than k rows: every valid row is kept
+  if (n_rows > k) {
+    unsigned long long v[1] = {best};
+    sort_keys_desc<1>(v, keys, tid);
+    if (tid == k - 1) s_bound = v[0] ? v[0] : 1ull;
+    __syncthreads();
+    bound = s_bound;
+  } else {
+    __syncthreads();
+  }
+  // survivors of this thread, then ONE append per wave: exclusive scan of the counts over the lanes
+  unsigned mine_n = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) mine_n += mine[e] >= bound ? 1u : 0u;
+  unsigned incl = mine_n;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = (unsigned)__shfl_up((int)incl, off, 64);
+    if ((tid & 63) >= off) incl += o;
+  }
+  unsigned base = 0;
+  if ((tid & 63) == 63) base = atomicAdd(&s_n_keys, incl);   // LDS; lane 63 holds the wave total
+  unsigned pos = (unsigned)__shfl((int)base, 63, 64) + incl - mine_n;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    if (mine[e] >= bound) {
+      if (pos < (unsigned)kMaxSortKeys) keys[pos] = mine[e];
+      ++pos;
+    }
+  }
+  __syncthreads();
+  unsigned total = s_n_keys;
+  if (total > (unsigned)kMaxSortKeys) {
+    if (tid == 0) *overflow = 1u;
+    total = kMaxSortKeys;
+  }
+  auto finish = [&](auto& v) {
+    constexpr int NK = sizeof(v) / sizeof(v[0]);
+    load_and_sort<NK>(v, keys, total, tid);
+    const unsigned keep = total < (unsigned)k ? total : (unsigned)k;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const unsigned i = (unsigned)tid * NK + j;
+      if (i < keep) run_keys[(size_t)q * k + i] = v[j];
+      if (i + 1 == (unsigned)k && keep == (unsigned)k) tau[q] = float_from_ord((unsigned)(v[j] >> 32));
+    }
+    if (tid == 0) {
+      run_n[q] = keep;
+      stat_candidates[q] += total;
+    }
+  };
+  if (total <= 1u * kMergeThreads) {
+    unsigned long long v[1];
+    finish(v);
+  } else if (total <= 2u * kMergeThreads) {
+    unsigned long long v[2];
+    finish(v);
+  } else if (total <= 4u * kMergeThreads) {
+    unsigned long long v[4];
+    finish(v);
+  } else {
+    unsigned long long v[8];
+    finish(v);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -969,6 +1125,30 @@ hipError_t launch_query_margins(const void* xq, int dtype, long long nq, long lo
   if (nq_pad == 0) return hipSuccess;
   hipLaunchKernelGGL(query_margins, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
                      norm_stats, xq32, margin, tau, tau_filter);
+  return hipGetLastError();
+}
+
+hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,
+                            unsigned long long* run_keys, unsigned* run_n, float* tau, unsigned long long* stat,
+                            unsigned* overflow, hipStream_t st) {
+  const int s_stride = (n_rows + 31) / 32 * 32;
+  const unsigned row_tiles = (unsigned)(s_stride / 32);
+  const unsigned per_wg = kBootWaves * kBootTilesPerWave;
+  hipLaunchKernelGGL(bootstrap_scores, dim3((row_tiles + per_wg - 1) / per_wg, nq_pad / 32), dim3(kBootWaves * 64), 0, st,
+                     xb, xq_pad, n_rows, s_stride, scores);
+#define PROQA_SELECT_CASE(E)                                                                                            \
+  hipLaunchKernelGGL(bootstrap_select<E>, dim3(nq_pad), dim3(kMergeThreads), 0, st, scores, n_rows, s_stride, k, run_keys, \
+                     run_n, tau, stat, overflow)
+  if (n_rows <= 4 * kMergeThreads)
+    PROQA_SELECT_CASE(4);
+  else if (n_rows <= 8 * kMergeThreads)
+    PROQA_SELECT_CASE(8);
+  else if (n_rows <= 16 * kMergeThreads)
+    PROQA_SELECT_CASE(16);
+  else
+    PROQA_SELECT_CASE(32);
+#undef PROQA_SELECT_CASE
+  static_assert(kBootstrapMaxRows == 32 * kMergeThreads, "largest select");
   return hipGetLastError();
 }
 

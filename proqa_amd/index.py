@@ -160,6 +160,10 @@ class IndexFlatIP:
         """Round schedule: rows of the first (dense) slab and the growth factor of later slabs."""
         _lib.check(self._lib.proqa_index_configure(self._h, first_slab_rows, growth))
 
+    def configure_bootstrap(self, rows):
+        """Rows covered by the dense bootstrap (exact top-k of the first rows from a score matrix); 0 disables it."""
+        _lib.check(self._lib.proqa_index_configure_bootstrap(self._h, int(rows)))
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.proqa_index_free(self._h)

@@ -517,3 +517,60 @@ def test_exact_mode_on_an_adopted_shard(gpu_device):
     np.testing.assert_array_equal(D, Do)
     index.reset()
     assert index.ntotal == 0 and not index.exact_f32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,k,rows", [(4096, 64, 80, 512), (20000, 300, 5, 4096), (9000, 33, 128, 1024),
+                                         (40000, 2032, 80, 8192), (1024, 7, 8, 32)])
+def test_bootstrap_rows_give_the_same_result(gpu_device, n, nq, k, rows):
+    """The dense bootstrap (score matrix of the first rows + per-query select) replaces the first rounds:
+    ids and scores are bit-identical with it on (any size) and off, and equal to the oracle."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(n + nq)
+    xb = _int_corpus(rng, n)
+    xq = _int_corpus(rng, nq)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    for r in (rows, 0):
+        index = IndexFlatIP(128)
+        index.configure_bootstrap(r)
+        index.add(xb)
+        D, I = index.search(xq, k)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
+        assert index.last_stats()["fallback_rounds"] == 0
+    # random fp16 data: a row's score has the same bits from the bootstrap and from the filter kernel
+    xb = rng.standard_normal((n, 128)).astype(np.float16)
+    xq = rng.standard_normal((nq, 128)).astype(np.float16)
+    res = []
+    for r in (rows, 0):
+        index = IndexFlatIP(128)
+        index.configure_bootstrap(r)
+        index.add(xb)
+        res.append(index.search(xq, k))
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+
+
+@pytest.mark.gpu
+def test_bootstrap_overflow_repeats_without_it(gpu_device):
+    """The select keeps the keys above the k-th largest of its 256 thread maxima (thread t owns rows t, t+256, ...).
+    If the good rows all sit in the strides of k-1 threads, that bound is low and (k-1)*rows/256 + 1 keys pass: more
+    than one sort holds at 8192 rows.  The page is then repeated without the bootstrap."""
+    from proqa_amd.index import IndexFlatIP
+    n, nq, k, rows = 40000, 5, 80, 8192
+    xb = np.zeros((n, 128), dtype=np.float16)
+    xb[:, 0] = 1.0
+    good = (np.arange(n) % 256 < k - 1) & (np.arange(n) < rows)
+    xb[good, 0] = 10.0
+    xb[:, 1] = (np.arange(n) % 7).astype(np.float16)       # some variety below the good rows
+    xq = np.zeros((nq, 128), dtype=np.float16)
+    xq[:, 0] = 1.0
+    xq[:, 1] = 0.125
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    index = IndexFlatIP(128)
+    index.configure_bootstrap(rows)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert index.last_stats()["fallback_rounds"] >= 1
