@@ -340,6 +340,22 @@ def main():
                      "frac": small_gbs / PEAK_HBM_GBS, "kernel": "mips_filter_f16<QW=1>",
                      "note": "algorithmic bytes = rows x 256 B per search; ~6.3 TB/s is the measured copy ceiling"}}
 
+    if world == 1:
+        # per-rank work of the strong-scaling runs, timed on this one GPU: the same queries over the first
+        # N/G rows (G = 1, 2, 4, 8) -- what a rank of a G-GPU job does before the all-gather
+        sweep = []
+        for g_ in (1, 2, 4, 8):
+            rows_g = n // g_
+            ix = IndexFlatIP(128)
+            ix.adopt_device(xb[:rows_g])
+            dt_g = timed(lambda: ix.search_device(xq, k), max(5, args.steps // 2), 2, 1, device)
+            ms_g = dt_g / max(5, args.steps // 2) * 1e3
+            sweep.append({"ranks": g_, "rows_per_rank": rows_g, "ms_per_search": ms_g,
+                          "queries_per_s_projected": nq / (ms_g * 1e-3)})
+            ix.close()
+        line["shard_sweep"] = {"note": "N=1 timing of the per-rank search of a G-rank job (no collective)", "points": sweep}
+        line["peak_measured"] = measured_peaks(device)
+
     if rank == 0 and world == 1 and not args.skip_cpu:   # CPU baselines: single-GPU runs only (contract)
         # CPU baseline + id parity on a bounded sample of the same workload
         cores = host_cores()
@@ -373,6 +389,32 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_peaks(device):
+    """Stream and MFMA micro-benchmarks of libproqa_hip.so on this box: the ceilings a HIP kernel
+    reaches here, next to the spec peaks the roofline fractions are priced against."""
+    import ctypes
+    from proqa_amd import _lib
+    lib = _lib.load()
+    nbytes = 2 << 30
+    buf = torch.empty(2 * nbytes, dtype=torch.uint8, device=device)
+    buf.zero_()
+    torch.cuda.synchronize()
+    out = {}
+    v = ctypes.c_double()
+    st = _lib.current_stream_ptr()
+    for name, kind in (("hbm_copy_GBs", 0), ("hbm_read_GBs", 1)):
+        _lib.check(lib.proqa_microbench_stream(buf.data_ptr(), nbytes, kind, 5, st, ctypes.byref(v)))
+        out[name] = v.value
+    del buf
+    for name, ms, zero in (("mfma_f16_TFLOPs_8ms_random_operands", 8.0, 0), ("mfma_f16_TFLOPs_8ms_zero_operands", 8.0, 1),
+                           ("mfma_f16_TFLOPs_0.3ms_random_operands", 0.3, 0)):
+        _lib.check(lib.proqa_microbench_mfma(ms, zero, st, ctypes.byref(v)))
+        out[name] = v.value
+    out["note"] = ("float4 grid-stride copy / read of 2 GiB; 4 independent v_mfma_f32_32x32x16_f16 chains per wave from "
+                   "registers, 8 waves per CU; best of repeated launches")
+    return out
 
 
 def pmc_traffic(shard_fraction):

@@ -289,6 +289,40 @@ int proqa_npy_write(const char* path, const void* data, int64_t rows, int64_t co
 int proqa_npy_create(const char* path, int64_t rows, int64_t cols, int dtype);
 int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* src);
 
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU search without PyTorch (BASELINE.json configs[3]).  One process (or thread)
+ * per GPU holds rows [lo, hi) of the corpus in its own proqa_index and all queries.  A sharded search is the
+ * local exact top-k with global ids, ONE RCCL all-gather of the per-rank [nq, k] (id, score) lists over xGMI,
+ * and the merge of proqa_topk_merge_device: bit-identical to searching the whole corpus on one GPU.
+ * The reference has no such call (its search is single-process faiss, retrieval/eval_retrieval.py:102-104; its
+ * one NCCL touch point is the process-group init of retrieval/get_embed.py:44-52).
+ * RCCL is bound at run time (dlopen); in a PyTorch process the RCCL PyTorch loaded is used.
+ * ---------------------------------------------------------------------------------- */
+#define PROQA_COMM_ID_BYTES 128
+typedef struct proqa_comm proqa_comm;
+/* rank 0: make a unique id (ncclGetUniqueId) and hand its 128 bytes to every rank by any side channel */
+int proqa_comm_get_unique_id(void* id_out);
+/* every rank, with its GPU current (hipSetDevice): collective ncclCommInitRank */
+int proqa_comm_create(const void* id, int world_size, int rank, proqa_comm** out);
+int proqa_comm_info(const proqa_comm* comm, int* world_size, int* rank);
+int proqa_comm_free(proqa_comm* comm);
+/* every rank calls with the SAME queries (device pointers), nq, dtype and k, and with idx_offset = its first global
+ * row; ranks must hold ascending row ranges in rank order.  D_dev / I_dev [nq, k] receive the merged result on every
+ * rank.  The collective runs even for world_size 1. */
+int proqa_sharded_search_device(proqa_index* idx, proqa_comm* comm, const void* xq_dev, int64_t nq, int dtype,
+                                int k, int64_t idx_offset, float* D_dev, int64_t* I_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Measured ceilings of this GPU (bench.py "peak_measured"; SURVEY.md section 8d asks for them next to the spec
+ * peaks): a 16-byte-per-lane stream over device memory and a register-resident 32x32x16 fp16 MFMA loop.
+ * ---------------------------------------------------------------------------------- */
+/* kind 0: copy buf[0,bytes) -> buf[bytes,2*bytes), read+written bytes counted; kind 1: read buf[0,bytes).
+ * Best of `reps` launches in GB/s. */
+int proqa_microbench_stream(void* buf_dev, size_t bytes, int kind, int reps, void* stream, double* gbs);
+/* launches of about ms_target milliseconds; zero_operands != 0 feeds all-zero inputs (the sustained clock depends on
+ * the operand bits).  Dense TFLOP/s. */
+int proqa_microbench_mfma(double ms_target, int zero_operands, void* stream, double* tflops);
+
 #ifdef __cplusplus
 }
 #endif

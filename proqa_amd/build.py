@@ -20,10 +20,12 @@ SOURCES = [
     "npy_io.cpp",
     "mips_index.cpp",
     "mips_kernels.hip",
+    "sharded_search.cpp",
     "encoder_kernels.hip",
     "attention_kernel.hip",
     "encoder.cpp",
     "kmeans_kernels.hip",
+    "microbench.hip",
 ]
 
 

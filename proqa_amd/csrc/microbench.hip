@@ -1,0 +1,146 @@
+// Measured ceilings of the box the benchmark runs on (bench.py: "peak_measured"): a float4 stream copy and a
+// register-resident MFMA loop.  They are what SURVEY.md section 8(d) asks to be recorded next to the spec peaks
+// (HBM3E 8 TB/s, 2.5 PFLOP/s dense fp16 MFMA) that the roofline fractions are priced against.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace proqa {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Each workgroup streams its own contiguous slice (as the search kernel streams a corpus chunk): 16 bytes per lane
+// and access, eight accesses in flight per lane.
+constexpr int kStreamUnroll = 8;
+__global__ __launch_bounds__(256) void stream_copy(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n_vec) {
+  const size_t per_wg = (n_vec + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per_wg;
+  const size_t hi = lo + per_wg < n_vec ? lo + per_wg : n_vec;
+  size_t i = lo + threadIdx.x;
+  for (; i + (kStreamUnroll - 1) * 256 < hi; i += kStreamUnroll * 256) {
+    f32x4 v[kStreamUnroll];
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) __builtin_nontemporal_store(v[u], dst + i + u * 256);
+  }
+  for (; i < hi; i += 256) dst[i] = src[i];
+}
+
+// read-only variant: the search kernel's traffic is all reads
+__global__ __launch_bounds__(256) void stream_read(const f32x4* __restrict__ src, float* __restrict__ sink, size_t n_vec) {
+  const size_t per_wg = (n_vec + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per_wg;
+  const size_t hi = lo + per_wg < n_vec ? lo + per_wg : n_vec;
+  size_t i = lo + threadIdx.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + (kStreamUnroll - 1) * 256 < hi; i += kStreamUnroll * 256) {
+    f32x4 v[kStreamUnroll];
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < kStreamUnroll; ++u) acc += v[u];
+  }
+  for (; i < hi; i += 256) acc += src[i];
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e-30f) *sink = acc[0];   // keeps the loads alive
+}
+
+// 4 independent 32x32x16 fp16 MFMA chains per wave, operands from registers: nothing but the matrix pipe.
+// `zero` selects all-zero operands (the clock the chip sustains depends on the operand bits).
+__global__ __launch_bounds__(256) void mfma_loop(int iters, int zero, float* __restrict__ sink) {
+  f16x8 a, b;
+  for (int e = 0; e < 8; ++e) {
+    const unsigned h = (threadIdx.x * 2654435761u + e * 40503u + blockIdx.x * 97u) >> 7;
+    a[e] = zero ? (_Float16)0.f : (_Float16)((float)(int)(h & 1023) / 512.f - 1.f);
+    b[e] = zero ? (_Float16)0.f : (_Float16)((float)(int)((h >> 10) & 1023) / 512.f - 1.f);
+  }
+  f32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c3, 0, 0, 0);
+  }
+  const f32x16 s = c0 + c1 + c2 + c3;
+  float t = 0.f;
+  for (int e = 0; e < 16; ++e) t += s[e];
+  if (t == 1.2345e-30f) *sink = t;
+}
+
+}  // namespace
+}  // namespace proqa
+
+using namespace proqa;
+
+extern "C" {
+
+// kind 0: copy (bytes read + bytes written are both counted), kind 1: read only.  `buf` holds 2*bytes (copy) or
+// bytes (read); result in GB/s of the best of `reps` launches.
+int proqa_microbench_stream(void* buf, size_t bytes, int kind, int reps, void* stream, double* gbs) {
+  if (!buf || !gbs || bytes < (1u << 20) || reps <= 0 || kind < 0 || kind > 1)
+    return fail(PROQA_EINVAL, "microbench_stream: bad argument");
+  hipStream_t st = as_stream(stream);
+  hipEvent_t e0, e1;
+  PROQA_HIP(hipEventCreate(&e0));
+  PROQA_HIP(hipEventCreate(&e1));
+  const size_t n_vec = bytes / 16;
+  const unsigned grid = (unsigned)device_cu_count() * (getenv("PROQA_STREAM_WGS") ? atoi(getenv("PROQA_STREAM_WGS")) : 8);
+  float* sink = nullptr;
+  PROQA_HIP(hipMalloc((void**)&sink, 4));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    PROQA_HIP(hipEventRecord(e0, st));
+    if (kind == 0)
+      hipLaunchKernelGGL(stream_copy, dim3(grid), dim3(256), 0, st, (const f32x4*)buf, (f32x4*)((char*)buf + bytes), n_vec);
+    else
+      hipLaunchKernelGGL(stream_read, dim3(grid), dim3(256), 0, st, (const f32x4*)buf, sink, n_vec);
+    PROQA_HIP(hipEventRecord(e1, st));
+    PROQA_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PROQA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;   // first launch warms up
+  }
+  (void)hipFree(sink);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *gbs = (kind == 0 ? 2.0 : 1.0) * (double)(n_vec * 16) / (best * 1e-3) / 1e9;
+  return PROQA_OK;
+}
+
+// dense fp16 MFMA rate of a kernel that does nothing else: `ms_target` sets the launch length (the sustained
+// clock depends on it); zero_operands != 0 runs all-zero inputs.  Result in TFLOP/s.
+int proqa_microbench_mfma(double ms_target, int zero_operands, void* stream, double* tflops) {
+  if (!tflops || !(ms_target > 0)) return fail(PROQA_EINVAL, "microbench_mfma: bad argument");
+  hipStream_t st = as_stream(stream);
+  hipEvent_t e0, e1;
+  PROQA_HIP(hipEventCreate(&e0));
+  PROQA_HIP(hipEventCreate(&e1));
+  float* sink = nullptr;
+  PROQA_HIP(hipMalloc((void**)&sink, 4));
+  const unsigned grid = (unsigned)device_cu_count() * 2;   // 8 waves per CU, 2 per SIMD
+  // one MFMA = 32 cycles per SIMD; two waves share a SIMD: iters * 4 * 2 * 32 cycles per launch at ~2.4 GHz
+  int iters = (int)(ms_target * 1e-3 * 2.4e9 / (4 * 2 * 32));
+  if (iters < 64) iters = 64;
+  float best = 1e30f;
+  for (int r = 0; r < 4; ++r) {
+    PROQA_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(mfma_loop, dim3(grid), dim3(256), 0, st, iters, zero_operands, sink);
+    PROQA_HIP(hipEventRecord(e1, st));
+    PROQA_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PROQA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  (void)hipFree(sink);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const double flops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*chains*/ * 2.0 * 32 * 32 * 16;
+  *tflops = flops / (best * 1e-3) / 1e12;
+  return PROQA_OK;
+}
+
+}  // extern "C"

@@ -267,13 +267,15 @@ int ensure_store(proqa_index* idx, unsigned chunks, unsigned n_qtiles, int64_t n
 // so a slab of g*seen rows yields ~g*k candidates per query; g is capped so that those fit the
 // lane lists and one LDS merge pass next to the k running keys (kCandidateBudget per round).
 constexpr double kCandidateBudget = 640.0;
+// developer override of the budget (schedule experiments)
+const double kBudget = getenv("PROQA_CAND_BUDGET") ? atof(getenv("PROQA_CAND_BUDGET")) : kCandidateBudget;
 
 // Default growth: 4 for MFMA-bound batches (fewer candidates per round keep the rare path rare); 8 for
 // the HBM-bound small batches (one query tile per wave: two rounds fewer of launch + merge latency,
 // measured 6-9 % on the whole search at Q <= 256, 3 % slower at Q >= 1024).
 double growth_for(int k, int configured, int qw) {
   const int g = configured > 0 ? configured : (qw == 1 ? 8 : 4);
-  return std::min<double>(g, kCandidateBudget / k);
+  return std::min<double>(g, kBudget / k);
 }
 
 // `start` > 0: rows [0, start) were covered by the bootstrap
@@ -760,7 +762,7 @@ int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev
     return fail(PROQA_EINVAL, "topk_merge_device: bad argument");
   if ((long long)n_parts * k >= (1ll << 27))
     return fail(PROQA_EINVAL, "topk_merge_device: n_parts*k=%lld is too large", (long long)n_parts * k);
-  PROQA_HIP(launch_merge_lists(D_parts_dev, (const long long*)I_parts_dev, n_parts, nq, k, D_dev,
+  PROQA_HIP(launch_merge_lists(D_parts_dev, (const long long*)I_parts_dev, n_parts, nq, k, (long long)nq * k, (long long)nq * k, D_dev,
                                (long long*)I_dev, as_stream(stream)));
   return PROQA_OK;
 }

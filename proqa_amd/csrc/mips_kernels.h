@@ -100,8 +100,9 @@ hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long lon
 hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                            long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
                            hipStream_t st);
+// part p's [nq, k] scores / ids start stride_d / stride_i ELEMENTS after part p-1's (nq*k for dense [n_parts, nq, k] arrays)
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
-                              int k, float* D, long long* I, hipStream_t st);
+                              int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st);
 hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, unsigned* inexact, hipStream_t st);
 // exact-float32 mode helpers
 hipError_t launch_upconvert_f16_to_f32(const void* src, float* dst, long long n, hipStream_t st);

@@ -39,6 +39,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRowBytes = kDim * 2;                     // 256 B per fp16 corpus row
 constexpr int kStageBytes = kStageRows * kRowBytes;     // 32 KiB
 constexpr int kSubRows = 32;                            // one MFMA M-tile
+#ifndef PROQA_DMA_AUX
+#define PROQA_DMA_AUX 2
+#endif
+constexpr int kDmaAux = PROQA_DMA_AUX;                  // cache policy bits of the single-reader corpus stream
 constexpr int kSubBytes = kSubRows * kRowBytes;         // 8 KiB
 
 __device__ __forceinline__ unsigned ord_from_float(float f) {
@@ -196,9 +200,11 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
       int rel = s * kStageRows + dma_rel[e];
       rel = rel < n_rows ? rel : n_rows - 1;
       const char* src = chunk_base + (long long)rel * kRowBytes + dma_piece_off[e];
+      // QW == 1 is the single-query-tile launch: this workgroup is the only reader of its chunk, so the stream
+      // is fetched non-temporally (aux 2); with several query tiles the others re-read the chunk from L2
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(lds + buf_off + (wave * 4 + e) * 1024),
-                                       16, 0, 0);
+                                       16, 0, QW == 1 ? kDmaAux : 0);
     }
   };
 
@@ -995,16 +1001,17 @@ __global__ __launch_bounds__(256) void query_margins(const void* __restrict__ xq
 template <int NK>
 __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __restrict__ D_parts,
                                                             const long long* __restrict__ I_parts,
-                                                            int n_parts, long long nq, int k,
+                                                            int n_parts, long long nq, int k, long long stride_d, long long stride_i,
                                                             float* __restrict__ D, long long* __restrict__ I) {
+  // part p's [nq, k] scores / ids start stride_d / stride_i elements after part p-1's (nq*k for dense arrays)
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // max(256, pow2 >= n_parts*k) keys
   const long long q = blockIdx.x;
   const int tid = threadIdx.x;
   const unsigned total = (unsigned)n_parts * (unsigned)k;
   for (unsigned i = tid; i < total; i += kMergeThreads) {
     const unsigned p = i / k, j = i - p * k;
-    const size_t src = ((size_t)p * nq + q) * k + j;
-    keys[i] = I_parts[src] >= 0 ? pack_key(D_parts[src], i) : 0ull;
+    const size_t off = (size_t)q * k + j;
+    keys[i] = I_parts[(size_t)p * stride_i + off] >= 0 ? pack_key(D_parts[(size_t)p * stride_d + off], i) : 0ull;
   }
   __syncthreads();
   unsigned long long v[NK];
@@ -1018,7 +1025,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __rest
       const unsigned pos = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
       const unsigned p = pos / k, sj = pos - p * k;
       D[q * k + j] = float_from_ord((unsigned)(key >> 32));
-      I[q * k + j] = I_parts[((size_t)p * nq + q) * k + sj];
+      I[q * k + j] = I_parts[(size_t)p * stride_i + (size_t)q * k + sj];
     } else {
       D[q * k + j] = -3.4028234663852886e38f;
       I[q * k + j] = -1;
@@ -1030,7 +1037,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __rest
 // retrieval/trec_process.py:76): the same packed keys, laid out [query][part*k + j] in HBM, are sorted
 // per query by a segmented radix sort; the first k of every segment are the answer.
 __global__ void pack_part_keys(const float* __restrict__ D_parts, const long long* __restrict__ I_parts,
-                               int n_parts, long long nq, int k, long long q0, long long nq_chunk,
+                               int n_parts, long long nq, int k, long long stride_d, long long stride_i, long long q0, long long nq_chunk,
                                unsigned long long* __restrict__ keys) {
   const long long per_q = (long long)n_parts * k;
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1038,8 +1045,8 @@ __global__ void pack_part_keys(const float* __restrict__ D_parts, const long lon
   const long long qc = t / per_q;
   const unsigned i = (unsigned)(t - qc * per_q);
   const unsigned p = i / k, j = i - p * k;
-  const size_t src = ((size_t)p * nq + (q0 + qc)) * k + j;
-  keys[t] = I_parts[src] >= 0 ? pack_key(D_parts[src], i) : 0ull;
+  const size_t off = (size_t)(q0 + qc) * k + j;
+  keys[t] = I_parts[(size_t)p * stride_i + off] >= 0 ? pack_key(D_parts[(size_t)p * stride_d + off], i) : 0ull;
 }
 
 __global__ void segment_offsets(long long n_segments, int per_segment, int* __restrict__ offsets) {
@@ -1048,7 +1055,7 @@ __global__ void segment_offsets(long long n_segments, int per_segment, int* __re
 }
 
 __global__ void emit_sorted_prefix(const unsigned long long* __restrict__ keys, const long long* __restrict__ I_parts,
-                                   int n_parts, long long nq, int k, long long q0, long long nq_chunk,
+                                   int n_parts, long long nq, int k, long long stride_d, long long stride_i, long long q0, long long nq_chunk,
                                    float* __restrict__ D, long long* __restrict__ I) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nq_chunk * k) return;
@@ -1060,7 +1067,7 @@ __global__ void emit_sorted_prefix(const unsigned long long* __restrict__ keys, 
     const unsigned pos = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
     const unsigned p = pos / k, jj = pos - p * k;
     D[q * k + j] = float_from_ord((unsigned)(key >> 32));
-    I[q * k + j] = I_parts[((size_t)p * nq + q) * k + jj];
+    I[q * k + j] = I_parts[(size_t)p * stride_i + (size_t)q * k + jj];
   } else {
     D[q * k + j] = -3.4028234663852886e38f;
     I[q * k + j] = -1;
@@ -1185,7 +1192,7 @@ hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* r
 }
 
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
-                              int k, float* D, long long* I, hipStream_t st) {
+                              int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st) {
   if (nq == 0) return hipSuccess;
   const long long per_q = (long long)n_parts * k;
   if (per_q <= kMaxMergeListKeys) {
@@ -1199,7 +1206,7 @@ hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, in
       e = hipFuncSetAttribute((const void*)merge_lists<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
     if (e == hipSuccess)                                                                                            \
       hipLaunchKernelGGL(merge_lists<NK>, dim3((unsigned)nq), dim3(kMergeThreads), lds, st, D_parts, I_parts,       \
-                         n_parts, nq, k, D, I);                                                                     \
+                         n_parts, nq, k, stride_d, stride_i, D, I);                                                       \
     break;
     switch (P / kMergeThreads) {
       PROQA_MERGE_CASE(1)
@@ -1243,11 +1250,11 @@ hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, in
     const long long m = std::min(chunk_q, nq - q0);
     const long long items = m * per_q;
     hipLaunchKernelGGL(pack_part_keys, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, D_parts, I_parts,
-                       n_parts, nq, k, q0, m, keys_in);
+                       n_parts, nq, k, stride_d, stride_i, q0, m, keys_in);
     MERGE_TRY(hipcub::DeviceSegmentedRadixSort::SortKeysDescending(tmp, tmp_bytes, keys_in, keys_out, (int)items,
                                                                     (int)m, offsets, offsets + 1, 0, 64, st));
     hipLaunchKernelGGL(emit_sorted_prefix, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, st, keys_out, I_parts,
-                       n_parts, nq, k, q0, m, D, I);
+                       n_parts, nq, k, stride_d, stride_i, q0, m, D, I);
     MERGE_TRY(hipGetLastError());
   }
 #undef MERGE_TRY

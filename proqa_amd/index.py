@@ -213,7 +213,11 @@ class ShardedIndexFlatIP:
     distributed plumbing can be exercised with the gloo backend on CPU in the tests.
     """
 
-    def __init__(self, n_total, d=EMBED_DIM, group=None, local_search=None, merge=None, preallocate=True):
+    def __init__(self, n_total, d=EMBED_DIM, group=None, local_search=None, merge=None, preallocate=True,
+                 transport="torch"):
+        """transport: who runs the all-gather -- "torch" (torch.distributed, RCCL under the nccl backend) or "cabi"
+        (libproqa_hip.so's own RCCL communicator, proqa_sharded_search_device: the path a caller without PyTorch
+        uses; torch.distributed only carries the 128-byte communicator id to the ranks here)."""
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -225,8 +229,31 @@ class ShardedIndexFlatIP:
         self._local_search = local_search
         self._merge = merge or merge_topk_device
         self._index = None
+        self._comm = None
+        if transport not in ("torch", "cabi"):
+            raise ValueError(f"unknown transport {transport!r}")
+        self.transport = transport
         if local_search is None:
             self._index = IndexFlatIP(d, capacity=(self.hi - self.lo) if preallocate else 0)
+        if transport == "cabi":
+            if self._index is None:
+                raise ValueError('transport="cabi" needs the built-in HIP searcher')
+            self._comm = self._create_comm()
+
+    def _create_comm(self):
+        """proqa_comm over the ranks of the group: rank 0 draws the id, every rank joins (a collective)."""
+        lib = _lib.load()
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(lib.proqa_comm_get_unique_id(ident))
+        if self.world_size > 1:
+            box = [ident.raw]
+            self.dist.broadcast_object_list(box, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
+                                            group=self.group)
+            ident = ctypes.create_string_buffer(box[0], 128)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.proqa_comm_create(ident, self.world_size, self.rank, ctypes.byref(handle)))
+        return handle
 
     def add_local(self, xb_local):
         """Add this rank's rows (exactly rows [lo, hi) of the corpus, in order)."""
@@ -248,14 +275,17 @@ class ShardedIndexFlatIP:
     def local_index(self):
         return self._index
 
-    def search(self, xq, k):
-        """All ranks call with the same queries; returns torch tensors (D, I) on xq's device."""
+    def search(self, xq, k, force_collective=False):
+        """All ranks call with the same queries; returns torch tensors (D, I) on xq's device.
+        force_collective: go through the all-gather and the merge even with a single rank."""
         import torch
+        if self._comm is not None:
+            return self._search_cabi(xq, k)
         if self._local_search is not None:
             D, I = self._local_search(xq, k, self.lo)
         else:
             D, I = self._index.search_device(xq, k, idx_offset=self.lo)
-        if self.world_size == 1:
+        if self.world_size == 1 and not force_collective:
             return D, I
         # ONE collective: ids (int64) and scores (float32) travel as one byte buffer per rank;
         # rank-ordered slices of the gathered buffer are exactly the [n_parts, nq, k] layout the merge consumes
@@ -269,3 +299,36 @@ class ShardedIndexFlatIP:
         I_all = gathered[:, :n_i].contiguous().view(torch.int64).reshape((self.world_size,) + tuple(I.shape))
         D_all = gathered[:, n_i:].contiguous().view(torch.float32).reshape((self.world_size,) + tuple(D.shape))
         return self._merge(D_all, I_all)
+
+    def _search_cabi(self, xq, k):
+        """proqa_sharded_search_device: local search, RCCL all-gather and merge inside the library."""
+        import torch
+        if not xq.is_cuda:
+            raise ValueError("sharded search expects a CUDA tensor")
+        xq = xq.contiguous()
+        nq = xq.shape[0]
+        D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+        I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        lib = _lib.load()
+        with torch.cuda.device(xq.device):
+            for q0 in range(0, max(nq, 1), QUERY_BATCH):
+                part = xq[q0:q0 + QUERY_BATCH]
+                _lib.check(lib.proqa_sharded_search_device(self._index._h, self._comm, part.data_ptr(), part.shape[0],
+                                                           _torch_dtype_code(xq), int(k), int(self.lo),
+                                                           D[q0:].data_ptr(), I[q0:].data_ptr(),
+                                                           _lib.current_stream_ptr()))
+        return D, I
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            _lib.load().proqa_comm_free(self._comm)
+            self._comm = None
+        if getattr(self, "_index", None) is not None:
+            self._index.close()
+            self._index = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

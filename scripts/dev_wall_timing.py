@@ -17,8 +17,13 @@ xb = torch.empty((n, 128), dtype=torch.float16, device=dev)
 for r0 in range(0, n, 2_000_000):
     m = min(2_000_000, n - r0)
     xb[r0:r0 + m] = torch.randn((m, 128), generator=g, device=dev).to(torch.float16)
+import os
 ix = IndexFlatIP(128)
 ix.adopt_device(xb)
+if os.environ.get("BOOT"):
+    ix.configure_bootstrap(int(os.environ["BOOT"]))
+if os.environ.get("GROWTH"):
+    ix.configure(0, int(os.environ["GROWTH"]))
 for nq in nqs:
     xq = torch.randn((nq, 128), generator=g, device=dev).to(torch.float16)
     for _ in range(3):
