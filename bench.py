@@ -45,6 +45,11 @@ def parse():
     p.add_argument("--skip-encode", action="store_true")
     p.add_argument("--skip-float32", action="store_true", help="skip the exact-float32 index leg")
     p.add_argument("--skip-cpu", action="store_true")
+    p.add_argument("--transport", choices=["torch", "cabi"], default=os.environ.get("PROQA_SHARDED_TRANSPORT", "torch"),
+                   help="who runs the all-gather of the sharded search: torch.distributed (RCCL backend) or the "
+                        "library's own RCCL communicator (proqa_sharded_search_device)")
+    p.add_argument("--force-collective", action="store_true",
+                   help="run the all-gather + list merge even with one rank (exercises the RCCL path on one GPU)")
     return p.parse_args()
 
 
@@ -271,7 +276,7 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or (args.force_collective and "MASTER_ADDR" in os.environ):
         dist.init_process_group(backend=os.environ.get("PROQA_DIST_BACKEND", "nccl"))   # RCCL
 
     from proqa_amd.index import IndexFlatIP, ShardedIndexFlatIP, shard_bounds
@@ -280,12 +285,12 @@ def main():
     lo, hi = shard_bounds(n, world, rank)
     xb = gen_rows(lo, hi, device)
     xq = gen_queries(nq, device)
-    sharded = ShardedIndexFlatIP(n, preallocate=False)
+    sharded = ShardedIndexFlatIP(n, preallocate=False, transport=args.transport)
     sharded.adopt_local(xb)
     result = {}
 
     def step():
-        result["DI"] = sharded.search(xq, k)
+        result["DI"] = sharded.search(xq, k, force_collective=args.force_collective)
 
     dt = timed(step, args.steps, args.warmup, world, device)
     qps = nq * args.steps / dt
@@ -314,6 +319,9 @@ def main():
         "config": {"workload": f"HIP Q.P^T + top-{k}: {nq} queries over {n} x 128 fp16 index resident in HBM "
                                f"(BASELINE.json configs[2]; row-sharded over {world} GPU(s), configs[3])",
                    "rows": n, "queries": nq, "topk": k, "parallelism": f"corpus-row-shard x{world}",
+                   "exchange": ("none (single rank)" if world == 1 and not args.force_collective else
+                                f"one all-gather of per-rank top-{k} lists, transport={args.transport}, "
+                                f"backend={dist.get_backend() if dist.is_initialized() else 'rccl (library communicator)'}"),
                    "rounds": st["rounds"], "fallback_rounds": st["fallback_rounds"],
                    "candidates_per_query": st["candidates"] / max(nq, 1)},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
@@ -386,7 +394,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -95,6 +95,11 @@ constexpr int kMaxRounds = 96;
 // round (adds a host sync per round), PROQA_DEBUG_ROUNDS prints per-round filter times when profiling
 bool debug_flag(const char* name) { return getenv(name) != nullptr; }
 const bool kDebugCand = debug_flag("PROQA_DEBUG_CAND");
+// query blocks per wave for batches of more than 256 queries: 2 (8 waves x 64 queries) or, PROQA_FILTER_QW=4, the
+// 4-wave variant with 128 resident queries per wave (one wave per SIMD; experiment of DESIGN.md section 2.3)
+const unsigned kFilterFlags = getenv("PROQA_FILTER_FLAGS") ? (unsigned)atoi(getenv("PROQA_FILTER_FLAGS")) : 0u;
+const int kWideQw = getenv("PROQA_FILTER_QW") && (atoi(getenv("PROQA_FILTER_QW")) == 4 || atoi(getenv("PROQA_FILTER_QW")) == 1)
+                        ? atoi(getenv("PROQA_FILTER_QW")) : 2;
 const bool kDebugRounds = debug_flag("PROQA_DEBUG_ROUNDS");
 
 int ensure_device(proqa_index* idx) {
@@ -342,6 +347,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   fa.ub = bounded ? (idx->exact ? idx->ub_filter : idx->ub) : nullptr;
   fa.store = store_of(idx, (unsigned)idx->ws_nq_pad, n_qtiles);
   fa.overflow = overflow_word;
+  fa.flags = kFilterFlags;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
   PROQA_HIP(launch_filter(fa, qw, inclusive, g.grid, st));
   if (f1) PROQA_HIP(hipEventRecord(f1, st));
@@ -490,8 +496,8 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   if (int rc = ensure_device(idx)) return rc;
 
   // wave tile: 2 query blocks of 32 per wave (512 queries per workgroup) unless the batch is small
-  const int qw = nq > 256 ? 2 : 1;
-  const unsigned tile_q = kFilterWaves * qw * 32;
+  const int qw = nq > 256 ? kWideQw : 1;
+  const unsigned tile_q = filter_tile_queries(qw);
   const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
   const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
   if (int rc = ensure_workspace(idx, nq_pad, std::min(k, kPageK))) return rc;

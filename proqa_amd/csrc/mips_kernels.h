@@ -10,6 +10,8 @@ namespace proqa {
 constexpr int kDim = PROQA_EMBED_DIM;  // 128
 constexpr int kFilterWaves = 8;
 constexpr int kFilterThreads = kFilterWaves * 64;
+// queries of one filter workgroup: 8 waves x qw blocks of 32 (qw = 1, 2), or 4 waves x 4 blocks (qw = 4)
+__host__ __device__ constexpr unsigned filter_tile_queries(int qw) { return (qw == 4 ? 4u : 8u) * (unsigned)qw * 32u; }
 constexpr int kStageRows = 128;  // corpus rows per LDS stage (32 KiB of fp16 rows)
 constexpr int kMergeThreads = 256;
 // merge_lists sorts up to this many gathered keys per query in LDS (128 KiB); above it the merge
@@ -59,6 +61,7 @@ struct FilterArgs {
   const float* ub;       // paged (k > kPageK) searches: scores above ub[q] were reported by an earlier page
   CandidateStore store;
   unsigned* overflow;    // set to 1 if a record had to be dropped in this launch
+  unsigned flags;        // developer experiments (PROQA_FILTER_FLAGS), 0 in production
 };
 
 struct MergeArgs {

@@ -124,9 +124,9 @@ __device__ __forceinline__ void log_columns(const f32x16& acc, bool hit, float t
 //     At the barrier of stage s (before its unit 2): every wave is past stage s-1, whose buffer
 //     (s+2)%3 is therefore free for DMA(s+2); and every wave has drained (vmcnt 0) its pieces of
 //     DMA(s+1), issued one full stage earlier, so buffer (s+1)%3 is readable from unit 3 on.
-template <int QW, bool INCLUSIVE, bool BOUNDED>
-__global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) {
-  static_assert(QW == 1 || QW == 2, "two accumulators per unit");
+template <int QW, int NW, bool INCLUSIVE, bool BOUNDED>
+__global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
+  static_assert((QW == 1 || QW == 2) && NW == 8 || QW == 4 && NW == 4, "8 waves x 32/64 queries or 4 waves x 128 queries");
   // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads)
   __shared__ __attribute__((aligned(16))) char lds[3 * kStageBytes];
 
@@ -156,12 +156,12 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 
   // resident query fragments (MFMA B operand): lane (li, half), k-step j holds the 16-byte
   // piece 2j+half of query row q0 + blk*32 + li.
-  const unsigned q0 = qt * (kFilterWaves * QW * 32) + wave * (QW * 32);
+  const unsigned q0 = qt * (NW * QW * 32) + wave * (QW * 32);
   f16x8 qf[QW][8];
-  float tau[2] = {0.f, 0.f};
-  float ub[2] = {0.f, 0.f};  // BOUNDED (pages after the first of a k > kPageK search)
-  WaveRecord* lane_list[2] = {nullptr, nullptr};
-  unsigned lane_n[2] = {0u, 0u};
+  float tau[QW];
+  float ub[QW];              // BOUNDED (pages after the first of a k > kPageK search)
+  WaveRecord* lane_list[QW];
+  unsigned lane_n[QW];
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk) {
     const unsigned q = q0 + blk * 32 + li;
@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[blk][j] = *(const f16x8*)(qrow + (2 * j + half) * 16);
     tau[blk] = a.tau[q];
-    if (BOUNDED) ub[blk] = a.ub[q];
+    ub[blk] = BOUNDED ? a.ub[q] : 0.f;
+    lane_n[blk] = 0u;
     lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * kLaneCap;
   }
   const unsigned wave_slot = (chunk * a.store.n_qtiles + qt) * kFilterWaves + wave;
@@ -185,25 +186,26 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
   // LDS-DMA: per stage each wave issues 4 instructions of 1 KiB (4 corpus rows); lane t lands
   // at base + 16 t = (row t>>4, slot t&15) and therefore fetches piece (t&15) ^ (row&15).
   // Rows past the chunk end re-read the chunk's last row (never logged: rows_left excludes them).
+  constexpr int kDmaPerWave = 32 / NW;   // 1 KiB pieces of a 32 KiB stage each wave fetches
   const int dma_row = lane >> 4;
   const int dma_slot = lane & 15;
-  int dma_rel[4];
-  int dma_piece_off[4];
+  int dma_rel[kDmaPerWave];
+  int dma_piece_off[kDmaPerWave];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    dma_rel[e] = (wave * 4 + e) * 4 + dma_row;
-    dma_piece_off[e] = (dma_slot ^ ((e * 4 + dma_row) & 15)) * 16;
+  for (int e = 0; e < kDmaPerWave; ++e) {
+    dma_rel[e] = (wave * kDmaPerWave + e) * 4 + dma_row;
+    dma_piece_off[e] = (dma_slot ^ (dma_rel[e] & 15)) * 16;
   }
   auto issue_stage = [&](int s, int buf_off) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < kDmaPerWave; ++e) {
       int rel = s * kStageRows + dma_rel[e];
       rel = rel < n_rows ? rel : n_rows - 1;
       const char* src = chunk_base + (long long)rel * kRowBytes + dma_piece_off[e];
       // QW == 1 is the single-query-tile launch: this workgroup is the only reader of its chunk, so the stream
       // is fetched non-temporally (aux 2); with several query tiles the others re-read the chunk from L2
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lds + buf_off + (wave * 4 + e) * 1024),
+                                       (__attribute__((address_space(3))) void*)(lds + buf_off + (wave * kDmaPerWave + e) * 1024),
                                        16, 0, QW == 1 ? kDmaAux : 0);
     }
   };
@@ -215,14 +217,19 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
   if (nstages > 1) issue_stage(1, off1);
   dma_wait_barrier();  // prologue only: both stages landed
 
+  if ((a.flags & 1u) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
+  if ((a.flags & 2u) && (wave & 1)) __builtin_amdgcn_s_setprio(1);         // experiment: every other wave
   f16x8 af[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(lds + off0 + rd_off[j]);
-  f32x16 pend[2] = {{0}, {0}};
+  f32x16 pend[QW];
+#pragma unroll
+  for (int blk = 0; blk < QW; ++blk) pend[blk] = f32x16{0};
   int pend_rel0 = -1;  // no pending unit yet
 
   auto test_and_log = [&](bool valid) {
-    bool hit[2] = {false, false};
+    bool hit[QW];
+    bool any_hit = false;
 #pragma unroll
     for (int blk = 0; blk < QW; ++blk) {
       if (BOUNDED) {  // rows scoring above the page bound were reported by an earlier page
@@ -233,8 +240,9 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
 #pragma unroll
       for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
       hit[blk] = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
+      any_hit = any_hit || hit[blk];
     }
-    if (__builtin_expect(__any((hit[0] || hit[1]) && valid), 0)) {
+    if (__builtin_expect(__any(any_hit && valid), 0)) {
 #pragma unroll
       for (int blk = 0; blk < QW; ++blk)
         if (__any(hit[blk]))
@@ -277,7 +285,9 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
       // where the next unit's fragments live (next stage's buffer after the last unit)
       const char* nxt = (u + 1 < kSubs) ? lds + off0 + (u + 1) * kSubBytes : lds + off1;
 
-      f32x16 cur[2] = {{0}, {0}};
+      f32x16 cur[QW];
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk) cur[blk] = f32x16{0};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -298,8 +308,8 @@ __global__ __launch_bounds__(kFilterThreads) void mips_filter_f16(FilterArgs a) 
       // lane-local test of the PREVIOUS unit, scheduled under the MFMAs just issued
       test_and_log(pend_rel0 >= 0);
 
-      pend[0] = cur[0];
-      pend[1] = cur[1];
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk) pend[blk] = cur[blk];
       pend_rel0 = s * kStageRows + u * kSubRows;
     }
     const int t = off0;
@@ -489,7 +499,7 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
   const unsigned long long run_pref = (unsigned)tid < nrun ? a.run_keys[(size_t)q * a.k + tid] : 0ull;
 
   // the wave slot that owns q in every chunk
-  const unsigned tile_q = kFilterWaves * a.qw * 32;
+  const unsigned tile_q = filter_tile_queries((int)a.qw);
   const unsigned qt = q / tile_q;
   const unsigned wave = (q - qt * tile_q) / (a.qw * 32);
 
@@ -848,7 +858,8 @@ __global__ void prep_queries(const void* xq, int dtype, long long nq, long long 
   if (i < nq_pad) {
     // padded queries (and queries a paged search has already exhausted) never log
     const bool live = i < nq && !debug_nohit && !(done && done[i]);
-    tau[i] = live ? -__builtin_inff() : __builtin_inff();
+    // debug_nohit: a finite threshold nothing beats -- the waves stay live (full MFMA work) but never log
+    tau[i] = live ? -__builtin_inff() : (debug_nohit && i < nq ? 3.0e38f : __builtin_inff());
     run_n[i] = 0;
     if (reset_stat) stat[i] = 0;
   }
@@ -1079,26 +1090,31 @@ __global__ void emit_sorted_prefix(const unsigned long long* __restrict__ keys, 
 // ---------------------------------------------------------------------------------------
 // launch wrappers (called from mips_index.cpp)
 // ---------------------------------------------------------------------------------------
-template <int QW, bool INCLUSIVE>
-static void launch_filter_bounded(const FilterArgs& a, dim3 g, dim3 blk, hipStream_t st) {
+template <int QW, int NW, bool INCLUSIVE>
+static void launch_filter_bounded(const FilterArgs& a, dim3 g, hipStream_t st) {
   if (a.ub)
-    hipLaunchKernelGGL((mips_filter_f16<QW, INCLUSIVE, true>), g, blk, 0, st, a);
+    hipLaunchKernelGGL((mips_filter_f16<QW, NW, INCLUSIVE, true>), g, dim3(NW * 64), 0, st, a);
   else
-    hipLaunchKernelGGL((mips_filter_f16<QW, INCLUSIVE, false>), g, blk, 0, st, a);
+    hipLaunchKernelGGL((mips_filter_f16<QW, NW, INCLUSIVE, false>), g, dim3(NW * 64), 0, st, a);
 }
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st) {
-  dim3 g(grid), blk(kFilterThreads);
-  if (qw == 2) {
+  dim3 g(grid);
+  if (qw == 4) {
     if (inclusive)
-      launch_filter_bounded<2, true>(a, g, blk, st);
+      launch_filter_bounded<4, 4, true>(a, g, st);
     else
-      launch_filter_bounded<2, false>(a, g, blk, st);
+      launch_filter_bounded<4, 4, false>(a, g, st);
+  } else if (qw == 2) {
+    if (inclusive)
+      launch_filter_bounded<2, 8, true>(a, g, st);
+    else
+      launch_filter_bounded<2, 8, false>(a, g, st);
   } else {
     if (inclusive)
-      launch_filter_bounded<1, true>(a, g, blk, st);
+      launch_filter_bounded<1, 8, true>(a, g, st);
     else
-      launch_filter_bounded<1, false>(a, g, blk, st);
+      launch_filter_bounded<1, 8, false>(a, g, st);
   }
   return hipGetLastError();
 }
