@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROQA_ABI_VERSION 1
+#define PROQA_ABI_VERSION 2
 
 /* element types of embedding matrices (the .npy index is '<f2' under --fp16, else '<f4':
  * retrieval/get_embed.py:139) */
@@ -127,13 +127,6 @@ int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
  * segmented radix sort in HBM (temporary buffers are allocated for the call). */
 int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts,
                             int64_t nq, int k, float* D_dev, int64_t* I_dev, void* stream);
-
-/* ------------------------------------------------------------------------------------
- * Encoder kernels.  Replace the non-GEMM arithmetic of
- *     BertForRetriever.get_embed (retrieval/retriever.py:33-43)
- * i.e. transformers' BertModel forward; the 768x768 / 768x3072 GEMMs stay on
- * PyTorch-ROCm (hipBLASLt).  All tensors fp16 row-major in HBM, fp32 statistics.
- * ---------------------------------------------------------------------------------- */
 
 /* ------------------------------------------------------------------------------------
  * Encoder: BertForRetriever.get_embed (retrieval/retriever.py:33-43 + transformers BertModel)
@@ -287,7 +280,9 @@ int proqa_npy_read_rows(const char* path, int64_t row0, int64_t n, void* dst, si
 int proqa_npy_write(const char* path, const void* data, int64_t rows, int64_t cols, int dtype);
 /* create a pre-sized file (header + zero-filled data) that ranks later fill by row range */
 int proqa_npy_create(const char* path, int64_t rows, int64_t cols, int dtype);
-int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* src);
+/* src: n rows of `cols` elements of `dtype`; both must match the file's header (a rank writing float32 rows into a
+ * '<f2' file is refused) */
+int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* src, int64_t cols, int dtype);
 
 /* ------------------------------------------------------------------------------------
  * Multi-GPU search without PyTorch (BASELINE.json configs[3]).  One process (or thread)

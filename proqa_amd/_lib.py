@@ -117,7 +117,7 @@ SIGNATURES = {
     "proqa_npy_read_rows": (c_int, [c_char_p, c_int64, c_int64, c_void_p, c_size_t]),
     "proqa_npy_write": (c_int, [c_char_p, c_void_p, c_int64, c_int64, c_int]),
     "proqa_npy_create": (c_int, [c_char_p, c_int64, c_int64, c_int]),
-    "proqa_npy_write_rows": (c_int, [c_char_p, c_int64, c_int64, c_void_p]),
+    "proqa_npy_write_rows": (c_int, [c_char_p, c_int64, c_int64, c_void_p, c_int64, c_int]),
     "proqa_comm_get_unique_id": (c_int, [c_void_p]),
     "proqa_comm_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "proqa_comm_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
@@ -182,7 +182,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.proqa_abi_version() != 1:
+        if lib.proqa_abi_version() != 2:
             raise RuntimeError("libproqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
         return lib

@@ -43,27 +43,55 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _child_env():
+    """Environment of the compiler children: a profiler's or sanitizer's LD_PRELOAD belongs to the process under
+    test, not to hipcc / g++."""
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)
+    return env
+
+
 def build(force=False, verbose=False):
-    """Compile every source for gfx950 and link csrc/libproqa_hip.so. Returns its path."""
+    """Compile every source for gfx950 and link csrc/libproqa_hip.so. Returns its path.
+
+    Safe when several processes start at once (torchrun ranks on a never-built checkout): one exclusive lock
+    around the whole build, objects and the library are written under temporary names and renamed into place,
+    so nobody can dlopen a half-written file."""
+    import fcntl
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "proqa_hip.h"))
-    objs = []
-    for src in SOURCES:
-        path = os.path.join(CSRC, src)
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        objs.append(obj)
-        if force or _stale(obj, [path] + headers):
-            cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-                   "-Wall", "-Wno-unused-function", "-c", path, "-o", obj]
+    env = _child_env()
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)          # released when the file is closed
+        objs = []
+        for src in SOURCES:
+            path = os.path.join(CSRC, src)
+            obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+            objs.append(obj)
+            if force or _stale(obj, [path] + headers):   # re-checked under the lock: another rank may have built it
+                tmp = f"{obj}.{os.getpid()}.tmp"
+                cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+                       "-Wall", "-Wno-unused-function", "-c", path, "-o", tmp]
+                if verbose:
+                    print(" ".join(cmd), file=sys.stderr)
+                try:
+                    subprocess.run(cmd, check=True, env=env)
+                    os.replace(tmp, obj)
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
+        if force or _stale(LIB_PATH, objs):
+            tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
+            cmd = ["g++", "-shared", "-o", tmp] + objs + ["-Wl,--no-as-needed", "-lpthread", "-lm", "-ldl"]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.run(cmd, check=True)
-    if force or _stale(LIB_PATH, objs):
-        cmd = ["g++", "-shared", "-o", LIB_PATH] + objs + ["-Wl,--no-as-needed", "-lpthread", "-lm"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True)
+            try:
+                subprocess.run(cmd, check=True, env=env)
+                os.replace(tmp, LIB_PATH)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
     return LIB_PATH
 
 

@@ -305,12 +305,6 @@ __global__ __launch_bounds__(256) void attention_cls_fwd(const _Float16* __restr
 }  // namespace
 }  // namespace proqa
 
-using namespace proqa;
-
-namespace {
-
-}  // namespace
-
 namespace proqa {
 
 int launch_attention(const void* qkv, const void* qkv_bias, const int32_t* seq_lens_dev, const int32_t* cu_seqlens_dev,

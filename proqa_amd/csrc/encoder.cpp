@@ -144,7 +144,7 @@ int gemm_tn(proqa_encoder* e, const _Float16* x, const void* w, _Float16* out, i
   return PROQA_OK;
 }
 
-int ensure_workspace(proqa_encoder* e, int batch, int64_t rows) {
+int ensure_workspace(proqa_encoder* e, int batch, int64_t rows, hipStream_t st) {
   Workspace& ws = e->ws;
   if (rows <= ws.rows && batch <= ws.batch) return PROQA_OK;
   rows = std::max(rows, ws.rows);
@@ -161,8 +161,9 @@ int ensure_workspace(proqa_encoder* e, int batch, int64_t rows) {
   ws = Workspace();
   hipError_t err = hipMalloc(&ws.base, total);
   if (err != hipSuccess) return fail(PROQA_ENOMEM, "encoder workspace of %zu B: %s", total, hipGetErrorString(err));
-  // rows past the last token are only ever GEMM/element-wise padding: start them at zero (finite)
-  PROQA_HIP(hipMemset(ws.base, 0, total));
+  // rows past the last token are only ever GEMM/element-wise padding: start them at zero (finite); on the
+  // stream of the forward pass, which may be a non-blocking stream the null stream does not order with
+  PROQA_HIP(hipMemsetAsync(ws.base, 0, total, st));
   char* p = (char*)ws.base;
   _Float16** slots[] = {&ws.h, &ws.h1, &ws.qkv, &ws.ctx, &ws.tmp, &ws.ff, &ws.c_ctx, &ws.c_res, &ws.c_tmp, &ws.c_h1,
                         &ws.c_ff, &ws.c_h, &ws.pooled};
@@ -254,9 +255,13 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
   // off at its regular padded shape
   const bool packed = (flags & PROQA_ENC_PACKED) && n_valid_tokens > 0 && n_valid_tokens * 10 < n_padded * 9;
   const bool cls_only = (flags & PROQA_ENC_CLS_ONLY_LAST) != 0;
-  if (int rc = ensure_workspace(e, batch, round_up<int64_t>(n_padded, kRowTile))) return rc;
-  Workspace& ws = e->ws;
+  // the weights, the workspace and the BLAS handle live on the device the encoder was created on
+  int dev = 0;
+  PROQA_HIP(hipGetDevice(&dev));
+  if (dev != e->device) PROQA_HIP(hipSetDevice(e->device));
   hipStream_t st = as_stream(stream);
+  if (int rc = ensure_workspace(e, batch, round_up<int64_t>(n_padded, kRowTile), st)) return rc;
+  Workspace& ws = e->ws;
   PROQA_BLAS(rocblas_set_stream(e->blas, st));
 
   int64_t n = n_padded;

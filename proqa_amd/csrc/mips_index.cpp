@@ -71,6 +71,7 @@ struct proqa_index {
   size_t stage_bytes = 0;
   void* stage_pinned = nullptr;
   size_t stage_pinned_bytes = 0;
+  hipStream_t io_stream = nullptr;         // stream of the host-pointer search (proqa_index_search)
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipEvent_t ev_filter[2 * 96] = {};       // per-round brackets, created when profiling is on
   bool profile = false;
@@ -443,17 +444,38 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
     return PROQA_OK;
   }
   const int fallback_before = *fallback_out;
+  // Overflow-safe re-scan of a round that dropped candidates (its running lists are still valid subsets and its
+  // thresholds valid lower bounds).  The slab is scanned again with the inclusive threshold (rows already merged
+  // come back and are de-duplicated by the merge) in four pieces, one after the other, so that each piece sees the
+  // thresholds the previous ones tightened; a piece that overflows again is split further, down to sub-slabs that
+  // hold fewer rows than one merge pass holds keys and are scanned densely (single-stage chunks): those cannot
+  // overflow.  An unlucky batch therefore costs about one more pass over the slab, not thousands of launches;
+  // only an adversarial row order reaches the dense leaves.
+  const long long leaf_rows = (long long)((kMaxSortKeys - page_k) / kStageRows) * kStageRows;
+  unsigned* word = idx->overflow + kMaxRounds - 1;
   for (size_t r = 0; r < slabs.size(); ++r) {
     if (!idx->overflow_host[r]) continue;
-    // overflow-safe re-scan: a sub-slab has fewer rows than one merge pass holds keys and every
-    // chunk is a single stage, so neither the lane lists nor the merge can overflow
-    const long long step = (long long)((kMaxSortKeys - page_k) / kStageRows) * kStageRows;
-    for (long long r0 = slabs[r].r0; r0 < slabs[r].r1; r0 += step) {
-      Slab sub{r0, std::min(slabs[r].r1, r0 + step)};
-      if (int rc = run_round(idx, sub, qw, n_qtiles, (unsigned)nq_pad, page_k, true, true, bounded,
-                             idx->overflow + kMaxRounds - 1, st, nullptr, nullptr))
+    std::vector<Slab> todo;
+    auto push_quarters = [&](const Slab& sl) {   // pushed in reverse: the stack pops them in row order
+      const long long q = round_up<long long>(ceil_div<long long>(sl.r1 - sl.r0, 4), kStageRows);
+      for (int i = 3; i >= 0; --i) {
+        const long long a0 = sl.r0 + i * q, a1 = std::min(sl.r1, a0 + q);
+        if (a0 < a1) todo.push_back({a0, a1});
+      }
+    };
+    push_quarters(slabs[r]);
+    while (!todo.empty()) {
+      const Slab sub = todo.back();
+      todo.pop_back();
+      const bool leaf = sub.r1 - sub.r0 <= leaf_rows;
+      if (!leaf) PROQA_HIP(hipMemsetAsync(word, 0, sizeof(unsigned), st));
+      if (int rc = run_round(idx, sub, qw, n_qtiles, (unsigned)nq_pad, page_k, true, leaf, bounded, word, st, nullptr, nullptr))
         return rc;
       ++*fallback_out;
+      if (leaf) continue;
+      PROQA_HIP(hipMemcpyAsync(idx->overflow_host + kMaxRounds - 1, word, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      PROQA_HIP(hipStreamSynchronize(st));
+      if (idx->overflow_host[kMaxRounds - 1]) push_quarters(sub);
     }
   }
   if (*fallback_out != fallback_before) {
@@ -591,6 +613,7 @@ int proqa_index_free(proqa_index* idx) {
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
   if (idx->boot_scores) (void)hipFree(idx->boot_scores);
   if (idx->stage_pinned) (void)hipHostFree(idx->stage_pinned);
+  if (idx->io_stream) (void)hipStreamDestroy(idx->io_stream);
   for (auto& e : idx->ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : idx->ev_filter)
@@ -747,18 +770,34 @@ int proqa_index_search(proqa_index* idx, const void* xq, int64_t nq, int dtype, 
   if (nq == 0) return PROQA_OK;
   if (k <= 0) return fail(PROQA_EINVAL, "index_search: k=%d", k);
   if (int rc = ensure_device(idx)) return rc;
+  // host buffers cross through one pinned staging area on the index's own stream: queries up, the search, results
+  // down, ONE synchronisation (pageable hipMemcpy calls on the null stream would each stage and synchronise)
   const size_t esz = dtype == PROQA_F16 ? 2 : 4;
   const size_t q_bytes = round_up<size_t>((size_t)nq * kDim * esz, 256);
   const size_t d_bytes = round_up<size_t>((size_t)nq * k * sizeof(float), 256);
   const size_t i_bytes = (size_t)nq * k * sizeof(int64_t);
-  if (int rc = ensure_stage(idx, q_bytes + d_bytes + i_bytes)) return rc;
-  char* base = (char*)idx->stage_dev;
-  PROQA_HIP(hipMemcpy(base, xq, (size_t)nq * kDim * esz, hipMemcpyHostToDevice));
-  float* D_dev = (float*)(base + q_bytes);
-  int64_t* I_dev = (int64_t*)(base + q_bytes + d_bytes);
-  if (int rc = search_device(idx, base, nq, dtype, k, 0, D_dev, I_dev, nullptr)) return rc;
-  PROQA_HIP(hipMemcpy(D, D_dev, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost));
-  PROQA_HIP(hipMemcpy(I, I_dev, i_bytes, hipMemcpyDeviceToHost));
+  const size_t total = q_bytes + d_bytes + i_bytes;
+  if (int rc = ensure_stage(idx, total)) return rc;
+  if (total > idx->stage_pinned_bytes) {
+    if (idx->stage_pinned) PROQA_HIP(hipHostFree(idx->stage_pinned));
+    idx->stage_pinned = nullptr;
+    idx->stage_pinned_bytes = 0;
+    PROQA_HIP(hipHostMalloc(&idx->stage_pinned, total, hipHostMallocDefault));
+    idx->stage_pinned_bytes = total;
+  }
+  if (!idx->io_stream) PROQA_HIP(hipStreamCreateWithFlags(&idx->io_stream, hipStreamNonBlocking));
+  hipStream_t st = idx->io_stream;
+  char* dev = (char*)idx->stage_dev;
+  char* host = (char*)idx->stage_pinned;
+  memcpy(host, xq, (size_t)nq * kDim * esz);
+  PROQA_HIP(hipMemcpyAsync(dev, host, (size_t)nq * kDim * esz, hipMemcpyHostToDevice, st));
+  float* D_dev = (float*)(dev + q_bytes);
+  int64_t* I_dev = (int64_t*)(dev + q_bytes + d_bytes);
+  if (int rc = search_device(idx, dev, nq, dtype, k, 0, D_dev, I_dev, st)) return rc;
+  PROQA_HIP(hipMemcpyAsync(host + q_bytes, dev + q_bytes, d_bytes + i_bytes, hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipStreamSynchronize(st));
+  memcpy(D, host + q_bytes, (size_t)nq * k * sizeof(float));
+  memcpy(I, host + q_bytes + d_bytes, i_bytes);
   return PROQA_OK;
 }
 

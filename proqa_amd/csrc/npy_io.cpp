@@ -28,6 +28,19 @@ struct File {
   }
 };
 
+// Writers end with this: the buffered tail is flushed (and, for files several ranks fill, synced) and the close
+// result is checked, so that ENOSPC / quota / NFS errors surface as PROQA_EIO like np.save would raise them.
+int close_written(File& fh, const char* path, bool sync) {
+  FILE* f = fh.f;
+  fh.f = nullptr;
+  int err = 0;
+  if (fflush(f) != 0) err = errno;
+  if (!err && sync && fsync(fileno(f)) != 0) err = errno;
+  if (fclose(f) != 0 && !err) err = errno;
+  if (err) return fail(PROQA_EIO, "%s: flushing the file failed: %s", path, strerror(err));
+  return PROQA_OK;
+}
+
 bool find_value(const std::string& h, const char* key, size_t* pos) {
   std::string pat = std::string("'") + key + "'";
   size_t p = h.find(pat);
@@ -170,7 +183,7 @@ int proqa_npy_write(const char* path, const void* data, int64_t rows, int64_t co
   const size_t bytes = (size_t)rows * cols * elem_size(dtype);
   if (fwrite(h.data(), 1, h.size(), fh.f) != h.size() || (bytes && fwrite(data, 1, bytes, fh.f) != bytes))
     return fail(PROQA_EIO, "%s: write failed: %s", path, strerror(errno));
-  return PROQA_OK;
+  return close_written(fh, path, false);
 }
 
 int proqa_npy_create(const char* path, int64_t rows, int64_t cols, int dtype) {
@@ -184,16 +197,19 @@ int proqa_npy_create(const char* path, int64_t rows, int64_t cols, int dtype) {
   const long long total = (long long)h.size() + (long long)rows * cols * (long long)elem_size(dtype);
   if (fflush(fh.f) != 0 || ftruncate(fileno(fh.f), (off_t)total) != 0)
     return fail(PROQA_EIO, "%s: cannot size file to %lld bytes: %s", path, total, strerror(errno));
-  return PROQA_OK;
+  return close_written(fh, path, true);
 }
 
-int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* src) {
+int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* src, int64_t cols, int dtype) {
   if (!path || row0 < 0 || n < 0 || (!src && n > 0)) return fail(PROQA_EINVAL, "npy_write_rows: bad argument");
   proqa_npy_info info;
   File fh;
   fh.f = fopen(path, "r+b");
   if (!fh.f) return fail(PROQA_EIO, "cannot open %s for update: %s", path, strerror(errno));
   if (int rc = parse_header(fh.f, path, &info)) return rc;
+  if (cols != info.cols || dtype != info.dtype)
+    return fail(PROQA_EINVAL, "%s holds %lld-column rows of dtype %d; the rows to write have %lld columns of dtype %d",
+                path, (long long)info.cols, info.dtype, (long long)cols, dtype);
   if (row0 + n > info.rows) return fail(PROQA_EINVAL, "%s: rows [%lld,%lld) out of range (%lld rows)", path,
                                         (long long)row0, (long long)(row0 + n), (long long)info.rows);
   const size_t row_bytes = (size_t)info.cols * elem_size(info.dtype);
@@ -201,7 +217,7 @@ int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* 
     return fail(PROQA_EIO, "%s: seek failed", path);
   const size_t bytes = (size_t)n * row_bytes;
   if (bytes && fwrite(src, 1, bytes, fh.f) != bytes) return fail(PROQA_EIO, "%s: write failed: %s", path, strerror(errno));
-  return PROQA_OK;
+  return close_written(fh, path, true);
 }
 
 }  // extern "C"

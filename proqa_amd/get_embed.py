@@ -75,6 +75,8 @@ def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=Tru
     chunks = []
     streams = [torch.cuda.Stream(device=device) for _ in range(N_STREAMS)]
     main = torch.cuda.current_stream(device)
+    for s in streams:
+        s.wait_stream(main)     # pool streams are non-blocking: order them after the weight preparation on `main`
     for i, batch in enumerate(eval_dataloader):
         if not _right_padded(batch["input_mask"]):
             raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")

@@ -131,10 +131,29 @@ class KMeans:
 
 
 def clusering(data, niter=1000, verbose=True, ncentroids=1024, max_points_per_centroid=10000000, gpu_id=0,
-              spherical=False):
-    """(D [n,1] float32, I [n,1] int64) like the reference's clusering() (its spelling)."""
+              spherical=False, allow_fp16_rounding=False):
+    """(D [n,1] float32, I [n,1] int64) like the reference's clusering() (its spelling).
+
+    The reference clusters `np.float32(x)` (retrieval/group_paras.py:72-73); the points live in HBM as fp16 here.
+    For the embeddings get_embed.py writes under --fp16 ('<f2' files) the float32 upcast holds exactly the fp16
+    values, so nothing is lost.  float32 values fp16 cannot hold are never rounded silently: they are refused
+    unless allow_fp16_rounding is set (the search index has an exact-float32 mode for such data; the k-means
+    does not)."""
     device = torch.device("cuda", gpu_id)
-    x = torch.from_numpy(np.ascontiguousarray(data)).to(device=device, dtype=torch.float16)
+    data = np.ascontiguousarray(data)
+    if data.dtype not in (np.float16, np.float32):
+        raise TypeError(f"embeddings must be float16 or float32, got {data.dtype}")
+    x = torch.empty(data.shape, dtype=torch.float16, device=device)
+    step = 1 << 20
+    inexact = 0
+    for r0 in range(0, data.shape[0], step):
+        piece = torch.from_numpy(data[r0:r0 + step]).to(device)
+        x[r0:r0 + step] = piece.to(torch.float16)
+        if data.dtype == np.float32 and not allow_fp16_rounding:
+            inexact += int((x[r0:r0 + step].float() != piece).sum())     # NaN counts as inexact: refused as well
+    if inexact:
+        raise ValueError(f"{inexact} float32 values are not representable in fp16; clustering them would round the "
+                         "points silently. Pass allow_fp16_rounding=True (--allow-fp16-rounding) to accept that.")
     km = KMeans(x.shape[1], ncentroids, niter=niter, max_points_per_centroid=max_points_per_centroid, verbose=verbose,
                 spherical_metric=spherical)
     with torch.cuda.device(device):
@@ -165,6 +184,8 @@ def main(argv=None):
     parser.add_argument("--max_points_per_centroid", type=int, default=1000)
     parser.add_argument("--indexpath", type=str, default=None)
     parser.add_argument("--spherical", action="store_true")
+    parser.add_argument("--allow-fp16-rounding", action="store_true",
+                        help="cluster float32 embeddings that fp16 cannot hold after rounding them to fp16")
     # the reference hard-codes these three paths (:61-62, :14)
     parser.add_argument("--train_para_embed_path", type=str, default="encodings/train_para_embed.npy")
     parser.add_argument("--split_save_path", type=str, default="../data/data_splits/")
@@ -180,7 +201,8 @@ def main(argv=None):
     from . import npy
     x = npy.load(args.train_para_embed_path)
     D, I = clusering(x, niter=args.niter, ncentroids=args.ncentroids,
-                     max_points_per_centroid=args.max_points_per_centroid, spherical=args.spherical)
+                     max_points_per_centroid=args.max_points_per_centroid, spherical=args.spherical,
+                     allow_fp16_rounding=args.allow_fp16_rounding)
     group_paras(I, args.ncentroids, split_path=split_save_path, train_file=args.train_file)
     return D, I
 

@@ -68,4 +68,7 @@ def create(path, rows, cols, dtype):
 
 def write_rows(path, row0, array):
     array = np.ascontiguousarray(array)
-    _lib.check(_lib.load().proqa_npy_write_rows(path.encode(), row0, array.shape[0], array.ctypes.data))
+    if array.ndim != 2:
+        raise ValueError("embedding matrices are 2-D")
+    _lib.check(_lib.load().proqa_npy_write_rows(path.encode(), row0, array.shape[0], array.ctypes.data,
+                                                array.shape[1], _code(array.dtype)))

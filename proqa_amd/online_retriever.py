@@ -24,10 +24,11 @@ class OnlineRetriever:
         index2paraid: the idx_id.json mapping {"<row>": paragraph id} or None."""
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         para_embed = np.ascontiguousarray(para_embed)
-        self.index = IndexFlatIP(128, capacity=para_embed.shape[0])
-        step = 1 << 21
-        for r0 in range(0, para_embed.shape[0], step):
-            self.index.add(para_embed[r0:r0 + step])
+        with torch.cuda.device(self.device):      # proqa_index_create binds the index to the current device
+            self.index = IndexFlatIP(128, capacity=para_embed.shape[0])
+            step = 1 << 21
+            for r0 in range(0, para_embed.shape[0], step):
+                self.index.add(para_embed[r0:r0 + step])
         self.para_embed = para_embed
         self.index2paraid = index2paraid
 
@@ -46,7 +47,8 @@ class OnlineRetriever:
             _, I = self.index.search_device(q_embed.reshape(1, -1).to(self.device), k)
             I = I.cpu().numpy()
         else:
-            _, I = self.index.search(np.asarray(q_embed).reshape(1, -1), k)
+            with torch.cuda.device(self.device):
+                _, I = self.index.search(np.asarray(q_embed).reshape(1, -1), k)
         para_embed_idx = I.reshape(-1)
         para_embed_idx = para_embed_idx[para_embed_idx >= 0]         # fewer than k rows in the index
         para_idx = None

@@ -1,0 +1,4 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02p; mkdir -p $O
+timeout 2400 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt

@@ -59,8 +59,10 @@ int main(int argc, char** argv) {
   const std::string c = dir + "/asan_c.npy";
   CHECK(proqa_npy_create(c.c_str(), 5, 128, PROQA_F32) == 0);
   std::vector<float> f(2 * 128, 1.5f);
-  CHECK(proqa_npy_write_rows(c.c_str(), 3, 2, f.data()) == 0);
-  CHECK(proqa_npy_write_rows(c.c_str(), 4, 2, f.data()) == PROQA_EINVAL);
+  CHECK(proqa_npy_write_rows(c.c_str(), 3, 2, f.data(), 128, PROQA_F32) == 0);
+  CHECK(proqa_npy_write_rows(c.c_str(), 4, 2, f.data(), 128, PROQA_F32) == PROQA_EINVAL);   // past the end
+  CHECK(proqa_npy_write_rows(c.c_str(), 0, 2, f.data(), 128, PROQA_F16) == PROQA_EINVAL);   // other dtype than the file
+  CHECK(proqa_npy_write_rows(c.c_str(), 0, 2, f.data(), 64, PROQA_F32) == PROQA_EINVAL);    // other width
   std::vector<float> g(5 * 128);
   CHECK(proqa_npy_read_rows(c.c_str(), 0, 5, g.data(), g.size() * 4) == 0);
   CHECK(g[0] == 0.f && g[3 * 128] == 1.5f && g[5 * 128 - 1] == 1.5f);

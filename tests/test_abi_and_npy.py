@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in proqa_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.proqa_abi_version() == 1
+    assert lib.proqa_abi_version() == 2
 
 
 def test_error_reporting_without_compute():
@@ -99,6 +99,11 @@ def test_npy_create_and_write_rows(tmp_path):
     np.testing.assert_array_equal(np.load(path), a)
     with pytest.raises(_lib.ProqaError):
         npy.write_rows(path, 8, a[:5])
+    # rows of another dtype or width must not be written into the file (they would corrupt it silently)
+    with pytest.raises(_lib.ProqaError):
+        npy.write_rows(path, 0, a[:2].astype(np.float32 if a.dtype == np.float16 else np.float16))
+    with pytest.raises(_lib.ProqaError):
+        npy.write_rows(path, 0, a[:2, :-1])
 
 
 def test_npy_rejects_bad_files(tmp_path):

@@ -103,6 +103,26 @@ def test_clusering_matches_oracle_trajectory(gpu_device):
     assert (I == Io).mean() > 0.999
 
 
+def test_clusering_never_rounds_float32_silently(gpu_device):
+    """The reference clusters np.float32(x) (group_paras.py:72-73).  float32 embeddings whose values are fp16
+    numbers (what '<f2' files upcast to) cluster exactly like the fp16 array; values fp16 cannot hold are refused
+    unless the caller accepts the rounding."""
+    from proqa_amd.group_paras import clusering
+    rng = np.random.default_rng(9)
+    x16, _ = blobs(rng, 2000, 8, spread=0.05)
+    x16 = x16.astype(np.float16)
+    D16, I16 = clusering(x16, niter=4, verbose=False, ncentroids=8, max_points_per_centroid=1000)
+    D32, I32 = clusering(x16.astype(np.float32), niter=4, verbose=False, ncentroids=8, max_points_per_centroid=1000)
+    np.testing.assert_array_equal(I16, I32)
+    np.testing.assert_array_equal(D16, D32)
+    bad = (rng.integers(-2500, 2501, (2000, 128))).astype(np.float32)     # odd integers above 2048 are not fp16 numbers
+    with pytest.raises(ValueError, match="not representable in fp16"):
+        clusering(bad, niter=2, verbose=False, ncentroids=8, max_points_per_centroid=1000)
+    D, I = clusering(bad, niter=2, verbose=False, ncentroids=8, max_points_per_centroid=1000, allow_fp16_rounding=True)
+    Dr, Ir = clusering(bad.astype(np.float16), niter=2, verbose=False, ncentroids=8, max_points_per_centroid=1000)
+    np.testing.assert_array_equal(I, Ir)
+
+
 def test_empty_cluster_split_like_faiss(gpu_device):
     """Update step with void clusters: means + faiss' re-seeding rule (size-weighted pick driven by
     RandomGenerator(1234), +-1/1024 perturbation) must equal the oracle's km_update_centroids."""

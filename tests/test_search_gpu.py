@@ -574,3 +574,32 @@ def test_bootstrap_overflow_repeats_without_it(gpu_device):
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
     assert index.last_stats()["fallback_rounds"] >= 1
+
+
+@pytest.mark.gpu
+def test_overflow_of_a_large_slab_costs_a_bounded_rescan(gpu_device):
+    """One query whose scores rise with the row number overflows its lists in the big late slabs.  The overflow-safe
+    path re-scans such a slab in quarters (recursively) instead of thousands of dense 1920-row launches: the result is
+    exact and the number of extra launches stays small for the queries that are not adversarial."""
+    import time
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(5)
+    n, nq, k = 1_000_000, 40, 80
+    xb = rng.integers(-3, 4, (n, 128)).astype(np.float16)
+    xb[:, 0] = (np.arange(n) // 2000).astype(np.float16)          # 0 .. 499, exact in fp16
+    xq = rng.integers(-3, 4, (nq, 128)).astype(np.float16)
+    xq[:, 0] = 0
+    xq[0] = 0
+    xq[0, 0] = 1                                                  # query 0: score = row // 2000, rising with the row
+    index = IndexFlatIP(128)
+    index.add(xb)
+    index.search(xq, k)
+    t0 = time.perf_counter()
+    D, I = index.search(xq, k)
+    dt = time.perf_counter() - t0
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    st = index.last_stats()
+    assert st["fallback_rounds"] > 0
+    assert st["fallback_rounds"] < 600 and dt < 0.5, (st, dt)
