@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--encode-batch", type=int, default=512)
     p.add_argument("--seq-len", type=int, default=128)
     p.add_argument("--skip-encode", action="store_true")
+    p.add_argument("--corpus-passages", type=int, default=1_000_000,
+                   help="passages of the corpus-scale encode leg (BASELINE.json configs[1]); 0 skips it")
     p.add_argument("--skip-float32", action="store_true", help="skip the exact-float32 index leg")
     p.add_argument("--skip-cpu", action="store_true")
     p.add_argument("--transport", choices=["torch", "cabi"], default=os.environ.get("PROQA_SHARDED_TRANSPORT", "torch"),
@@ -261,7 +263,80 @@ def encode_leg(args, device, world, rank):
                                "kind": "port",
                                "sample": f"{cb} passages x {S} tokens, torch-CPU fp32 restatement of "
                                          f"BertForRetriever.get_embed (oracle/bert_torch_cpu.py), best of 3 passes"}
+    if args.corpus_passages > 0:
+        res["corpus_1m"] = corpus_leg(args, device, world, rank, model, sd)
     return res
+
+
+def corpus_leg(args, device, world, rank, model, sd):
+    """BASELINE.json configs[1] as written: N synthetic 128-token passages, batch 512, fp16 -> .npy index, through
+    the product's own loop -- proqa_amd.get_embed.predict (get_embed.py:142-172: batches to the GPU, get_embed,
+    embeddings kept on the device, torch.cat) and npy.save (get_embed.py:138-139: D2H + file write).  The timed
+    region covers all of it; tokenisation is excluded (pre-tokenised ids, as in the encode leg).  Each rank
+    encodes N/world passages and writes its own file (the reference's sharded get_embed runs do the same)."""
+    import tempfile
+    from proqa_amd import npy
+    from proqa_amd.get_embed import predict
+    B, S = args.encode_batch, args.seq_len
+    n_local = args.corpus_passages // world
+    g = torch.Generator().manual_seed(1234 + rank)
+    pool = []                                       # 8 distinct full batches, cycled: 1M x 128 ids would be 1 GB of host memory
+    for _ in range(8):
+        ids = torch.randint(1000, 30522, (B, S), generator=g, dtype=torch.int64)
+        ids[:, 0], ids[:, -1] = 101, 102
+        pool.append({"input_ids": ids.pin_memory(), "input_mask": torch.ones((B, S), dtype=torch.bool).pin_memory()})
+
+    def loader():
+        done = 0
+        i = 0
+        while done < n_local:
+            m = min(B, n_local - done)              # the ragged last batch (1M = 1953 x 512 + 64)
+            b = pool[i % len(pool)]
+            yield b if m == B else {k: v[:m] for k, v in b.items()}
+            done += m
+            i += 1
+
+    model.half()
+    out_dir = tempfile.mkdtemp(prefix="proqa_bench_")
+    path = os.path.join(out_dir, f"para_embed_{rank}.npy")
+    predict(args, model, ({k: v[:64] for k, v in pool[0].items()} for _ in range(2)), device, is_query_embed=False)  # warm-up
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    embeds = predict(args, model, loader(), device, is_query_embed=False)
+    torch.cuda.synchronize()
+    t_gpu = time.perf_counter() - t0
+    local = embeds.cpu().numpy()
+    t_d2h = time.perf_counter() - t0
+    npy.save(path, local)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    out = {"metric": "passages/sec encoded, corpus run", "value": n_local * world / dt, "unit": "passages/s",
+           "passages": n_local * world, "batch": B, "seq_len": S, "seconds": dt,
+           "seconds_encode_loop": t_gpu, "seconds_d2h": t_d2h - t_gpu, "seconds_npy_write": dt - t_d2h if world == 1 else None,
+           "bytes_written_per_rank": os.path.getsize(path), "dtype": str(local.dtype),
+           "workload": f"{n_local * world} pre-tokenised {S}-token passages, batch {B}, get_embed.predict -> torch.cat -> "
+                       f"D2H -> npy.save, all inside the timed region (BASELINE.json configs[1])"}
+    if rank == 0 and not args.skip_cpu:
+        from oracle import bert_oracle
+        rows = [0, 1, n_local // 2, n_local - 1]     # first batch, a middle batch, the ragged last batch
+        sd_np = {k: v.numpy() for k, v in sd.items()}
+        back = npy.load(path)
+        err = 0.0
+        for r in rows:
+            b = pool[(r // B) % len(pool)]
+            ids_np = b["input_ids"][r % B:r % B + 1].numpy()
+            ref = bert_oracle.get_embed(sd_np, ids_np, np.ones_like(ids_np, dtype=bool), False, 12, 12)
+            err = max(err, float(np.abs(back[r].astype(np.float32) - ref[0]).max()))
+        out["parity_max_abs_err_vs_oracle"] = err
+        out["parity_rows"] = rows
+    os.remove(path)
+    os.rmdir(out_dir)
+    return out
 
 
 def main():
