@@ -176,6 +176,14 @@ int proqa_encoder_forward(proqa_encoder* enc, const int64_t* ids_dev, const int3
                           int seq_len, int64_t n_valid_tokens, int flags, void* out, int out_dtype, void* stream);
 
 /* The kernels the encoder is made of, individually (tests, other drivers). */
+/* y[m,n] = epilogue(x[m,k] . w[n,k]^T + bias[n]): the encoder's dense layer as a hand-written MFMA GEMM (fp16 in, fp32
+ * accumulate, fp16 out; 256 x 256 x 64 tiles, LDS-DMA ring).  epilogue 0: none (bias ignored), 1: + bias,
+ * 2: erf-GELU(. + bias) = BertIntermediate.  m and n multiples of 256, k a multiple of 64. */
+#define PROQA_GEMM_EPI_NONE 0
+#define PROQA_GEMM_EPI_BIAS 1
+#define PROQA_GEMM_EPI_BIAS_GELU 2
+int proqa_gemm_tn_f16(const void* x_dev, const void* w_dev, const void* bias_dev, void* y_dev, int64_t m, int n, int k,
+                      int epilogue, void* stream);
 /* out[b,s,:] = LayerNorm(word[ids[b,s]] + pos[s] + type[0]) , eps = 1e-12
  * (BertEmbeddings; token_type_ids are never passed by the reference => row 0) */
 int proqa_embed_layernorm_f16(const int64_t* ids_dev, int64_t n_tokens, int seq_len, int hidden,

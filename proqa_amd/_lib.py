@@ -102,6 +102,7 @@ SIGNATURES = {
     "proqa_attention_cls_varlen_f16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "proqa_attention_ex_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p]),
+    "proqa_gemm_tn_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "proqa_bias_gelu_f16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "proqa_bias_residual_layernorm_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                   c_float, c_int64, c_int, c_void_p, c_void_p]),

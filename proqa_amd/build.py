@@ -22,6 +22,7 @@ SOURCES = [
     "mips_kernels.hip",
     "sharded_search.cpp",
     "encoder_kernels.hip",
+    "gemm_kernels.hip",
     "attention_kernel.hip",
     "encoder.cpp",
     "kmeans_kernels.hip",

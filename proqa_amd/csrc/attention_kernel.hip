@@ -344,6 +344,8 @@ int launch_attention_cls(const void* qkv, const void* qkv_bias, const int32_t* s
 
 }  // namespace proqa
 
+using namespace proqa;
+
 extern "C" int proqa_attention_f16(const void* qkv, const int32_t* seq_lens_dev, int batch, int seq_len,
                                    int n_heads, void* ctx_out, void* stream) {
   return launch_attention(qkv, nullptr, seq_lens_dev, nullptr, batch, seq_len, n_heads, ctx_out, stream);

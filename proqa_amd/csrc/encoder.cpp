@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <map>
 #include <new>
+#include <string>
 #include <tuple>
 #include <vector>
 
@@ -43,6 +44,7 @@ struct proqa_encoder {
   Workspace ws;
   int device = 0;
   // opt-in GEMM solution tuning (proqa_encoder_set_gemm_tuning): shape -> rocBLAS solution index (0 = default)
+  bool own_ffn1 = true;   // BertIntermediate on the hand-written GEMM with the fused bias + GELU epilogue (PROQA_FFN1=lib: library GEMM + bias_gelu)
   bool tune = false;
   std::map<std::tuple<int64_t, int, int>, int> solution;
 };
@@ -213,6 +215,7 @@ int proqa_encoder_create(const proqa_bert_weights* w, proqa_encoder** out) {
   e->layers.assign(w->layers, w->layers + w->n_layers);
   e->w.layers = e->layers.data();
   PROQA_HIP(hipGetDevice(&e->device));
+  if (const char* v = getenv("PROQA_FFN1")) e->own_ffn1 = std::string(v) != "lib";   // developer A/B switch
   rocblas_status s = rocblas_create_handle(&e->blas);
   if (s != rocblas_status_success) {
     delete e;
@@ -282,6 +285,8 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
   // hold finite stale values nothing reads back; small batches stay small)
   const int64_t rows = n > 8 * kRowTile ? round_up<int64_t>(n, kRowTile) : n;
   const int32_t* lens = packed ? nullptr : seq_lens_dev;
+  // the fused dense+GELU kernel wants whole 256-row tiles and enough of them to occupy every XCD
+  const bool own_ffn1 = e->own_ffn1 && rows % 256 == 0 && rows >= 64 * 256 && I % 256 == 0 && H % 64 == 0;
   _Float16 *h = ws.h, *h1 = ws.h1;
   const int n_full = cls_only ? w.n_layers - 1 : w.n_layers;
   for (int l = 0; l < n_full; ++l) {
@@ -290,8 +295,14 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
     if (int rc = launch_attention(ws.qkv, L.qkv_b, lens, cu, batch, seq_len, NH, ws.ctx, stream)) return rc;
     if (int rc = gemm_tn(e, ws.ctx, L.ao_w, ws.tmp, rows, H, H, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.tmp, L.ao_b, h, L.ln1_g, L.ln1_b, eps, rows, H, h1, stream)) return rc;
-    if (int rc = gemm_tn(e, h1, L.ff1_w, ws.ff, rows, I, H, st)) return rc;
-    if (int rc = proqa_bias_gelu_f16(ws.ff, L.ff1_b, rows, I, stream)) return rc;
+    if (own_ffn1) {
+      // BertIntermediate as ONE launch: the hand-written GEMM adds the bias and applies the erf GELU in its epilogue
+      // (gemm_kernels.hip), which saves the 2 x rows x 3072 x 2 B round trip of a separate bias_gelu pass
+      if (int rc = proqa_gemm_tn_f16(h1, L.ff1_w, L.ff1_b, ws.ff, rows, I, H, PROQA_GEMM_EPI_BIAS_GELU, stream)) return rc;
+    } else {
+      if (int rc = gemm_tn(e, h1, L.ff1_w, ws.ff, rows, I, H, st)) return rc;
+      if (int rc = proqa_bias_gelu_f16(ws.ff, L.ff1_b, rows, I, stream)) return rc;
+    }
     if (int rc = gemm_tn(e, ws.ff, L.ff2_w, ws.tmp, rows, H, I, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.tmp, L.ff2_b, h1, L.ln2_g, L.ln2_b, eps, rows, H, h, stream)) return rc;
   }

@@ -422,3 +422,51 @@ def test_row_without_valid_tokens_does_not_disturb_the_batch(gpu_device):
         assert np.isfinite(out).all()
         keep = [i for i in range(len(out)) if i != 5]
         assert np.abs(out[keep] - ref[keep]).max() < 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (768, 512, 768), (2048, 3072, 768), (1024, 768, 3072)])
+def test_hand_written_dense_layer_matches_fp32_reference(gpu_device, M, N, K):
+    """proqa_gemm_tn_f16 (256x256x64 MFMA tiles, LDS-DMA ring, fused epilogues) against a plain fp32 product of the same
+    fp16 operands: every epilogue, a feature count that is not one tile, a K that is many steps.  Tolerance = fp16
+    rounding of the result (2^-11 relative) plus the fp32 accumulation order."""
+    import ctypes
+    from proqa_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device=gpu_device).manual_seed(M + N + K)
+    x = torch.randn((M, K), generator=g, device=gpu_device).half()
+    w = (torch.randn((N, K), generator=g, device=gpu_device) * 0.05).half()
+    b = torch.randn(N, generator=g, device=gpu_device).half()
+    ref = x.float() @ w.float().t()
+    for epi in (0, 1, 2):
+        want = ref if epi == 0 else ref + b.float()
+        if epi == 2:
+            want = torch.nn.functional.gelu(want)          # erf form, like hidden_act = 'gelu'
+        y = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu_device)
+        _lib.check(lib.proqa_gemm_tn_f16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M, N, K, epi,
+                                         _lib.current_stream_ptr()))
+        torch.cuda.synchronize()
+        err = (y.float() - want).abs()
+        tol = 2.0 ** -10 * want.abs() + 2e-3
+        assert bool((err <= tol).all()), (epi, float(err.max()))
+    # shapes the tiling cannot take are refused, not mis-computed
+    with pytest.raises(_lib.ProqaError):
+        _lib.check(lib.proqa_gemm_tn_f16(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), M - 1, N, K, 0,
+                                         _lib.current_stream_ptr()))
+
+
+def test_fused_ffn1_path_equals_library_path(gpu_device, monkeypatch):
+    """The encoder with BertIntermediate on the hand-written GEMM (default for >= 64 row tiles) and on the library GEMM +
+    bias_gelu (PROQA_FFN1=lib) agree to fp16 round-off on a bert-base-width layer stack."""
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
+    cfg = dict(BERT_BASE, num_hidden_layers=2)
+    sd = random_state_dict(cfg, seed=3)
+    B, S = 160, 128                                         # 20480 token rows = 80 tiles: the fused path is taken
+    ids = torch.randint(1000, 30000, (B, S), device=gpu_device)
+    mask = torch.ones((B, S), dtype=torch.bool, device=gpu_device)
+    outs = []
+    for mode in ("own", "lib"):
+        monkeypatch.setenv("PROQA_FFN1", mode)
+        model = BertForRetriever(cfg, device=gpu_device)
+        model.load_state_dict(sd)
+        outs.append(model.get_embed({"input_ids": ids, "input_mask": mask}, False)["embed"].float())
+    assert float((outs[0] - outs[1]).abs().max()) < 5e-3
