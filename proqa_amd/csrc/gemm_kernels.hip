@@ -82,7 +82,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 template <int EPI>
 __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                           const _Float16* __restrict__ bias, _Float16* __restrict__ Y,
-                                                          int M, int N, int K, int dbg) {
+                                                          int M, int N, int K) {
   // [buffer][operand]: operand 0 = weight tile (A), 1 = token tile (B); the only LDS object of the kernel
   // ... plus 4 KiB per wave of epilogue staging (160 KiB in all)
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * kOpBytes + kWaves * 4096];
@@ -168,15 +168,12 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
     const int nt = grp * kGroup + (int)(r % g);
     m0 = slab * kTile;
     n0 = nt * kTile;
-    wbase = (const char*)W + (long long)((dbg & 1) ? 0 : n0) * K * 2;   // dbg 1: every tile streams the same operands (L2-hot)
-    xbase = (const char*)X + (long long)((dbg & 1) ? 0 : m0) * K * 2;
+    wbase = (const char*)W + (long long)n0 * K * 2;
+    xbase = (const char*)X + (long long)m0 * K * 2;
   };
 
   long long t = slot;
   if (t >= my_tiles) return;
-  if ((dbg & 8) && (slot & 1)) {            // experiment: half of the workgroups start half a tile late
-    for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
-  }
   const char *wbase, *xbase;
   int m0, n0;
   tile_bases(t, wbase, xbase, m0, n0);
@@ -201,7 +198,6 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
       if (step + 1 < n_steps) issue_step(wbase, xbase, step + 1, buf ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       auto mfmas = [&](f16x8 (&fa)[4], f16x8 (&fb)[2]) {
-        if (dbg & 4) return;   // experiment: data movement only
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -241,7 +237,6 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
     // Stored straight from the registers a wave-instruction would write 64 scattered 16-byte pieces (32 rows x 2);
     // instead every 32-row x 64-feature sub-block (4 KiB of fp16) goes through a wave-private LDS buffer and leaves as
     // whole 128-byte row segments: 8 lanes per row, 8 rows per store instruction.
-    if ((dbg & 2) && acc[0][0][0] != 12345.678f) continue;   // experiment: no stores
     char* stage = lds + 2 * 2 * kOpBytes + wave * 4096;
     const int wr_sw = (li >> 1) & 7;                  // swizzle of the row this lane writes (row = li)
     const int rd_row = lane >> 3, rd_q = lane & 7;    // row within an 8-row group / 16-byte piece this lane stores
@@ -307,20 +302,19 @@ int proqa_gemm_tn_f16(const void* x, const void* w, const void* bias, void* y, i
   const long long tiles = (m / kTile) * (long long)(n / kTile);
   const unsigned grid = (unsigned)std::min<long long>(tiles, device_cu_count());
   hipStream_t st = as_stream(stream);
-  static const int dbg = getenv("PROQA_GEMM_DBG") ? atoi(getenv("PROQA_GEMM_DBG")) : 0;   // developer experiments
   const dim3 g(grid), b(kWaves * 64);
   switch (epilogue) {
     case EPI_NONE:
       hipLaunchKernelGGL(gemm_tn_f16<EPI_NONE>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
-                         (_Float16*)y, (int)m, n, k, dbg);
+                         (_Float16*)y, (int)m, n, k);
       break;
     case EPI_BIAS:
       hipLaunchKernelGGL(gemm_tn_f16<EPI_BIAS>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
-                         (_Float16*)y, (int)m, n, k, dbg);
+                         (_Float16*)y, (int)m, n, k);
       break;
     default:
       hipLaunchKernelGGL(gemm_tn_f16<EPI_BIAS_GELU>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w,
-                         (const _Float16*)bias, (_Float16*)y, (int)m, n, k, dbg);
+                         (const _Float16*)bias, (_Float16*)y, (int)m, n, k);
   }
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
