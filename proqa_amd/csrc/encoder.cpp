@@ -22,7 +22,10 @@ using namespace proqa;
 namespace {
 
 constexpr size_t kMaxTunedShapes = 32;
-constexpr int kRowTile = 256;  // token rows handed to the GEMMs are a multiple of the macro-tile (when large)
+// Token rows handed to the GEMMs are a multiple of this (when large).  The library's default kernel for these shapes is
+// a 256 x 256 macro-tile scheme that runs 25-40 % slower on an ODD number of 256-row tiles (scripts/dev_gemm_vs_m.py:
+// N=768 K=3072 at M = 161 x 256: 998 TFLOP/s, at 162 x 256: 1373), so packed (ragged) batches are padded to 512.
+constexpr int kRowTile = 512;
 
 struct Workspace {
   void* base = nullptr;
@@ -283,7 +286,7 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
   }
   // rows handed to the dense layers: the tokens, rounded up to the GEMM tile for large batches (the extra rows
   // hold finite stale values nothing reads back; small batches stay small)
-  const int64_t rows = n > 8 * kRowTile ? round_up<int64_t>(n, kRowTile) : n;
+  const int64_t rows = n > 4096 ? round_up<int64_t>(n, kRowTile) : n;
   const int32_t* lens = packed ? nullptr : seq_lens_dev;
   // the fused dense+GELU kernel wants whole 256-row tiles and enough of them to occupy every XCD
   const bool own_ffn1 = e->own_ffn1 && rows % 256 == 0 && rows >= 64 * 256 && I % 256 == 0 && H % 64 == 0;

@@ -16,7 +16,9 @@ def run(x, w, out):
 for (N, K) in [(3072, 768), (768, 3072), (2304, 768)]:
     w = (torch.randn((N, K), device=dev) * 0.02).half()
     line = []
-    for M in [32768, 36864, 40960, 41216, 41472, 43008, 45056, 49152, 53248, 57344, 61440, 65536]:
+    import sys
+    Ms = [int(a) for a in sys.argv[1:]] or [32768, 36864, 40960, 41216, 41472, 43008, 45056, 49152, 53248, 57344, 61440, 65536]
+    for M in Ms:
         x = torch.randn((M, K), device=dev).half(); out = torch.empty((M, N), device=dev, dtype=torch.float16)
         for _ in range(3): run(x, w, out)
         torch.cuda.synchronize(); t0 = time.perf_counter()
