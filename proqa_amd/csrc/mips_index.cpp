@@ -63,6 +63,7 @@ struct proqa_index {
   unsigned* spill_cnt = nullptr;
   unsigned store_chunks = 0;               // chunks the store is sized for (at ws_nq_pad queries)
   unsigned store_qtiles = 0;
+  unsigned store_lane_cap = 0;             // records per lane list it is sized for
   unsigned* overflow = nullptr;            // [kMaxRounds] device
   unsigned* overflow_host = nullptr;       // pinned mirror
   unsigned long long* stat_dev = nullptr;  // [ws_nq_pad] candidates per query (part of the workspace)
@@ -204,6 +205,7 @@ void free_store(proqa_index* idx) {
   idx->spill_cnt = nullptr;
   idx->store_chunks = 0;
   idx->store_qtiles = 0;
+  idx->store_lane_cap = 0;
 }
 
 void free_workspace(proqa_index* idx) {
@@ -254,13 +256,18 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
 }
 
 // candidate store for launches of up to `chunks` corpus chunks x `n_qtiles` query tiles
-int ensure_store(proqa_index* idx, unsigned chunks, unsigned n_qtiles, int64_t nq_pad) {
-  if (chunks <= idx->store_chunks && n_qtiles == idx->store_qtiles) return PROQA_OK;
+int ensure_store(proqa_index* idx, unsigned chunks, unsigned n_qtiles, int64_t nq_pad, unsigned lane_cap) {
+  if (chunks <= idx->store_chunks && n_qtiles == idx->store_qtiles && lane_cap <= idx->store_lane_cap) return PROQA_OK;
   const unsigned c = std::max(chunks, idx->store_chunks);
+  lane_cap = std::max(lane_cap, idx->store_lane_cap);
   free_store(idx);
   const size_t lists = (size_t)c * nq_pad * 2;
   const size_t slots = (size_t)c * n_qtiles * kFilterWaves;
-  PROQA_HIP(hipMalloc((void**)&idx->lane_log, lists * kLaneCap * sizeof(WaveRecord)));
+  hipError_t e = hipMalloc((void**)&idx->lane_log, lists * lane_cap * sizeof(WaveRecord));
+  if (e != hipSuccess)
+    return fail(PROQA_ENOMEM, "search: candidate store of %zu lists x %u records: %s (fewer queries per call need less)", lists,
+                lane_cap, hipGetErrorString(e));
+  idx->store_lane_cap = lane_cap;
   PROQA_HIP(hipMalloc((void**)&idx->lane_cnt, lists * sizeof(unsigned)));
   PROQA_HIP(hipMalloc((void**)&idx->spill_log, slots * kSpillCap * sizeof(WaveRecord)));
   PROQA_HIP(hipMalloc((void**)&idx->spill_cnt, slots * sizeof(unsigned)));
@@ -281,7 +288,9 @@ const double kBudget = getenv("PROQA_CAND_BUDGET") ? atof(getenv("PROQA_CAND_BUD
 // measured 6-9 % on the whole search at Q <= 256, 3 % slower at Q >= 1024).
 double growth_for(int k, int configured, int qw) {
   const int g = configured > 0 ? configured : (qw == 1 ? 8 : 4);
-  return std::min<double>(g, kBudget / k);
+  // big pages: 60 % of the free keys of the big merge (the rest is headroom for the spread of the candidate count)
+  const double budget = k <= kPageK ? kBudget : 0.6 * (kBigSortKeys - k);
+  return std::min<double>(g, budget / k);
 }
 
 // `start` > 0: rows [0, start) were covered by the bootstrap
@@ -307,12 +316,14 @@ struct LaunchGeom {
   unsigned grid;     // workgroups launched (chunks padded to a multiple of 8, times n_qtiles)
 };
 
-LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage) {
+LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage, int page_k) {
   const int cus = device_cu_count();
+  // big pages put thousands of candidates per query into a round: more chunks = more lane lists to spread them over
+  const long long min_chunks = page_k > kPageK ? kBigMinChunks : 64;
   // one workgroup per CU: target_chunks * n_qtiles ~= #CUs, chunks a multiple of 8 (XCD map); never
   // fewer than 64 chunks, so that a round's ~kCandidateBudget records per query spread over >= 128
   // lane lists (capacity kLaneCap each) however many query tiles there are
-  long long target = std::max<long long>(64, (cus / (long long)n_qtiles) / 8 * 8);
+  long long target = std::max<long long>(min_chunks, (cus / (long long)n_qtiles) / 8 * 8);
   long long rpc = round_up<long long>(ceil_div<long long>(slab_rows, target), kStageRows);
   // dense launches (threshold -inf, or the inclusive overflow-safe re-scan) log EVERY tile: a lane
   // list holds exactly one stage of them (kLaneCap = 8 tiles), so each chunk is one stage
@@ -321,7 +332,7 @@ LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage) {
   return {(int)rpc, (unsigned)chunks, (unsigned)(round_up<long long>(chunks, 8) * n_qtiles)};
 }
 
-CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtiles) {
+CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtiles, unsigned lane_cap) {
   CandidateStore st;
   st.lane_log = idx->lane_log;
   st.lane_cnt = idx->lane_cnt;
@@ -329,14 +340,15 @@ CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtil
   st.spill_cnt = idx->spill_cnt;
   st.nq_pad = nq_pad;
   st.n_qtiles = n_qtiles;
+  st.lane_cap = lane_cap;
   return st;
 }
 
 int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
               bool inclusive, bool dense, bool bounded, unsigned* overflow_word, hipStream_t st, hipEvent_t f0,
               hipEvent_t f1) {
-  const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense);
-  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad)) return rc;
+  const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense, k);
+  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad, lane_capacity(k))) return rc;
   FilterArgs fa;
   fa.xq = idx->xq_pad;
   fa.xb = idx->xb;
@@ -346,7 +358,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   // exact-float32 mode: the fp16 filter tests against thresholds moved by the error margin
   fa.tau = idx->exact ? idx->tau_filter : idx->tau;
   fa.ub = bounded ? (idx->exact ? idx->ub_filter : idx->ub) : nullptr;
-  fa.store = store_of(idx, (unsigned)idx->ws_nq_pad, n_qtiles);
+  fa.store = store_of(idx, (unsigned)idx->ws_nq_pad, n_qtiles, idx->store_lane_cap);
   fa.overflow = overflow_word;
   fa.flags = kFilterFlags;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
@@ -361,6 +373,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.run_n = idx->run_n;
   ma.tau = idx->tau;
   ma.k = k;
+  ma.sort_cap = sort_capacity(k);
   ma.inclusive = inclusive ? 1 : 0;
   ma.bound_keys = bounded ? idx->bound_keys : nullptr;
   ma.stat_candidates = idx->stat_dev;
@@ -394,7 +407,9 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
       page_k <= idx->bootstrap_rows / 4 && idx->n >= 4ll * idx->bootstrap_rows)
     boot = std::min<long long>(idx->bootstrap_rows, kBootstrapMaxRows);
   // every row of the first slab is a candidate (threshold -inf): it must fit one merge pass
-  const int first = std::min<int>(idx->first_slab_rows, (kMaxSortKeys - page_k) / kStageRows * kStageRows);
+  // (big pages: as many rows as the merge holds -- their growth per round is small, so the rounds should start high)
+  const int first_cap = (sort_capacity(page_k) - page_k) / kStageRows * kStageRows;
+  const int first = page_k > kPageK ? first_cap : std::min<int>(idx->first_slab_rows, first_cap);
   std::vector<Slab> slabs = plan_slabs(idx->n, first, growth_for(page_k, idx->growth, qw), boot);
   if ((int)slabs.size() + 2 > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
   if (boot) {
@@ -451,7 +466,7 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
   // hold fewer rows than one merge pass holds keys and are scanned densely (single-stage chunks): those cannot
   // overflow.  An unlucky batch therefore costs about one more pass over the slab, not thousands of launches;
   // only an adversarial row order reaches the dense leaves.
-  const long long leaf_rows = (long long)((kMaxSortKeys - page_k) / kStageRows) * kStageRows;
+  const long long leaf_rows = (long long)((sort_capacity(page_k) - page_k) / kStageRows) * kStageRows;
   unsigned* word = idx->overflow + kMaxRounds - 1;
   for (size_t r = 0; r < slabs.size(); ++r) {
     if (!idx->overflow_host[r]) continue;
@@ -499,7 +514,7 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
       for (size_t r = 0; r < slabs.size(); ++r) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, idx->ev_filter[2 * r], idx->ev_filter[2 * r + 1]);
-        const LaunchGeom g = geometry(slabs[r].r1 - slabs[r].r0, n_qtiles, slabs[r].r0 < page_k);
+        const LaunchGeom g = geometry(slabs[r].r1 - slabs[r].r0, n_qtiles, slabs[r].r0 < page_k, page_k);
         fprintf(stderr, "round %zu rows [%lld,%lld) grid %u rpc %d filter %.3f ms\n", r, slabs[r].r0, slabs[r].r1,
                 g.grid, g.rows_per_chunk, ms);
       }
@@ -522,16 +537,17 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   const unsigned tile_q = filter_tile_queries(qw);
   const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
   const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
-  if (int rc = ensure_workspace(idx, nq_pad, std::min(k, kPageK))) return rc;
+  const int page_size = k <= kPageK ? kPageK : kBigPageK;
+  if (int rc = ensure_workspace(idx, nq_pad, std::min(k, page_size))) return rc;
 
   PROQA_HIP(hipEventRecord(idx->ev[0], st));
   // k <= kPageK: one page.  Larger k (retrieval/trec_process.py:76 asks for 10000) is served page by
   // page: page p re-runs the search restricted to keys strictly below the last key of page p-1.
   int fallback = 0;
-  const int n_pages = ceil_div<int>(k, kPageK);
+  const int n_pages = ceil_div<int>(k, page_size);
   if (n_pages > 1) PROQA_HIP(hipMemsetAsync(idx->done, 0, (size_t)idx->ws_nq_pad, st));
   for (int p = 0; p < n_pages; ++p) {
-    const int page_k = std::min(kPageK, k - p * kPageK);
+    const int page_k = std::min(page_size, k - p * page_size);
     const bool check_q = p == 0 && dtype == PROQA_F32;
     if (check_q) PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), st));
     PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
@@ -546,7 +562,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
     if (idx->exact)
       PROQA_HIP(launch_query_margins(xq_dev, dtype, nq, idx->ws_nq_pad, idx->norm_stats, idx->xq32, idx->margin,
                                      idx->tau, idx->tau_filter, st));
-    const PageOut out{D_dev, (long long*)I_dev, idx_offset, k, p * kPageK};
+    const PageOut out{D_dev, (long long*)I_dev, idx_offset, k, p * page_size};
     bool boot_overflow = false;
     if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, p > 0, out, st, &fallback, true, &boot_overflow)) return rc;
     if (boot_overflow) {

@@ -17,9 +17,17 @@ constexpr int kMergeThreads = 256;
 // merge_lists sorts up to this many gathered keys per query in LDS (128 KiB); above it the merge
 // runs as a segmented radix sort in HBM
 constexpr int kMaxMergeListKeys = 16384;
-constexpr int kMaxSortKeys = 2048;  // running list + candidates of one query per merge (LDS)
-constexpr int kPageK = kMaxSortKeys / 2;  // results per page; k > kPageK is served page by page
+constexpr int kMaxSortKeys = 2048;  // running list + candidates of one query per merge (LDS), k <= kPageK
+constexpr int kPageK = kMaxSortKeys / 2;  // k up to here is one page at the small merge capacity
+// k > kPageK (retrieval/trec_process.py:76 asks for 10000, qa/online_sampler.py:113 for 5000): pages of kBigPageK
+// results on a merge that holds kBigSortKeys keys (64 KiB of LDS), with deeper lane lists and more corpus chunks
+constexpr int kBigSortKeys = 8192;
+constexpr int kBigPageK = kBigSortKeys / 2;
 constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling
+constexpr int kBigLaneCap = 32;     // the same for big pages (thousands of candidates per query and round)
+constexpr int kBigMinChunks = 256;  // corpus chunks of a big-page launch (>= 512 lane lists per query)
+__host__ __device__ constexpr int sort_capacity(int page_k) { return page_k <= kPageK ? kMaxSortKeys : kBigSortKeys; }
+__host__ __device__ constexpr int lane_capacity(int page_k) { return page_k <= kPageK ? kLaneCap : kBigLaneCap; }
 constexpr int kBootstrapMaxRows = 8192;  // rows the bootstrap can cover (32 keys per thread)
 constexpr int kBootstrapMaxK = 256;       // its bound is the k-th of 256 thread maxima
 constexpr int kSpillCap = 256;      // shared spill records per (chunk, wave)
@@ -49,6 +57,7 @@ struct CandidateStore {
   unsigned* spill_cnt;
   unsigned nq_pad;
   unsigned n_qtiles;
+  unsigned lane_cap;     // records per lane list of this search (kLaneCap or kBigLaneCap)
 };
 
 struct FilterArgs {
@@ -72,6 +81,7 @@ struct MergeArgs {
   unsigned* run_n;               // valid entries per query
   float* tau;
   int k;
+  int sort_cap;                  // kMaxSortKeys or kBigSortKeys: keys one merge holds (selects the kernel instantiation)
   int inclusive;                 // overflow-safe rounds: >= threshold, duplicates removed
   const unsigned long long* bound_keys;  // paged searches: only keys strictly below bound_keys[q] count (or NULL)
   unsigned long long* stat_candidates;  // [nq_pad] candidates merged per query (statistics)

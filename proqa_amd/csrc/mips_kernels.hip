@@ -81,13 +81,13 @@ __device__ __forceinline__ void write_record(WaveRecord* dst, const f32x16& acc,
 // the lane among the spilling lanes).
 __device__ __forceinline__ void log_columns(const f32x16& acc, bool hit, float tau, unsigned q, int rel_row0,
                                             int half, int n_rows, unsigned row_begin32, WaveRecord* lane_list,
-                                            unsigned& lane_n, WaveRecord* spill_log, int& spill_n,
+                                            unsigned& lane_n, unsigned lane_cap, WaveRecord* spill_log, int& spill_n,
                                             unsigned* overflow) {
   asm volatile("" : "+v"(rel_row0));  // keep this arithmetic out of the MFMA loop
   const int rel = rel_row0 + 4 * half;
   bool spill = false;
   if (hit) {
-    if (lane_n < (unsigned)kLaneCap) {
+    if (lane_n < lane_cap) {
       write_record(lane_list + lane_n, acc, q, row_begin32 + (unsigned)rel, n_rows - rel, tau);
       ++lane_n;
     } else {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
     tau[blk] = a.tau[q];
     ub[blk] = BOUNDED ? a.ub[q] : 0.f;
     lane_n[blk] = 0u;
-    lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * kLaneCap;
+    lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
   }
   const unsigned wave_slot = (chunk * a.store.n_qtiles + qt) * kFilterWaves + wave;
   WaveRecord* spill_log = a.store.spill_log + (size_t)wave_slot * kSpillCap;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
       for (int blk = 0; blk < QW; ++blk)
         if (__any(hit[blk]))
           log_columns(pend[blk], hit[blk], tau[blk], q0 + blk * 32 + li, pend_rel0, half, n_rows, row_begin32,
-                      lane_list[blk], lane_n[blk], spill_log, spill_n, a.overflow);
+                      lane_list[blk], lane_n[blk], a.store.lane_cap, spill_log, spill_n, a.overflow);
     }
   };
 
@@ -348,7 +348,7 @@ struct ExactCtx {
 
 __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned q, bool inclusive,
                                                  unsigned long long bound, const ExactCtx& ex,
-                                                 unsigned long long* keys, unsigned* n_keys) {
+                                                 unsigned long long* keys, unsigned* n_keys, unsigned cap) {
   const uint4 h = src[0];
   if (h.x != q) return;  // spill logs mix the wave's queries
   const float tau = __uint_as_float(h.w);
@@ -363,13 +363,13 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
         const unsigned row = h.y + (unsigned)(e + 8 * g);
         if (ex.nom) {  // the fp16 score only nominates the row
           const unsigned pos = atomicAdd(ex.n_nom, 1u);  // LDS
-          if (pos < (unsigned)kMaxSortKeys) ex.nom[pos] = row;
+          if (pos < cap) ex.nom[pos] = row;
           continue;
         }
         const unsigned long long key = pack_key(sc[e], row);
         if (key < bound) {  // paged search: ties with the bound score that were already reported
           const unsigned pos = atomicAdd(n_keys, 1u);  // LDS
-          if (pos < (unsigned)kMaxSortKeys) keys[pos] = key;
+          if (pos < cap) keys[pos] = key;
         }
       }
     }
@@ -378,11 +378,11 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
 
 __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
                                             unsigned long long bound, const ExactCtx& ex, unsigned long long* keys,
-                                            unsigned* n_keys) {
+                                            unsigned* n_keys, unsigned cap) {
   uint4 buf[5];
 #pragma unroll
   for (int g = 0; g < 5; ++g) buf[g] = ((const uint4*)rec)[g];
-  keep_scores_regs(buf, q, inclusive, bound, ex, keys, n_keys);
+  keep_scores_regs(buf, q, inclusive, bound, ex, keys, n_keys, cap);
 }
 
 // Append the lanes' items (pred lanes only) to an LDS array: one LDS atomic per wave, ranks by mbcnt.
@@ -465,15 +465,17 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
 }
 
 // EXACT = exact-float32 mode (own instantiation: its LDS list and registers stay out of the fp16 kernel)
-template <bool EXACT>
-__global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(MergeArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned long long keys[kMaxSortKeys];
+// CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
+template <bool EXACT, int CAP>
+__global__ __launch_bounds__(kMergeThreads, CAP > kMaxSortKeys ? 2 : (EXACT ? 4 : 8)) void topk_merge(MergeArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
   constexpr unsigned kWorkCap = 1024;
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
-  static_assert(kLaneCap <= 16, "work item packing");
+  static_assert(kBigLaneCap <= 64, "work item packing: (list within the pass << 6) | slot");
+  const unsigned lane_cap = a.store.lane_cap;
   const unsigned q = blockIdx.x;
   const int tid = threadIdx.x;
   const CandidateStore& st = a.store;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
   if constexpr (EXACT) {
     // this query's float32 vector and the rows the fp16 scan nominated
     __shared__ __attribute__((aligned(16))) float s_xq32[kDim];
-    __shared__ unsigned s_nom[kMaxSortKeys];
+    __shared__ unsigned s_nom[CAP];
     __shared__ unsigned s_n_nom;
     if (tid < kDim) s_xq32[tid] = a.xq32[(size_t)q * kDim + tid];   // visible after the first barrier below
     if (tid == 0) s_n_nom = 0;
@@ -530,9 +532,9 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
         const unsigned pos = atomicAdd(&s_n_work, cnt[e]);   // LDS
         for (unsigned s = 0; s < cnt[e]; ++s) {
           if (pos + s < kWorkCap)
-            s_work[pos + s] = (unsigned short)((t << 4) | s);
+            s_work[pos + s] = (unsigned short)((t << 6) | s);
           else
-            keep_scores(st.lane_log + li[e] * kLaneCap + s, q, inclusive, bound, ex, keys, &s_n_keys);
+            keep_scores(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
         }
       }
     }
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
         const unsigned n_s = (unsigned)__shfl((int)n_spill, src, 64);
         const size_t slot_s = spill_slot0 + (size_t)((tid & ~63) + src) * spill_stride;
         for (unsigned i = lane; i < n_s; i += 64)
-          keep_scores(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys);
+          keep_scores(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
       }
     }
     __syncthreads();
@@ -556,16 +558,16 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
       const unsigned w1 = w0 + kMergeThreads;
       const bool two = w1 < n_work;
       const unsigned i0 = s_work[w0], i1 = two ? s_work[w1] : i0;
-      const unsigned l0 = base + (i0 >> 4), l1 = base + (i1 >> 4);
-      const uint4* r0 = (const uint4*)(st.lane_log + lane_list_index(st, l0 >> 1, q, (int)(l0 & 1)) * kLaneCap + (i0 & 15u));
-      const uint4* r1 = (const uint4*)(st.lane_log + lane_list_index(st, l1 >> 1, q, (int)(l1 & 1)) * kLaneCap + (i1 & 15u));
+      const unsigned l0 = base + (i0 >> 6), l1 = base + (i1 >> 6);
+      const uint4* r0 = (const uint4*)(st.lane_log + lane_list_index(st, l0 >> 1, q, (int)(l0 & 1)) * lane_cap + (i0 & 63u));
+      const uint4* r1 = (const uint4*)(st.lane_log + lane_list_index(st, l1 >> 1, q, (int)(l1 & 1)) * lane_cap + (i1 & 63u));
       uint4 b0[5], b1[5];
 #pragma unroll
       for (int g = 0; g < 5; ++g) b0[g] = r0[g];
 #pragma unroll
       for (int g = 0; g < 5; ++g) b1[g] = r1[g];
-      keep_scores_regs(b0, q, inclusive, bound, ex, keys, &s_n_keys);
-      if (two) keep_scores_regs(b1, q, inclusive, bound, ex, keys, &s_n_keys);
+      keep_scores_regs(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+      if (two) keep_scores_regs(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
     }
     __syncthreads();
   }
@@ -575,9 +577,9 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
     // 512-byte row; products of two floats are exact in double, the 128 of them are summed in double
     // and rounded ONCE -- the correctly rounded score, independent of summation order (unlike an sgemm).
     unsigned n_nom = *ex.n_nom;
-    if (n_nom > (unsigned)kMaxSortKeys) {  // more nominations than the list holds: overflow-safe path
+    if (n_nom > (unsigned)CAP) {  // more nominations than the list holds: overflow-safe path
       if (tid == 0) *a.overflow = 1u;
-      n_nom = kMaxSortKeys;
+      n_nom = CAP;
     }
     const float tau_exact = a.tau[q];
     const int sub = tid & 7;
@@ -606,7 +608,7 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
           const unsigned long long key = pack_key(score, row);
           if (key < bound) {
             const unsigned pos = atomicAdd(&s_n_keys, 1u);
-            if (pos < (unsigned)kMaxSortKeys) keys[pos] = key;
+            if (pos < (unsigned)CAP) keys[pos] = key;
           }
         }
       }
@@ -617,9 +619,9 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
   const unsigned n_seen = s_n_keys;
   if (n_seen == 0) return;  // nothing passed the threshold this round: list and threshold stand
   unsigned n_cand = n_seen;
-  if (n_cand + nrun > (unsigned)kMaxSortKeys) {  // more survivors than one LDS pass holds
+  if (n_cand + nrun > (unsigned)CAP) {  // more survivors than one LDS pass holds
     if (tid == 0) *a.overflow = 1u;
-    n_cand = kMaxSortKeys - nrun;
+    n_cand = CAP - nrun;
   }
   if ((unsigned)tid < nrun) keys[n_cand + tid] = run_pref;
   for (unsigned i = kMergeThreads + tid; i < nrun; i += kMergeThreads) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
@@ -664,10 +666,18 @@ __global__ __launch_bounds__(kMergeThreads, EXACT ? 4 : 8) void topk_merge(Merge
   } else if (total <= 4u * kMergeThreads) {
     unsigned long long v[4];
     finish(v);
-  } else {
-    static_assert(kMaxSortKeys == 8 * kMergeThreads, "largest sort");
+  } else if (total <= 8u * kMergeThreads) {
     unsigned long long v[8];
     finish(v);
+  } else if constexpr (CAP > 8 * kMergeThreads) {
+    static_assert(CAP == 8 * kMergeThreads || CAP == 32 * kMergeThreads, "largest sort");
+    if (total <= 16u * kMergeThreads) {
+      unsigned long long v[16];
+      finish(v);
+    } else {
+      unsigned long long v[32];
+      finish(v);
+    }
   }
   if (!inclusive) return;
   __syncthreads();
@@ -1176,10 +1186,18 @@ hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsi
 }
 
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
-  if (a.xq32)
-    hipLaunchKernelGGL(topk_merge<true>, dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
-  else
-    hipLaunchKernelGGL(topk_merge<false>, dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+  const bool big = a.sort_cap > kMaxSortKeys;
+  if (a.xq32) {
+    if (big)
+      hipLaunchKernelGGL((topk_merge<true, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((topk_merge<true, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+  } else {
+    if (big)
+      hipLaunchKernelGGL((topk_merge<false, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((topk_merge<false, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+  }
   return hipGetLastError();
 }
 

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02y; mkdir -p $O; rm -f $O/*.txt
+timeout 1500 python -m pytest tests/test_search_gpu.py tests/test_rccl_gpu.py -x -q -m gpu > $O/pytest.txt 2>&1
+python scripts/dev_largek_timing.py 6980 > $O/largek_6980.txt 2>&1
+python scripts/dev_largek_timing.py 1000 > $O/largek_1000.txt 2>&1
+python scripts/dev_single_query.py > $O/single.txt 2>&1
