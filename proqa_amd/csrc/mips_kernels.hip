@@ -450,6 +450,46 @@ __device__ __forceinline__ void sort_keys_desc(unsigned long long (&v)[NK], unsi
   }
 }
 
+// Last phase of a bitonic sort on 256*NK keys that already form a bitonic sequence (first half descending, second half
+// ascending): log2(256 NK) compare-exchange stages instead of a whole sort.  The keys are held STRIPED: v[j] is element
+// j*256 + tid, so the strides >= 256 pair registers of one thread, the strides 128 and 64 cross waves (LDS), the rest
+// are lane shuffles.  Result: element j*256 + tid of the descending sequence.
+template <int NK>
+__device__ __forceinline__ void bitonic_merge_striped_desc(unsigned long long (&v)[NK], unsigned long long* xchg, int tid) {
+#pragma unroll
+  for (int sj = NK / 2; sj >= 1; sj >>= 1) {       // strides sj * 256
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      if ((j & sj) == 0) {
+        const unsigned long long x = v[j], y = v[j + sj];
+        const bool sw = x < y;
+        v[j] = sw ? y : x;
+        v[j + sj] = sw ? x : y;
+      }
+    }
+  }
+  for (unsigned m = kMergeThreads / 2; m > 0; m >>= 1) {   // strides m < 256: partner thread tid ^ m, same register
+    const bool keep_max = ((unsigned)tid & m) == 0;
+    if (m >= 64u) {
+#pragma unroll
+      for (int j = 0; j < NK; ++j) xchg[j * kMergeThreads + tid] = v[j];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        const unsigned long long o = xchg[j * kMergeThreads + (tid ^ m)];
+        v[j] = ((v[j] < o) == keep_max) ? o : v[j];
+      }
+      __syncthreads();
+    } else {
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        const unsigned long long o = __shfl_xor(v[j], (int)m, 64);
+        v[j] = ((v[j] < o) == keep_max) ? o : v[j];
+      }
+    }
+  }
+}
+
 // Sort keys[0, total) (LDS, total <= 256*NK; the tail is padded with 0, which is below every real key) and
 // leave the sorted sequence in registers: v[j] = element tid*NK + j.  keys[] doubles as the exchange buffer.
 template <int NK>
@@ -622,6 +662,49 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kMaxSortKeys ? 2 : (EXACT ? 4 
   if (n_cand + nrun > (unsigned)CAP) {  // more survivors than one LDS pass holds
     if (tid == 0) *a.overflow = 1u;
     n_cand = CAP - nrun;
+  }
+  if constexpr (CAP > kMaxSortKeys) {
+    // Big pages: the running list is already sorted, so only the candidates are sorted (at most CAP/2 of them: a
+    // sort of half the size) and the two sorted runs are combined by ONE bitonic merge phase -- about 40 % of the
+    // compare-exchanges of sorting all CAP keys again every round.
+    constexpr unsigned H = CAP / 2;
+    if (!inclusive && n_cand <= H && nrun <= H) {
+      __syncthreads();
+      unsigned long long vc[CAP / 2 / kMergeThreads];
+      constexpr int NKC = CAP / 2 / kMergeThreads;
+      load_and_sort<NKC>(vc, keys, n_cand, tid);        // vc[j] = candidate of rank tid*NKC + j (descending, 0-padded)
+      __syncthreads();
+      // second half of the bitonic sequence: the candidates in ASCENDING order (rank r at H + H-1-r); first half: the running list
+#pragma unroll
+      for (int j = 0; j < NKC; ++j) keys[2 * H - 1 - ((unsigned)tid * NKC + j)] = vc[j];
+      if ((unsigned)tid < nrun) keys[tid] = run_pref;
+      for (unsigned i = kMergeThreads + tid; i < H; i += kMergeThreads) keys[i] = i < nrun ? a.run_keys[(size_t)q * a.k + i] : 0ull;
+      if ((unsigned)tid >= nrun) keys[tid] = 0ull;
+      __syncthreads();
+      unsigned long long v[CAP / kMergeThreads];
+      constexpr int NK = CAP / kMergeThreads;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) v[j] = keys[j * kMergeThreads + tid];
+      __syncthreads();
+      bitonic_merge_striped_desc<NK>(v, keys, tid);
+      const unsigned total = n_cand + nrun;
+      const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        const unsigned i = (unsigned)j * kMergeThreads + tid;
+        if (i < keep) a.run_keys[(size_t)q * a.k + i] = v[j];
+        if (i + 1 == (unsigned)a.k && keep == (unsigned)a.k) {
+          const float t = float_from_ord((unsigned)(v[j] >> 32));
+          a.tau[q] = t;
+          if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
+        }
+      }
+      if (tid == 0) {
+        a.run_n[q] = keep;
+        a.stat_candidates[q] += n_seen;
+      }
+      return;
+    }
   }
   if ((unsigned)tid < nrun) keys[n_cand + tid] = run_pref;
   for (unsigned i = kMergeThreads + tid; i < nrun; i += kMergeThreads) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
