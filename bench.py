@@ -47,6 +47,9 @@ def parse():
                    help="passages of the corpus-scale encode leg (BASELINE.json configs[1]); 0 skips it")
     p.add_argument("--skip-float32", action="store_true", help="skip the exact-float32 index leg")
     p.add_argument("--skip-cpu", action="store_true")
+    p.add_argument("--skip-extras", action="store_true",
+                   help="skip the shard sweep and the measured-peak micro-benchmarks (profiler passes: keeps the kernel "
+                        "statistics to the searches of the headline workload)")
     p.add_argument("--transport", choices=["torch", "cabi"], default=os.environ.get("PROQA_SHARDED_TRANSPORT", "torch"),
                    help="who runs the all-gather of the sharded search: torch.distributed (RCCL backend) or the "
                         "library's own RCCL communicator (proqa_sharded_search_device)")
@@ -352,7 +355,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or (args.force_collective and "MASTER_ADDR" in os.environ):
-        dist.init_process_group(backend=os.environ.get("PROQA_DIST_BACKEND", "nccl"))   # RCCL
+        backend = os.environ.get("PROQA_DIST_BACKEND", "nccl")                          # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
 
     from proqa_amd.index import IndexFlatIP, ShardedIndexFlatIP, shard_bounds
 
@@ -423,7 +427,7 @@ def main():
                      "frac": small_gbs / PEAK_HBM_GBS, "kernel": "mips_filter_f16<QW=1>",
                      "note": "algorithmic bytes = rows x 256 B per search; ~6.3 TB/s is the measured copy ceiling"}}
 
-    if world == 1:
+    if world == 1 and not args.skip_extras:
         # per-rank work of the strong-scaling runs, timed on this one GPU: the same queries over the first
         # N/G rows (G = 1, 2, 4, 8) -- what a rank of a G-GPU job does before the all-gather
         sweep = []

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r02_final; mkdir -p $O
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+for t in torch cabi; do
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --force-collective --transport $t --steps 10 --skip-encode --skip-float32 --skip-cpu --skip-extras > $O/bench_rccl_1rank_$t.json 2> $O/bench_rccl_1rank_$t.err
+done

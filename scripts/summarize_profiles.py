@@ -17,8 +17,9 @@ root = sys.argv[1]
 def short(name):
     if "mips_filter_f16<1" in name:
         return "mips_filter_f16_qw1"      # the HBM-bound small-batch instantiation (bench.py scan_small_batch)
-    for key in ("mips_filter_f16", "topk_merge", "merge_lists", "prep_queries", "finalize_topk", "attention_fwd", "attention_cls_fwd",
-                "bias_gelu", "bias_residual_layernorm", "embed_layernorm", "pool_project", "Cijk_"):
+    for key in ("mips_filter_f16", "topk_merge", "merge_lists", "bootstrap_scores", "bootstrap_select", "prep_queries",
+                "finalize_topk", "gemm_tn_f16", "attention_fwd", "attention_cls_fwd", "bias_gelu", "bias_residual_layernorm",
+                "embed_layernorm", "pool_project", "cls_dense_mfma", "stream_copy", "stream_read", "mfma_loop", "Cijk_"):
         if key in name:
             return key if key != "Cijk_" else "hipblaslt_gemm(" + name.split("_MT")[1].split("_")[0] + ")" if "_MT" in name else "hipblaslt_gemm"
     return None
@@ -89,7 +90,13 @@ if "GRBM_GUI_ACTIVE" in f:
 if "SQ_VALU_MFMA_BUSY_CYCLES" in f and "SQ_BUSY_CYCLES" in f:
     # SQ_BUSY_CYCLES is summed over 32 shader engines; 1024 SIMDs
     cycles = f["SQ_BUSY_CYCLES"] / 32
-    derived["mfma_pipe_busy_fraction"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)
+    # two denominators: cycles in which a wave is resident somewhere (SQ busy), and all GPU-active cycles of the
+    # launches (GRBM_GUI_ACTIVE / 8 XCDs, from the GRBM pass scaled by launch count) -- the latter counts launch ramps
+    # and tails as idle and is the figure DESIGN.md section 2.3 quotes
+    derived["mfma_pipe_busy_of_sq_busy"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)
+    if "GRBM_GUI_ACTIVE" in f and f.get("launches_pmc_grbm"):
+        scale = f["launches_pmc_grbm"] / max(f.get("launches_pmc_sq", 1), 1)
+        derived["mfma_pipe_busy_of_gpu_active"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] * scale / (1024 * f["GRBM_GUI_ACTIVE"] / 8)
     derived["lds_active_fraction"] = f["SQ_LDS_IDX_ACTIVE"] / (256 * cycles)
     derived["wave_wait_fraction"] = f["SQ_WAIT_ANY"] / f["SQ_WAVE_CYCLES"]
     derived["wave_issue_stall_fraction"] = f["SQ_WAIT_INST_ANY"] / f["SQ_WAVE_CYCLES"]
@@ -122,7 +129,7 @@ for n, d in enc.items():
     o = {}
     if d.get("SQ_BUSY_CYCLES"):
         cycles = d["SQ_BUSY_CYCLES"] / 32
-        o["mfma_pipe_busy_fraction"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)
+        o["mfma_pipe_busy_of_sq_busy"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)
         o["share_of_encoder_gpu_cycles"] = cycles
         tot_busy += d["SQ_VALU_MFMA_BUSY_CYCLES"]
         tot_cycles += cycles
@@ -134,7 +141,7 @@ for o in derived_enc.values():
     if "share_of_encoder_gpu_cycles" in o and tot_cycles:
         o["share_of_encoder_gpu_cycles"] /= tot_cycles
 if tot_cycles:
-    derived_enc["whole_encoder"] = {"mfma_pipe_busy_fraction": tot_busy / (1024 * tot_cycles)}
+    derived_enc["whole_encoder"] = {"mfma_pipe_busy_of_sq_busy": tot_busy / (1024 * tot_cycles)}
 if derived_enc:
     summary["derived_encoder"] = derived_enc
 json.dump(summary, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
