@@ -155,3 +155,10 @@ def test_npy_round_trips_fuzz(tmp_path):
             npy.write_rows(p2, cut, arr[cut:])
             npy.write_rows(p2, 0, arr[:cut])
             assert open(p2, "rb").read() == buf.getvalue()
+
+
+def test_driver_build_entry_point_runs():
+    """__graft_entry__.build() is what the driver calls: it must compile (a no-op when up to date), load and bind
+    the library and import the package."""
+    import __graft_entry__
+    assert os.path.exists(__graft_entry__.build())
