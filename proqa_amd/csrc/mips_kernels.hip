@@ -128,7 +128,7 @@ template <int QW, int NW, bool INCLUSIVE, bool BOUNDED>
 __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   static_assert((QW == 1 || QW == 2) && NW == 8 || QW == 4 && NW == 4, "8 waves x 32/64 queries or 4 waves x 128 queries");
   // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads)
-  __shared__ __attribute__((aligned(16))) char lds[3 * kStageBytes];
+  __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytes];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -212,10 +212,29 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 
   constexpr int kSubs = kStageRows / kSubRows;  // 4 units per stage
   // rotating LDS offsets of stage s, s+1, s+2
-  int off0 = 0, off1 = kStageBytes, off2 = 2 * kStageBytes;
+  // Four stage buffers: stage s is being read, s+1 has landed, s+2 and s+3 are in flight (3 x 32 KiB per CU: what a
+  // single reader needs to keep HBM busy -- bytes in flight / latency).  A barrier that publishes stage s+1 waits
+  // vmcnt(kDmaPerWave) when stage s+2 was issued behind it: loads retire in order, so every older DMA piece is
+  // complete once at most the kDmaPerWave youngest are outstanding (record stores in between only make the wait
+  // longer, never shorter: an incomplete piece of stage s+1 implies all kDmaPerWave pieces of s+2 are outstanding too).
+  auto publish = [&](bool younger_stage_in_flight) {
+    if (younger_stage_in_flight) {
+      // (a raw s_barrier: __syncthreads() lets hipcc drain vmcnt to 0 on account of the LDS-DMA in flight)
+      if constexpr (kDmaPerWave == 4)
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      dma_wait_barrier();
+    }
+  };
+  int off0 = 0, off1 = kStageBytes, off2 = 2 * kStageBytes, off3 = 3 * kStageBytes;
   issue_stage(0, off0);
   if (nstages > 1) issue_stage(1, off1);
-  dma_wait_barrier();  // prologue only: both stages landed
+  if (nstages > 2) issue_stage(2, off2);
+  publish(nstages > 2);  // prologue: stages 0 and 1 landed
 
   if ((a.flags & 1u) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
   if ((a.flags & 2u) && (wave & 1)) __builtin_amdgcn_s_setprio(1);         // experiment: every other wave
@@ -261,12 +280,13 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   wave_live = __any(wave_live);
   if (!wave_live) {
     for (int s = 0; s < nstages; ++s) {
-      dma_wait_barrier();
-      if (s + 2 < nstages) issue_stage(s + 2, off2);
+      publish(s + 2 < nstages);
+      if (s + 3 < nstages) issue_stage(s + 3, off3);
       const int t = off0;
       off0 = off1;
       off1 = off2;
-      off2 = t;
+      off2 = off3;
+      off3 = t;
     }
 #pragma unroll
     for (int blk = 0; blk < QW; ++blk)
@@ -279,8 +299,8 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 #pragma unroll
     for (int u = 0; u < kSubs; ++u) {
       if (u == 2) {
-        dma_wait_barrier();  // explicit vmcnt(0): this wave's pieces of DMA(s+1) have landed
-        if (s + 2 < nstages) issue_stage(s + 2, off2);
+        publish(s + 2 < nstages);  // this wave's pieces of DMA(s+1) have landed; every wave is past stage s-1
+        if (s + 3 < nstages) issue_stage(s + 3, off3);
       }
       // where the next unit's fragments live (next stage's buffer after the last unit)
       const char* nxt = (u + 1 < kSubs) ? lds + off0 + (u + 1) * kSubBytes : lds + off1;
@@ -315,7 +335,8 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
     const int t = off0;
     off0 = off1;
     off1 = off2;
-    off2 = t;
+    off2 = off3;
+    off3 = t;
   }
   test_and_log(true);  // drain the last unit
 
