@@ -6,7 +6,7 @@
 //   mips_filter_f16   Q.P^T on MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) with the score
 //                     matrix never leaving registers.  A workgroup of 8 waves keeps 8*QW*32
 //                     queries as MFMA B fragments in VGPRs for its whole lifetime and streams a
-//                     contiguous chunk of corpus rows through a 3 x 32 KiB LDS ring filled by
+//                     contiguous chunk of corpus rows through a 4 x 32 KiB LDS ring filled by
 //                     LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, XOR-swizzled
 //                     on the SOURCE address so ds_read_b128 is conflict-free).  Each lane owns one
 //                     query column of the 32x32 accumulator, so the top-k test is lane-local: max
@@ -119,11 +119,11 @@ __device__ __forceinline__ void log_columns(const f32x16& acc, bool hit, float t
 //     after the current unit consumed them, k-steps 4-7 after its last MFMA;
 //   * the lane-local max-tree + threshold test of unit g-1 sits in the same basic block as unit
 //     g's MFMAs (ONE wave-wide branch per unit);
-//   * three LDS stage buffers and ONE barrier per stage placed mid-stage: crossing a stage
+//   * four LDS stage buffers and ONE barrier per stage placed mid-stage: crossing a stage
 //     boundary needs no barrier, so the fragment prefetch runs straight across it.
 //     At the barrier of stage s (before its unit 2): every wave is past stage s-1, whose buffer
-//     (s+2)%3 is therefore free for DMA(s+2); and every wave has drained (vmcnt 0) its pieces of
-//     DMA(s+1), issued one full stage earlier, so buffer (s+1)%3 is readable from unit 3 on.
+//     is therefore free for DMA(s+3); and every wave has retired its pieces of DMA(s+1), issued two
+//     stages earlier (counted vmcnt: DMA(s+2) stays in flight), so stage s+1 is readable from unit 3 on.
 template <int QW, int NW, bool INCLUSIVE, bool BOUNDED>
 __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   static_assert((QW == 1 || QW == 2) && NW == 8 || QW == 4 && NW == 4, "8 waves x 32/64 queries or 4 waves x 128 queries");
