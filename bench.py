@@ -425,7 +425,8 @@ def main():
         "queries": nq_small, "filter_ms_per_search": small_s * 1e3,
         "roofline": {"bound": "hbm", "achieved": small_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": small_gbs / PEAK_HBM_GBS, "kernel": "mips_filter_f16<QW=1>",
-                     "note": "algorithmic bytes = rows x 256 B per search; ~6.3 TB/s is the measured copy ceiling"}}
+                     "note": "algorithmic bytes = rows x 256 B per search over the HIP-event time of all filter launches of the search; "
+                             "peak_measured.hbm_read_GBs is what a read-only stream reaches on this box"}}
 
     if world == 1 and not args.skip_extras:
         # per-rank work of the strong-scaling runs, timed on this one GPU: the same queries over the first
