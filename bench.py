@@ -409,6 +409,13 @@ def main():
                      "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / PEAK_HBM_GBS},
     }
 
+    if dist.is_initialized():
+        # where a sharded step goes: the rank-local search alone (max over ranks) vs the whole step with the exchange
+        n_loc = max(5, args.steps // 2)
+        dt_loc = timed(lambda: sharded.local_index.search_device(xq, k, idx_offset=lo), n_loc, 1, world, device)
+        line["sharded_step"] = {"local_search_ms": dt_loc / n_loc * 1e3, "exchange_and_merge_ms": dt / args.steps * 1e3 - dt_loc / n_loc * 1e3,
+                                "rows_per_rank": hi - lo}
+
     # the HBM-bound regime of the same kernel (north_star: "achieved HBM GB/s for the MIPS scan"):
     # 32 queries over the same shard -- intensity 32 flop/B, the corpus stream is the bound
     nq_small = 32
