@@ -287,6 +287,9 @@ class ShardedIndexFlatIP:
             D, I = self._index.search_device(xq, k, idx_offset=self.lo)
         if self.world_size == 1 and not force_collective:
             return D, I
+        if not self.dist.is_initialized():
+            raise RuntimeError('force_collective with transport="torch" needs an initialised torch.distributed process '
+                               'group (transport="cabi" brings its own RCCL communicator)')
         # ONE collective: ids (int64) and scores (float32) travel as one byte buffer per rank;
         # rank-ordered slices of the gathered buffer are exactly the [n_parts, nq, k] layout the merge consumes
         n_i, n_d = I.numel() * 8, D.numel() * 4
