@@ -19,6 +19,15 @@
 
 using namespace proqa;
 
+namespace proqa {
+// encoder_kernels.hip
+int launch_cu_seqlens(const int32_t* seq_lens_dev, int batch, int32_t* cu_out, void* stream);
+int launch_small_dense(const void* x, int rows, const void* w, const void* bias, int n_feat, int k_dim, int act, void* y,
+                       void* stream);
+int launch_gather_rows(const void* src, int64_t src_row_stride_elems, const int32_t* row_index_dev, int64_t fixed_stride_rows,
+                       int n_rows, int cols, void* dst, void* stream);
+}  // namespace proqa
+
 namespace {
 
 constexpr size_t kMaxTunedShapes = 32;
@@ -133,8 +142,15 @@ int tune_shape(proqa_encoder* e, hipStream_t st, const _Float16* x, const void* 
 }
 #pragma clang diagnostic pop
 
+constexpr int kSmallDenseMaxRows = 256;   // up to here the dense layers run on small_dense_mfma (encoder_kernels.hip)
+
+const int kSmallDenseRows = [] { const char* v = getenv("PROQA_SMALL_DENSE"); return v ? atoi(v) : kSmallDenseMaxRows; }();   // developer A/B switch (0: off)
+
+inline bool small_dense_ok(int64_t M, int N, int K) { return M <= kSmallDenseRows && N % 32 == 0 && K % 128 == 0; }
+
 int gemm_tn(proqa_encoder* e, const _Float16* x, const void* w, _Float16* out, int64_t M, int N, int K, hipStream_t st) {
   if (M == 0) return PROQA_OK;
+  if (small_dense_ok(M, N, K)) return launch_small_dense(x, (int)M, w, nullptr, N, K, 0, out, st);
   int solution = 0;
   if (e->tune && M >= 4096) {
     const auto key = std::make_tuple(M, N, K);
@@ -184,13 +200,6 @@ int ensure_workspace(proqa_encoder* e, int batch, int64_t rows, hipStream_t st) 
 }
 
 }  // namespace
-
-namespace proqa {
-// encoder_kernels.hip
-int launch_cu_seqlens(const int32_t* seq_lens_dev, int batch, int32_t* cu_out, void* stream);
-int launch_gather_rows(const void* src, int64_t src_row_stride_elems, const int32_t* row_index_dev, int64_t fixed_stride_rows,
-                       int n_rows, int cols, void* dst, void* stream);
-}  // namespace proqa
 
 extern "C" {
 
@@ -298,7 +307,9 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
     if (int rc = launch_attention(ws.qkv, L.qkv_b, lens, cu, batch, seq_len, NH, ws.ctx, stream)) return rc;
     if (int rc = gemm_tn(e, ws.ctx, L.ao_w, ws.tmp, rows, H, H, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.tmp, L.ao_b, h, L.ln1_g, L.ln1_b, eps, rows, H, h1, stream)) return rc;
-    if (own_ffn1) {
+    if (small_dense_ok(rows, I, H)) {
+      if (int rc = launch_small_dense(h1, (int)rows, L.ff1_w, L.ff1_b, I, H, 1, ws.ff, stream)) return rc;
+    } else if (own_ffn1) {
       // BertIntermediate as ONE launch: the hand-written GEMM adds the bias and applies the erf GELU in its epilogue
       // (gemm_kernels.hip), which saves the 2 x rows x 3072 x 2 B round trip of a separate bias_gelu pass
       if (int rc = proqa_gemm_tn_f16(h1, L.ff1_w, L.ff1_b, ws.ff, rows, I, H, PROQA_GEMM_EPI_BIAS_GELU, stream)) return rc;
@@ -323,8 +334,12 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
     if (int rc = gemm_tn(e, ws.c_ctx, L.ao_w, ws.c_tmp, batch, H, H, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.c_tmp, L.ao_b, ws.c_res, L.ln1_g, L.ln1_b, eps, batch, H, ws.c_h1, stream))
       return rc;
-    if (int rc = gemm_tn(e, ws.c_h1, L.ff1_w, ws.c_ff, batch, I, H, st)) return rc;
-    if (int rc = proqa_bias_gelu_f16(ws.c_ff, L.ff1_b, batch, I, stream)) return rc;
+    if (small_dense_ok(batch, I, H)) {
+      if (int rc = launch_small_dense(ws.c_h1, batch, L.ff1_w, L.ff1_b, I, H, 1, ws.c_ff, stream)) return rc;
+    } else {
+      if (int rc = gemm_tn(e, ws.c_h1, L.ff1_w, ws.c_ff, batch, I, H, st)) return rc;
+      if (int rc = proqa_bias_gelu_f16(ws.c_ff, L.ff1_b, batch, I, stream)) return rc;
+    }
     if (int rc = gemm_tn(e, ws.c_ff, L.ff2_w, ws.c_tmp, batch, H, I, st)) return rc;
     if (int rc = proqa_bias_residual_layernorm_f16(ws.c_tmp, L.ff2_b, ws.c_h1, L.ln2_g, L.ln2_b, eps, batch, H, ws.c_h, stream))
       return rc;

@@ -193,6 +193,53 @@ __global__ __launch_bounds__(256) void cls_dense_mfma(const _Float16* __restrict
   }
 }
 
+// Dense layer for a FEW token rows (a question is <= 30 tokens; up to 256 rows): y[n][m] = act(sum_k w[m][k] x[n][k] + bias[m]).
+// The library GEMM costs ~20 us of host and device time per call on such shapes, whatever the row count (its macro-tiles
+// are mostly padding), and a single-question encode is 48 of them.  Here one workgroup owns a 32-feature x 32-row output
+// tile; its four waves split K in quarters (two accumulator chains each, so consecutive MFMAs do not wait for each other),
+// reduce through LDS and write 8-byte pieces; N/32 workgroups stream the weight once.  ACT: 0 none, 1 erf GELU.
+// bias may be null.  (A variant that issued all of a wave's loads before its first MFMA, with up to 16 waves over K, was
+// not faster: at 16 rows the launch itself is the cost, ~5.6 us per kernel on a dependent chain.)
+__device__ __forceinline__ float gelu_erf_small(float t) { return 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f)); }
+
+template <int ACT>
+__global__ __launch_bounds__(256) void small_dense_mfma(const _Float16* __restrict__ x, int n_rows,
+                                                        const _Float16* __restrict__ w, const _Float16* __restrict__ bias,
+                                                        int n_feat, int k_dim, _Float16* __restrict__ y) {
+  __shared__ float part[4][32][33];   // [wave][feature][row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int n = n0 + li;
+  const int kq = k_dim / 4;           // this wave's K range (k_dim is a multiple of 128)
+  const _Float16* wrow = w + (long long)(m0 + li) * k_dim + wave * kq + half * 8;
+  const _Float16* xrow = x + (long long)(n < n_rows ? n : n_rows - 1) * k_dim + wave * kq + half * 8;
+  f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll 2
+  for (int k = 0; k < kq; k += 32) {
+    const f16x8 a0 = *(const f16x8*)(wrow + k), b0 = *(const f16x8*)(xrow + k);
+    const f16x8 a1 = *(const f16x8*)(wrow + k + 16), b1 = *(const f16x8*)(xrow + k + 16);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc1, 0, 0, 0);
+  }
+  // lane (li, half) holds row n, features (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * half][li] = acc0[r] + acc1[r];
+  __syncthreads();
+  // 256 threads: row = tid / 8, features 4*(tid % 8) .. +3
+  const int row = tid >> 3, f0 = (tid & 7) * 4;
+  if (n0 + row >= n_rows) return;
+  f16x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v = part[0][f0 + e][row] + part[1][f0 + e][row] + part[2][f0 + e][row] + part[3][f0 + e][row];
+    if (bias) v += (float)bias[m0 + f0 + e];
+    if (ACT == 1) v = gelu_erf_small(v);
+    o[e] = (_Float16)v;
+  }
+  *(f16x4*)(y + (long long)(n0 + row) * n_feat + m0 + f0) = o;
+}
+
 }  // namespace
 }  // namespace proqa
 
@@ -236,6 +283,22 @@ __global__ void gather_rows_kernel(const _Float16* __restrict__ src, long long r
 int launch_cu_seqlens(const int32_t* seq_lens_dev, int batch, int32_t* cu_out, void* stream) {
   hipLaunchKernelGGL(cu_seqlens_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const int*)seq_lens_dev, batch,
                      (int*)cu_out);
+  PROQA_LAUNCH_CHECK();
+  return PROQA_OK;
+}
+
+// y[rows, n_feat] = act(x[rows, k] . w[n_feat, k]^T + bias) for a few rows; n_feat % 32 == 0, k % 128 == 0
+int launch_small_dense(const void* x, int rows, const void* w, const void* bias, int n_feat, int k_dim, int act, void* y,
+                       void* stream) {
+  if (rows == 0) return PROQA_OK;
+  if (n_feat % 32 || k_dim % 128 || k_dim <= 0) return fail(PROQA_EINVAL, "small_dense: n_feat=%d k=%d", n_feat, k_dim);
+  const dim3 g((unsigned)(n_feat / 32), (unsigned)((rows + 31) / 32));
+  if (act == 1)
+    hipLaunchKernelGGL(small_dense_mfma<1>, g, dim3(256), 0, as_stream(stream), (const _Float16*)x, rows, (const _Float16*)w,
+                       (const _Float16*)bias, n_feat, k_dim, (_Float16*)y);
+  else
+    hipLaunchKernelGGL(small_dense_mfma<0>, g, dim3(256), 0, as_stream(stream), (const _Float16*)x, rows, (const _Float16*)w,
+                       (const _Float16*)bias, n_feat, k_dim, (_Float16*)y);
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
 }

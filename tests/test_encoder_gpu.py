@@ -330,6 +330,33 @@ def test_bert_base_shape_against_oracle(gpu_device):
         model.get_embed(batch, False, seq_lens_host=[128] * B)
 
 
+@pytest.mark.parametrize("lens", [[9], [30], [5, 17, 30, 12], [20] * 6 + [8], [33, 31, 32, 32]])
+def test_question_sized_batches_against_oracle(gpu_device, lens):
+    """A few short questions (<= 128 token rows): every dense layer runs on small_dense_mfma
+    (encoder_kernels.hip) instead of the library GEMM; bert-base geometry, 2 layers, both towers' flags."""
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE, config_from_dict
+    cfg = config_from_dict(dict(BERT_BASE, num_hidden_layers=2))
+    sd = {k: v.half().float() for k, v in random_state_dict(cfg, seed=9).items()}
+    model = BertForRetriever(cfg, device=gpu_device)
+    model.load_state_dict(sd)
+    rng = np.random.default_rng(len(lens))
+    B, S = len(lens), max(lens)
+    ids = np.zeros((B, S), np.int64)
+    mask = np.zeros((B, S), bool)
+    for b, n in enumerate(lens):
+        ids[b, :n] = rng.integers(1000, 30522, n)
+        mask[b, :n] = True
+    batch = {"input_ids": torch.from_numpy(ids).to(gpu_device), "input_mask": torch.from_numpy(mask).to(gpu_device)}
+    for is_query in (True, False):
+        ref = bert_oracle.get_embed({k: v.numpy() for k, v in sd.items()}, ids, mask, is_query, 2, 12)
+        for cls_only in (True, False):
+            for packed in (True, False):
+                model.cls_only_last_layer, model.pack_tokens = cls_only, packed
+                got = model.get_embed(batch, is_query)["embed"].float().cpu().numpy()
+                assert np.abs(got - ref).max() < 1e-2, (is_query, cls_only, packed)
+                assert cosine(got, ref).min() > 0.9995
+
+
 def test_rejects_bad_inputs(gpu_device):
     from proqa_amd.retriever import BertForRetriever
     z, sd, cfg = load_golden()
