@@ -316,10 +316,11 @@ struct LaunchGeom {
   unsigned grid;     // workgroups launched (chunks padded to a multiple of 8, times n_qtiles)
 };
 
-LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage, int page_k) {
+LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage, int page_k, unsigned want_chunks = 0) {
   const int cus = device_cu_count();
   // big pages put thousands of candidates per query into a round: more chunks = more lane lists to spread them over
-  const long long min_chunks = page_k > kPageK ? kBigMinChunks : 64;
+  // (the one-pass launch of a large k asks for its own count)
+  const long long min_chunks = want_chunks ? want_chunks : (page_k > kPageK ? kBigMinChunks : 64);
   // one workgroup per CU: target_chunks * n_qtiles ~= #CUs, chunks a multiple of 8 (XCD map); never
   // fewer than 64 chunks, so that a round's ~kCandidateBudget records per query spread over >= 128
   // lane lists (capacity kLaneCap each) however many query tiles there are
@@ -344,11 +345,20 @@ CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtil
   return st;
 }
 
+// the one-pass launch of a large k overrides what a round derives from k
+struct RoundShape {
+  unsigned want_chunks = 0;   // corpus chunks to aim at
+  unsigned lane_cap = 0;      // records per lane list
+  int sort_cap = 0;           // keys the merge holds
+};
+
 int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
               bool inclusive, bool dense, bool bounded, unsigned* overflow_word, hipStream_t st, hipEvent_t f0,
-              hipEvent_t f1) {
-  const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense, k);
-  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad, lane_capacity(k))) return rc;
+              hipEvent_t f1, const RoundShape& shape = RoundShape()) {
+  const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense, k, shape.want_chunks);
+  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad,
+                            shape.lane_cap ? shape.lane_cap : lane_capacity(k)))
+    return rc;
   FilterArgs fa;
   fa.xq = idx->xq_pad;
   fa.xb = idx->xb;
@@ -373,7 +383,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.run_n = idx->run_n;
   ma.tau = idx->tau;
   ma.k = k;
-  ma.sort_cap = sort_capacity(k);
+  ma.sort_cap = shape.sort_cap ? shape.sort_cap : sort_capacity(k);
   ma.inclusive = inclusive ? 1 : 0;
   ma.bound_keys = bounded ? idx->bound_keys : nullptr;
   ma.stat_candidates = idx->stat_dev;
@@ -523,6 +533,127 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
   return PROQA_OK;
 }
 
+// ---- large k in one pass -----------------------------------------------------------------------------------------
+// Paging a large k (trec_process.py:76 asks for 10000, online_sampler.py:113 for 5000) costs a whole search per 4096
+// results, each with ~15 rounds whose merges re-sort 8192 keys.  Instead: (1) the ordinary small-k rounds over a SAMPLE
+// of the shard give every query the r-th best score t of n_s rows; the number of rows of the whole shard that beat t
+// is then ~ r N / n_s, with a relative spread of 1/sqrt(r); n_s is chosen so that this is f k with f = 1 / (1 - 5.5 /
+// sqrt(r)) -- fewer than k such rows is a 5.5-sigma event, more than the merge holds a 5-sigma one.  (2) ONE filter launch over all N rows against t, into
+// lane lists spread over enough chunks (~8 records per list), and ONE merge per query that sorts the ~f k survivors.
+// (3) The result is exact iff every query collected >= k rows (all rows above t are then known, the best k of them are
+// the best k of the shard) and nothing overflowed; otherwise -- an ordered corpus the sample misjudges -- the search
+// is repeated page by page.  The sample's slabs are spread over the shard, not taken from its head, for that reason.
+struct OnePassPlan {
+  bool use = false;
+  int r = 0;                // rank whose score in the sample becomes the threshold
+  long long n_sample = 0;   // sample rows
+  int sort_cap = 0;         // keys the final merge holds
+  unsigned want_chunks = 0;
+};
+
+const bool kOnePass = !(getenv("PROQA_ONE_PASS") && atoi(getenv("PROQA_ONE_PASS")) == 0);   // developer A/B switch
+constexpr size_t kOnePassMaxStoreBytes = 48ull << 30;
+
+OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k) {
+  OnePassPlan p;
+  if (!kOnePass || idx->exact || k <= kPageK || idx->n < 65536) return p;
+  // the smallest rank (cheapest sample) whose 5-sigma candidate count still fits the largest merge
+  double expected = 0.0, most = 0.0;
+  const int ranks[3] = {k <= 2560 ? 256 : 512, 512, 1024};
+  for (int r : ranks) {
+    const double sigma = 1.0 / std::sqrt((double)r);
+    const double f = 1.0 / (1.0 - 5.5 * sigma);
+    p.r = r;
+    expected = f * k;
+    most = expected * (1.0 + 5.0 * sigma);
+    if (most <= kOnePassSortKeys) break;
+  }
+  if (most > kOnePassSortKeys) return p;                       // k beyond ~11700: pages
+  p.sort_cap = most <= kBigSortKeys ? kBigSortKeys : kOnePassSortKeys;
+  p.n_sample = round_up<long long>((long long)(p.r * (double)idx->n / expected), kStageRows);
+  if (p.n_sample > idx->n / 4) return p;                       // k is a large part of the shard
+  p.want_chunks = round_up<unsigned>((unsigned)std::ceil(expected / 16.0), 8);   // two lists per chunk, ~8 records each
+  if ((long long)p.want_chunks * kStageRows > idx->n) return p;
+  const size_t store = (size_t)(p.want_chunks + 8) * nq_pad * 2 * kOnePassLaneCap * sizeof(WaveRecord);
+  if (store > kOnePassMaxStoreBytes) return p;                 // thousands of queries x large k: pages need less memory
+  p.use = true;
+  return p;
+}
+
+// returns PROQA_OK with *done = false when the estimate failed (the caller searches page by page)
+int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int k,
+                    const PageOut& out, hipStream_t st, bool* done) {
+  *done = false;
+  const RoundShape shape{pl.want_chunks, (unsigned)kOnePassLaneCap, pl.sort_cap};
+  // the big launch's store first, so that the sample rounds do not allocate a small one that is thrown away
+  {
+    const LaunchGeom g = geometry(idx->n, n_qtiles, false, k, shape.want_chunks);
+    if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad, shape.lane_cap)) return rc;
+  }
+  PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
+  // (1) thresholds from the sample.  Overflow in here is harmless: it loosens the estimate.
+  const int r = pl.r;
+  long long boot = 0;
+  if (idx->bootstrap_rows > 0 && r <= kBootstrapMaxK && r <= idx->bootstrap_rows / 4 && pl.n_sample >= 4ll * idx->bootstrap_rows)
+    boot = std::min<long long>(idx->bootstrap_rows, kBootstrapMaxRows);
+  const int first_cap = (sort_capacity(r) - r) / kStageRows * kStageRows;
+  std::vector<Slab> slabs = plan_slabs(pl.n_sample, std::min<int>(idx->first_slab_rows, first_cap), growth_for(r, idx->growth, qw), boot);
+  if ((int)slabs.size() + 4 > kMaxRounds) return PROQA_OK;
+  if (boot) {
+    const size_t need = (size_t)idx->ws_nq_pad * round_up<long long>(boot, 32);
+    if (need > idx->boot_floats) {
+      PROQA_HIP(hipStreamSynchronize(st));
+      if (idx->boot_scores) PROQA_HIP(hipFree(idx->boot_scores));
+      idx->boot_scores = nullptr;
+      idx->boot_floats = 0;
+      PROQA_HIP(hipMalloc((void**)&idx->boot_scores, need * sizeof(float)));
+      idx->boot_floats = need;
+    }
+    PROQA_HIP(launch_bootstrap(idx->xb, idx->xq_pad, (int)boot, (unsigned)nq_pad, r, idx->boot_scores, idx->run_keys,
+                               idx->run_n, idx->tau, idx->stat_dev, idx->overflow + kMaxRounds - 2, st));
+  }
+  // spread the slabs over [boot, n): slab i keeps its length and starts i/m of the way through
+  {
+    const size_t m = slabs.size();
+    long long prev_end = boot;
+    bool fits = true;
+    std::vector<Slab> spread(m);
+    for (size_t i = 0; i < m; ++i) {
+      const long long len = slabs[i].r1 - slabs[i].r0;
+      long long r0 = boot + (long long)((double)i / (double)m * (double)(idx->n - boot)) / kStageRows * kStageRows;
+      r0 = std::max(r0, prev_end);
+      if (r0 + len > idx->n) fits = false;
+      spread[i] = {r0, r0 + len};
+      prev_end = r0 + len;
+    }
+    if (fits) slabs.swap(spread);
+  }
+  long long seen = boot;
+  for (size_t i = 0; i < slabs.size(); ++i) {
+    // while fewer than r rows have been merged the threshold is still -inf: every row is logged
+    if (int rc = run_round(idx, slabs[i], qw, n_qtiles, (unsigned)nq_pad, r, false, seen < r, false, idx->overflow, st, nullptr,
+                           nullptr))
+      return rc;
+    seen += slabs[i].r1 - slabs[i].r0;
+  }
+  // (2) keep the thresholds, forget the sample's lists; one launch over the shard, one merge
+  PROQA_HIP(hipMemsetAsync(idx->run_n, 0, (size_t)idx->ws_nq_pad * sizeof(unsigned), st));
+  unsigned* word = idx->overflow + 1;   // [1]: the pass overflowed, [2]: a query came back short
+  if (int rc = run_round(idx, Slab{0, idx->n}, qw, n_qtiles, (unsigned)nq_pad, k, false, false, false, word, st, nullptr, nullptr,
+                         shape))
+    return rc;
+  PROQA_HIP(launch_flag_short_lists(idx->run_n, nq, (unsigned)k, word + 1, st));
+  // (3) results, optimistically, before the one host sync
+  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, out.idx_offset, out.D, out.I, out.out_stride, 0, st));
+  PROQA_HIP(hipMemcpyAsync(idx->overflow_host, idx->overflow, kMaxRounds * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipEventRecord(idx->ev[1], st));
+  PROQA_HIP(hipStreamSynchronize(st));
+  idx->stats.rounds += (int)slabs.size() + 1;
+  *done = !idx->overflow_host[1] && !idx->overflow_host[2];
+  return PROQA_OK;
+}
+
 int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
                   float* D_dev, int64_t* I_dev, hipStream_t st) {
   if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
@@ -538,26 +669,52 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
   const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
   const int page_size = k <= kPageK ? kPageK : kBigPageK;
-  if (int rc = ensure_workspace(idx, nq_pad, std::min(k, page_size))) return rc;
+  OnePassPlan one_pass = plan_one_pass(idx, nq_pad, k);
+  if (int rc = ensure_workspace(idx, nq_pad, one_pass.use ? k : std::min(k, page_size))) return rc;
 
   PROQA_HIP(hipEventRecord(idx->ev[0], st));
-  // k <= kPageK: one page.  Larger k (retrieval/trec_process.py:76 asks for 10000) is served page by
-  // page: page p re-runs the search restricted to keys strictly below the last key of page p-1.
   int fallback = 0;
-  const int n_pages = ceil_div<int>(k, page_size);
-  if (n_pages > 1) PROQA_HIP(hipMemsetAsync(idx->done, 0, (size_t)idx->ws_nq_pad, st));
-  for (int p = 0; p < n_pages; ++p) {
-    const int page_k = std::min(page_size, k - p * page_size);
-    const bool check_q = p == 0 && dtype == PROQA_F32;
+  // pad the queries and reset the per-query state for the first (or only) page; float32 queries fp16 cannot hold
+  // switch the index to exact-float32 mode unless rounding is allowed
+  auto prep_first = [&]() -> int {
+    const bool check_q = dtype == PROQA_F32;
     if (check_q) PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), st));
     PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
-                                  p > 0 ? idx->done : nullptr, p == 0, check_q ? idx->inexact : nullptr, st));
+                                  nullptr, true, check_q ? idx->inexact : nullptr, st));
     if (check_q) {
-      // float32 queries fp16 cannot hold: search exactly (float32 copies of the rows) unless rounding is allowed
       unsigned bad = 0;
       if (int rc = read_inexact(idx, "index_search (queries)", st, &bad)) return rc;
       if (bad && !idx->allow_rounding)
         if (int rc = enable_exact(idx, st)) return rc;
+    }
+    return PROQA_OK;
+  };
+  // 1024 < k <= ~11000 on a shard much larger than k: one pass against sampled thresholds (search_one_pass)
+  if (one_pass.use) {
+    if (int rc = prep_first()) return rc;
+    bool done = false;
+    if (!idx->exact)
+      if (int rc = search_one_pass(idx, one_pass, qw, n_qtiles, nq, nq_pad, k, PageOut{D_dev, (long long*)I_dev, idx_offset, k, 0},
+                                   st, &done))
+        return rc;
+    if (done) {
+      for (int64_t i = 0; i < nq; ++i) idx->stats.candidates += (int64_t)idx->stat_host[i];
+      (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
+      return PROQA_OK;
+    }
+    if (!idx->exact) ++fallback;   // the estimate failed: page by page from scratch
+  }
+  // k <= kPageK: one page.  Larger k that did not go (or get) through the one-pass search is served page by
+  // page: page p re-runs the search restricted to keys strictly below the last key of page p-1.
+  const int n_pages = ceil_div<int>(k, page_size);
+  if (n_pages > 1) PROQA_HIP(hipMemsetAsync(idx->done, 0, (size_t)idx->ws_nq_pad, st));
+  for (int p = 0; p < n_pages; ++p) {
+    const int page_k = std::min(page_size, k - p * page_size);
+    if (p == 0) {
+      if (int rc = prep_first()) return rc;
+    } else {
+      PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
+                                    idx->done, false, nullptr, st));
     }
     if (idx->exact)
       PROQA_HIP(launch_query_margins(xq_dev, dtype, nq, idx->ws_nq_pad, idx->norm_stats, idx->xq32, idx->margin,

@@ -23,6 +23,10 @@ constexpr int kPageK = kMaxSortKeys / 2;  // k up to here is one page at the sma
 // results on a merge that holds kBigSortKeys keys (64 KiB of LDS), with deeper lane lists and more corpus chunks
 constexpr int kBigSortKeys = 8192;
 constexpr int kBigPageK = kBigSortKeys / 2;
+// One-pass search of a large k (see search_one_pass in mips_index.cpp): ONE filter launch over the whole shard against
+// thresholds estimated from a sample, and ONE merge per query that holds up to kOnePassSortKeys keys (128 KiB of LDS)
+constexpr int kOnePassSortKeys = 16384;
+constexpr int kOnePassLaneCap = 24;  // records per lane list of that launch (the chunk count aims at ~8 per list)
 constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling
 constexpr int kBigLaneCap = 32;     // the same for big pages (thousands of candidates per query and round)
 constexpr int kBigMinChunks = 256;  // corpus chunks of a big-page launch (>= 512 lane lists per query)
@@ -81,7 +85,7 @@ struct MergeArgs {
   unsigned* run_n;               // valid entries per query
   float* tau;
   int k;
-  int sort_cap;                  // kMaxSortKeys or kBigSortKeys: keys one merge holds (selects the kernel instantiation)
+  int sort_cap;                  // kMaxSortKeys, kBigSortKeys or kOnePassSortKeys: keys one merge holds (selects the kernel instantiation)
   int inclusive;                 // overflow-safe rounds: >= threshold, duplicates removed
   const unsigned long long* bound_keys;  // paged searches: only keys strictly below bound_keys[q] count (or NULL)
   unsigned long long* stat_candidates;  // [nq_pad] candidates merged per query (statistics)
@@ -101,6 +105,8 @@ hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigne
                                unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,
                                float* ub_filter, hipStream_t st);
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st);
+// *flag = 1 if any of the nq lists holds fewer than `want` keys
+hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag, hipStream_t st);
 // exact top-k of rows [0, n_rows) (n_rows <= kBootstrapMaxRows, k <= kBootstrapMaxK) for every query: run_keys / run_n /
 // tau as the geometric rounds would leave them after those rows.  scores: [nq_pad, round_up(n_rows, 32)] floats
 hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,

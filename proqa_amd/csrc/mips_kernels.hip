@@ -528,11 +528,12 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
 // EXACT = exact-float32 mode (own instantiation: its LDS list and registers stay out of the fp16 kernel)
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
 template <bool EXACT, int CAP>
-__global__ __launch_bounds__(kMergeThreads, CAP > kMaxSortKeys ? 2 : (EXACT ? 4 : 8)) void topk_merge(MergeArgs a) {
+__global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2 : (EXACT ? 4 : 8))) void topk_merge(MergeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
-  constexpr unsigned kWorkCap = 1024;
+  // (the one-pass merge of a large k gathers ~8 records from every list: a queue four times as long)
+  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 4096 : 1024;
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
   static_assert(kBigLaneCap <= 64, "work item packing: (list within the pass << 6) | slot");
@@ -774,12 +775,15 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kMaxSortKeys ? 2 : (EXACT ? 4 
     unsigned long long v[8];
     finish(v);
   } else if constexpr (CAP > 8 * kMergeThreads) {
-    static_assert(CAP == 8 * kMergeThreads || CAP == 32 * kMergeThreads, "largest sort");
+    static_assert(CAP == 8 * kMergeThreads || CAP == 32 * kMergeThreads || CAP == 64 * kMergeThreads, "largest sort");
     if (total <= 16u * kMergeThreads) {
       unsigned long long v[16];
       finish(v);
-    } else {
+    } else if (total <= 32u * kMergeThreads) {
       unsigned long long v[32];
+      finish(v);
+    } else if constexpr (CAP > 32 * kMergeThreads) {
+      unsigned long long v[64];
       finish(v);
     }
   }
@@ -994,6 +998,12 @@ __global__ void finalize_topk(const unsigned long long* run_keys, const unsigned
     D[o] = -3.4028234663852886e38f;  // faiss CMin<float>::neutral()
     I[o] = -1;
   }
+}
+
+// one-pass search of a large k: a query that collected fewer than `want` rows above its estimated threshold
+__global__ void flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq && run_n[q] < want) *flag = 1u;
 }
 
 // after a page of a k > kPageK search: the last reported key bounds the next page; a query whose
@@ -1289,6 +1299,11 @@ hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsi
   return hipGetLastError();
 }
 
+hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag, hipStream_t st) {
+  hipLaunchKernelGGL(flag_short_lists, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, run_n, nq, want, flag);
+  return hipGetLastError();
+}
+
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   const bool big = a.sort_cap > kMaxSortKeys;
   if (a.xq32) {
@@ -1297,7 +1312,9 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
     else
       hipLaunchKernelGGL((topk_merge<true, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   } else {
-    if (big)
+    if (a.sort_cap > kBigSortKeys)
+      hipLaunchKernelGGL((topk_merge<false, kOnePassSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    else if (big)
       hipLaunchKernelGGL((topk_merge<false, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
     else
       hipLaunchKernelGGL((topk_merge<false, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);

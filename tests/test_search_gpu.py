@@ -409,6 +409,46 @@ def test_large_k_random_scores(gpu_device):
     assert agree > 1 - 1e-4
 
 
+@pytest.mark.parametrize("n,nq,k", [(300000, 40, 10000), (300000, 3, 5000), (200000, 300, 1500), (400000, 1, 5000),
+                                    (250000, 70, 3000), (500000, 9, 11000)])
+def test_large_k_one_pass_is_exact(gpu_device, n, nq, k):
+    """1024 < k <= ~11000 on a shard much larger than k goes through ONE filter launch against thresholds estimated
+    from a sample (search_one_pass, mips_index.cpp).  Integer data in [-8, 8]: scores are exact, a score level holds
+    ~100 rows (ties across the k-th place are the rule), and ids must match the oracle bit for bit."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(n + k)
+    xb = _int_corpus(rng, n, lo=-8, hi=8)
+    xq = _int_corpus(rng, nq, lo=-8, hi=8)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    st = index.last_stats()
+    assert st["fallback_rounds"] == 0 and st["rounds"] < 40, st      # the estimate held: no paging
+    assert st["candidates"] / nq < 4 * k
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+
+
+def test_large_k_one_pass_falls_back_on_an_ordered_corpus(gpu_device):
+    """Rows sorted by their score against the first query: whatever the sample sees of them misjudges that query's
+    threshold (too tight: fewer than k rows pass; too loose: the lists overflow).  The search notices and repeats
+    page by page; the result is exact either way."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(77)
+    xb = _int_corpus(rng, 200000, lo=-8, hi=8)
+    xq = _int_corpus(rng, 5, lo=-8, hi=8)
+    order = np.argsort(xb.astype(np.float32) @ xq[0].astype(np.float32), kind="stable")
+    for name, rows in (("ascending", xb[order]), ("descending", xb[order[::-1]])):
+        index = IndexFlatIP(128)
+        index.add(rows)
+        D, I = index.search(xq, 4000)
+        Do, Io = search_oracle.topk_ip(xq, rows, 4000)
+        np.testing.assert_array_equal(I, Io, err_msg=name)
+        np.testing.assert_array_equal(D, Do, err_msg=name)
+    assert index.last_stats()["fallback_rounds"] > 0   # descending: the head of the shard holds every good row
+
+
 def test_randomised_shapes_against_oracle(gpu_device):
     """Seeded sweep over ragged shapes (rows not a multiple of the 128-row stage or the 32-row tile,
     query counts straddling the 256/512 tile sizes, k from 1 to several hundred, repeated searches on
