@@ -423,9 +423,9 @@ __device__ __forceinline__ void wave_append(bool pred, T item, T* arr, unsigned*
 // element tid*NK + j of the sequence.  Strides below NK are compare-exchanges between a thread's own registers,
 // strides below 64*NK are lane shuffles inside a wave; only the two widest strides cross waves and go through
 // LDS (`xchg`, 256*NK keys), i.e. three barrier pairs per sort instead of one barrier per stage.
-template <int NK>
+template <int NK, int T = kMergeThreads>
 __device__ __forceinline__ void sort_keys_desc(unsigned long long (&v)[NK], unsigned long long* xchg, int tid) {
-  constexpr unsigned P = (unsigned)kMergeThreads * NK;
+  constexpr unsigned P = (unsigned)T * NK;
   for (unsigned size = 2; size <= P; size <<= 1) {
     for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
       if (stride >= (unsigned)NK) {
@@ -435,11 +435,11 @@ __device__ __forceinline__ void sort_keys_desc(unsigned long long (&v)[NK], unsi
         const bool keep_max = (((unsigned)tid & m) == 0) == desc;
         if (m >= 64u) {
 #pragma unroll
-          for (int j = 0; j < NK; ++j) xchg[j * kMergeThreads + tid] = v[j];
+          for (int j = 0; j < NK; ++j) xchg[j * T + tid] = v[j];
           __syncthreads();
 #pragma unroll
           for (int j = 0; j < NK; ++j) {
-            const unsigned long long o = xchg[j * kMergeThreads + (tid ^ m)];
+            const unsigned long long o = xchg[j * T + (tid ^ m)];
             v[j] = ((v[j] < o) == keep_max) ? o : v[j];
           }
           __syncthreads();
@@ -475,7 +475,7 @@ __device__ __forceinline__ void sort_keys_desc(unsigned long long (&v)[NK], unsi
 // ascending): log2(256 NK) compare-exchange stages instead of a whole sort.  The keys are held STRIPED: v[j] is element
 // j*256 + tid, so the strides >= 256 pair registers of one thread, the strides 128 and 64 cross waves (LDS), the rest
 // are lane shuffles.  Result: element j*256 + tid of the descending sequence.
-template <int NK>
+template <int NK, int T = kMergeThreads>
 __device__ __forceinline__ void bitonic_merge_striped_desc(unsigned long long (&v)[NK], unsigned long long* xchg, int tid) {
 #pragma unroll
   for (int sj = NK / 2; sj >= 1; sj >>= 1) {       // strides sj * 256
@@ -489,15 +489,15 @@ __device__ __forceinline__ void bitonic_merge_striped_desc(unsigned long long (&
       }
     }
   }
-  for (unsigned m = kMergeThreads / 2; m > 0; m >>= 1) {   // strides m < 256: partner thread tid ^ m, same register
+  for (unsigned m = T / 2; m > 0; m >>= 1) {   // strides m < 256: partner thread tid ^ m, same register
     const bool keep_max = ((unsigned)tid & m) == 0;
     if (m >= 64u) {
 #pragma unroll
-      for (int j = 0; j < NK; ++j) xchg[j * kMergeThreads + tid] = v[j];
+      for (int j = 0; j < NK; ++j) xchg[j * T + tid] = v[j];
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < NK; ++j) {
-        const unsigned long long o = xchg[j * kMergeThreads + (tid ^ m)];
+        const unsigned long long o = xchg[j * T + (tid ^ m)];
         v[j] = ((v[j] < o) == keep_max) ? o : v[j];
       }
       __syncthreads();
@@ -513,30 +513,31 @@ __device__ __forceinline__ void bitonic_merge_striped_desc(unsigned long long (&
 
 // Sort keys[0, total) (LDS, total <= 256*NK; the tail is padded with 0, which is below every real key) and
 // leave the sorted sequence in registers: v[j] = element tid*NK + j.  keys[] doubles as the exchange buffer.
-template <int NK>
+template <int NK, int T = kMergeThreads>
 __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsigned long long* keys, unsigned total,
                                               int tid) {
 #pragma unroll
   for (int j = 0; j < NK; ++j) {
-    const unsigned i = j * kMergeThreads + tid;   // any assignment will do: it is a sort
+    const unsigned i = j * T + tid;   // any assignment will do: it is a sort
     v[j] = i < total ? keys[i] : 0ull;
   }
   __syncthreads();   // keys[] is free for the exchanges from here on
-  sort_keys_desc<NK>(v, keys, tid);
+  sort_keys_desc<NK, T>(v, keys, tid);
 }
 
 // EXACT = exact-float32 mode (own instantiation: its LDS list and registers stay out of the fp16 kernel)
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
-template <bool EXACT, int CAP>
-__global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2 : (EXACT ? 4 : 8))) void topk_merge(MergeArgs a) {
+// T = threads: 256, or 512 for the largest CAP (one workgroup per CU there: the second wave per SIMD hides the latencies)
+template <bool EXACT, int CAP, int T = kMergeThreads>
+__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2 : (EXACT ? 4 : 8))) void topk_merge(MergeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
-  // (the one-pass merge of a large k gathers ~8 records from every list: a queue four times as long)
-  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 4096 : 1024;
+  // (the one-pass merge of a large k gathers ~8 records from each of 1024 lists per pass: a longer queue)
+  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 8192 : 1024;
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
-  static_assert(kBigLaneCap <= 64, "work item packing: (list within the pass << 6) | slot");
+  static_assert(kBigLaneCap <= 64 && 2 * T <= 1024, "work item packing: (list within the pass << 6) | slot, 16 bits");
   const unsigned lane_cap = a.store.lane_cap;
   const unsigned q = blockIdx.x;
   const int tid = threadIdx.x;
@@ -569,17 +570,17 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
 
   if (tid == 0) s_n_keys = 0;
 
-  for (unsigned base = 0; base < n_lists; base += 512) {
+  for (unsigned base = 0; base < n_lists; base += 2 * T) {
     if (tid == 0) s_n_work = 0;
     __syncthreads();
     // list lengths of this query (chunk-major, half-minor; two lists per thread) and the spill counter of
     // one chunk per thread: three independent loads, then one work item per logged record
-    const unsigned n_here = (n_lists - base) < 512u ? (n_lists - base) : 512u;
+    const unsigned n_here = (n_lists - base) < 2u * T ? (n_lists - base) : 2u * T;
     size_t li[2];
     unsigned cnt[2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const unsigned t = (unsigned)tid + e * kMergeThreads;
+      const unsigned t = (unsigned)tid + e * T;
       const unsigned l = base + t;
       li[e] = lane_list_index(st, l >> 1, q, (int)(l & 1));
       cnt[e] = t < n_here ? st.lane_cnt[li[e]] : 0u;
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       if (cnt[e]) {
-        const unsigned t = (unsigned)tid + e * kMergeThreads;
+        const unsigned t = (unsigned)tid + e * T;
         const unsigned pos = atomicAdd(&s_n_work, cnt[e]);   // LDS
         for (unsigned s = 0; s < cnt[e]; ++s) {
           if (pos + s < kWorkCap)
@@ -616,8 +617,8 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
     __syncthreads();
     const unsigned n_work = s_n_work < kWorkCap ? s_n_work : kWorkCap;
     // two records per thread in flight
-    for (unsigned w0 = tid; w0 < n_work; w0 += 2 * kMergeThreads) {
-      const unsigned w1 = w0 + kMergeThreads;
+    for (unsigned w0 = tid; w0 < n_work; w0 += 2 * T) {
+      const unsigned w1 = w0 + T;
       const bool two = w1 < n_work;
       const unsigned i0 = s_work[w0], i1 = two ? s_work[w1] : i0;
       const unsigned l0 = base + (i0 >> 6), l1 = base + (i1 >> 6);
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
     }
     const float tau_exact = a.tau[q];
     const int sub = tid & 7;
-    for (unsigned c = tid >> 3; c < ((n_nom + 31u) & ~31u); c += kMergeThreads / 8) {
+    for (unsigned c = tid >> 3; c < ((n_nom + 31u) & ~31u); c += T / 8) {
       const bool live = c < n_nom;
       const unsigned row = live ? ex.nom[c] : 0u;
       double acc = 0.0;
@@ -692,28 +693,28 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
     constexpr unsigned H = CAP / 2;
     if (!inclusive && n_cand <= H && nrun <= H) {
       __syncthreads();
-      unsigned long long vc[CAP / 2 / kMergeThreads];
-      constexpr int NKC = CAP / 2 / kMergeThreads;
-      load_and_sort<NKC>(vc, keys, n_cand, tid);        // vc[j] = candidate of rank tid*NKC + j (descending, 0-padded)
+      unsigned long long vc[CAP / 2 / T];
+      constexpr int NKC = CAP / 2 / T;
+      load_and_sort<NKC, T>(vc, keys, n_cand, tid);        // vc[j] = candidate of rank tid*NKC + j (descending, 0-padded)
       __syncthreads();
       // second half of the bitonic sequence: the candidates in ASCENDING order (rank r at H + H-1-r); first half: the running list
 #pragma unroll
       for (int j = 0; j < NKC; ++j) keys[2 * H - 1 - ((unsigned)tid * NKC + j)] = vc[j];
       if ((unsigned)tid < nrun) keys[tid] = run_pref;
-      for (unsigned i = kMergeThreads + tid; i < H; i += kMergeThreads) keys[i] = i < nrun ? a.run_keys[(size_t)q * a.k + i] : 0ull;
+      for (unsigned i = T + tid; i < H; i += T) keys[i] = i < nrun ? a.run_keys[(size_t)q * a.k + i] : 0ull;
       if ((unsigned)tid >= nrun) keys[tid] = 0ull;
       __syncthreads();
-      unsigned long long v[CAP / kMergeThreads];
-      constexpr int NK = CAP / kMergeThreads;
+      unsigned long long v[CAP / T];
+      constexpr int NK = CAP / T;
 #pragma unroll
-      for (int j = 0; j < NK; ++j) v[j] = keys[j * kMergeThreads + tid];
+      for (int j = 0; j < NK; ++j) v[j] = keys[j * T + tid];
       __syncthreads();
-      bitonic_merge_striped_desc<NK>(v, keys, tid);
+      bitonic_merge_striped_desc<NK, T>(v, keys, tid);
       const unsigned total = n_cand + nrun;
       const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
 #pragma unroll
       for (int j = 0; j < NK; ++j) {
-        const unsigned i = (unsigned)j * kMergeThreads + tid;
+        const unsigned i = (unsigned)j * T + tid;
         if (i < keep) a.run_keys[(size_t)q * a.k + i] = v[j];
         if (i + 1 == (unsigned)a.k && keep == (unsigned)a.k) {
           const float t = float_from_ord((unsigned)(v[j] >> 32));
@@ -729,7 +730,7 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
     }
   }
   if ((unsigned)tid < nrun) keys[n_cand + tid] = run_pref;
-  for (unsigned i = kMergeThreads + tid; i < nrun; i += kMergeThreads) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
+  for (unsigned i = T + tid; i < nrun; i += T) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
   const unsigned total = n_cand + nrun;
   __syncthreads();
 
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
   // by the overflow-safe path may already be in the running list) drop exact duplicates first
   auto finish = [&](auto& v) {
     constexpr int NK = sizeof(v) / sizeof(v[0]);
-    load_and_sort<NK>(v, keys, total, tid);
+    load_and_sort<NK, T>(v, keys, total, tid);
     if (!inclusive) {
       const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
 #pragma unroll
@@ -762,27 +763,27 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
       }
     }
   };
-  if (total <= 1u * kMergeThreads) {
+  if (total <= 1u * T) {
     unsigned long long v[1];
     finish(v);
-  } else if (total <= 2u * kMergeThreads) {
+  } else if (total <= 2u * T) {
     unsigned long long v[2];
     finish(v);
-  } else if (total <= 4u * kMergeThreads) {
+  } else if (total <= 4u * T) {
     unsigned long long v[4];
     finish(v);
-  } else if (total <= 8u * kMergeThreads) {
+  } else if (total <= 8u * T) {
     unsigned long long v[8];
     finish(v);
-  } else if constexpr (CAP > 8 * kMergeThreads) {
-    static_assert(CAP == 8 * kMergeThreads || CAP == 32 * kMergeThreads || CAP == 64 * kMergeThreads, "largest sort");
-    if (total <= 16u * kMergeThreads) {
+  } else if constexpr (CAP > 8 * T) {
+    static_assert(CAP == 8 * T || CAP == 32 * T || CAP == 64 * T, "largest sort");
+    if (total <= 16u * T) {
       unsigned long long v[16];
       finish(v);
-    } else if (total <= 32u * kMergeThreads) {
+    } else if (total <= 32u * T) {
       unsigned long long v[32];
       finish(v);
-    } else if constexpr (CAP > 32 * kMergeThreads) {
+    } else if constexpr (CAP > 32 * T) {
       unsigned long long v[64];
       finish(v);
     }
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(kMergeThreads, CAP > kBigSortKeys ? 1 : (CAP > kMax
   }
   __syncthreads();
   const unsigned keep = s_n_keys;
-  for (unsigned i = tid; i < keep; i += kMergeThreads) a.run_keys[(size_t)q * a.k + i] = keys[i];
+  for (unsigned i = tid; i < keep; i += T) a.run_keys[(size_t)q * a.k + i] = keys[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1313,7 +1314,7 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
       hipLaunchKernelGGL((topk_merge<true, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   } else {
     if (a.sort_cap > kBigSortKeys)
-      hipLaunchKernelGGL((topk_merge<false, kOnePassSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+      hipLaunchKernelGGL((topk_merge<false, kOnePassSortKeys, kOnePassMergeThreads>), dim3(nq_pad), dim3(kOnePassMergeThreads), 0, st, a);
     else if (big)
       hipLaunchKernelGGL((topk_merge<false, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
     else
