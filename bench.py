@@ -449,6 +449,21 @@ def main():
                           "queries_per_s_projected": nq / (ms_g * 1e-3)})
             ix.close()
         line["shard_sweep"] = {"note": "N=1 timing of the per-rank search of a G-rank job (no collective)", "points": sweep}
+        # the reference's large-k callers on the same index: retrieval/trec_process.py:76 (6980 MS MARCO dev queries,
+        # top-10000 of 8.8M passages) and qa/online_sampler.py:113 (one question, k = 5000)
+        large = {}
+        for name, rows_l, nq_l, k_l in (("trec_top10000", min(n, 8_800_000), 6980, 10000), ("one_question_top5000", n, 1, 5000)):
+            ix = IndexFlatIP(128)
+            ix.adopt_device(xb[:rows_l])
+            xq_l = gen_queries(nq_l, device)
+            dt_l = timed(lambda: ix.search_device(xq_l, k_l), 3, 1, 1, device)
+            st_l = ix.last_stats()
+            large[name] = {"rows": rows_l, "queries": nq_l, "topk": k_l, "ms_per_search": dt_l / 3 * 1e3,
+                           "rounds": st_l["rounds"], "fallback_rounds": st_l["fallback_rounds"]}
+            ix.close()
+            del ix, xq_l
+        torch.cuda.empty_cache()
+        line["large_k"] = large
         line["peak_measured"] = measured_peaks(device)
 
     if rank == 0 and world == 1 and not args.skip_cpu:   # CPU baselines: single-GPU runs only (contract)

@@ -23,11 +23,15 @@ while time.time() < t_end:
         nq = int(rng.choice([1, 3, 31, 32, 33, 200, 256, 257, 600]))
         if n <= 5000 and rng.random() < 0.05:
             nq = 17000                                  # more than one library call per search (QUERY_BATCH)
-    k = int(rng.choice([1, 2, 5, 80, 100, 640, 1024, 1025, 1500, 3000]))
-    kind = rng.choice(["int", "int_narrow", "sorted", "const", "f32_int", "f32_dense_band"])
+    k = int(rng.choice([1, 2, 5, 80, 100, 640, 1024, 1025, 1500, 3000, 5000, 10000, 11500]))
+    kind = rng.choice(["int", "int_wide", "int_wide", "int_narrow", "sorted", "const", "f32_int", "f32_dense_band"])
+    if k > 3000 and nq > 300:
+        nq = int(rng.choice([1, 40, 300]))
     shards = int(rng.choice([1, 1, 2, 3]))
     if kind == "int":
         xb = rng.integers(-4, 5, (n, 128)).astype(np.float16); xq = rng.integers(-4, 5, (nq, 128)).astype(np.float16)
+    elif kind == "int_wide":                        # few rows per score level: the one-pass large-k search holds its estimate
+        xb = rng.integers(-8, 9, (n, 128)).astype(np.float16); xq = rng.integers(-8, 9, (nq, 128)).astype(np.float16)
     elif kind == "int_narrow":                      # massive ties
         xb = rng.integers(0, 2, (n, 128)).astype(np.float16); xq = rng.integers(0, 2, (nq, 128)).astype(np.float16)
     elif kind == "sorted":                          # adversarial order: scores increase with the row index
