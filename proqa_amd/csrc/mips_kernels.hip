@@ -59,6 +59,18 @@ __device__ __forceinline__ unsigned long long pack_key(float score, unsigned row
   return ((unsigned long long)ord_from_float(score) << 32) | (unsigned long long)(0xFFFFFFFFu - row);
 }
 
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+__device__ __forceinline__ float max2_f32(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ size_t lane_list_index(const CandidateStore& st, unsigned chunk, unsigned q, int half) {
   return ((size_t)chunk * st.nq_pad + q) * 2 + half;
 }
@@ -255,9 +267,13 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) pend[blk][r] = pend[blk][r] <= ub[blk] ? pend[blk][r] : -__builtin_inff();
       }
-      float m = pend[blk][0];
+      // v_max3_f32 by hand: fmaxf() makes hipcc quiet possible NaNs of the MFMA results first (two more VALU ops per
+      // block and unit); a NaN score cannot beat a threshold either way
+      float m = max3_f32(pend[blk][0], pend[blk][1], pend[blk][2]);
+      m = max3_f32(m, pend[blk][3], pend[blk][4]);
 #pragma unroll
-      for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, pend[blk][r]);
+      for (int r = 5; r < 15; r += 2) m = max3_f32(m, pend[blk][r], pend[blk][r + 1]);
+      m = max2_f32(m, pend[blk][15]);
       hit[blk] = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
       any_hit = any_hit || hit[blk];
     }
