@@ -554,12 +554,17 @@ struct OnePassPlan {
 const bool kOnePass = !(getenv("PROQA_ONE_PASS") && atoi(getenv("PROQA_ONE_PASS")) == 0);   // developer A/B switch
 constexpr size_t kOnePassMaxStoreBytes = 48ull << 30;
 
-OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k) {
+OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool latency_bound) {
   OnePassPlan p;
-  if (!kOnePass || idx->exact || k <= kPageK || idx->n < 65536) return p;
-  // the smallest rank (cheapest sample) whose 5-sigma candidate count still fits the largest merge
+  // k <= 1024 (down to ~670: below that the rank-256 sample would have to cover more than a quarter of the shard) only
+  // for small batches, where the launches of ~20 rounds cost more than a second look at 17-24 % of the shard (one
+  // question, k = 1000, 18M rows: 1.65 -> 1.12 ms; at 2032 queries the rounds are as fast or faster)
+  if (!kOnePass || idx->exact || k <= 512 || (k <= kPageK && !latency_bound) || idx->n < 65536) return p;
+  // the smallest rank (cheapest sample) whose 5-sigma candidate count still fits the largest merge.  A small batch is
+  // bound by the number of launches, not by the candidates: rank 256 takes the bootstrap and four rounds where rank 512
+  // takes thirteen, for 15 % more candidates
   double expected = 0.0, most = 0.0;
-  const int ranks[3] = {k <= 2560 ? 256 : 512, 512, 1024};
+  const int ranks[3] = {k <= 2560 || latency_bound ? 256 : 512, 512, 1024};
   for (int r : ranks) {
     const double sigma = 1.0 / std::sqrt((double)r);
     const double f = 1.0 / (1.0 - 5.5 * sigma);
@@ -569,7 +574,7 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k) {
     if (most <= kOnePassSortKeys) break;
   }
   if (most > kOnePassSortKeys) return p;                       // k beyond ~11700: pages
-  p.sort_cap = most <= kBigSortKeys ? kBigSortKeys : kOnePassSortKeys;
+  p.sort_cap = most <= kMaxSortKeys ? kMaxSortKeys : (most <= kBigSortKeys ? kBigSortKeys : kOnePassSortKeys);
   p.n_sample = round_up<long long>((long long)(p.r * (double)idx->n / expected), kStageRows);
   if (p.n_sample > idx->n / 4) return p;                       // k is a large part of the shard
   p.want_chunks = round_up<unsigned>((unsigned)std::ceil(expected / 16.0), 8);   // two lists per chunk, ~8 records each
@@ -669,7 +674,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   const unsigned n_qtiles = (unsigned)ceil_div<int64_t>(nq, tile_q);
   const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
   const int page_size = k <= kPageK ? kPageK : kBigPageK;
-  OnePassPlan one_pass = plan_one_pass(idx, nq_pad, k);
+  OnePassPlan one_pass = plan_one_pass(idx, nq_pad, k, qw == 1);
   if (int rc = ensure_workspace(idx, nq_pad, one_pass.use ? k : std::min(k, page_size))) return rc;
 
   PROQA_HIP(hipEventRecord(idx->ev[0], st));
@@ -689,7 +694,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
     }
     return PROQA_OK;
   };
-  // 1024 < k <= ~11000 on a shard much larger than k: one pass against sampled thresholds (search_one_pass)
+  // ~670 <= k <= ~11700 on a shard much larger than k: one pass against sampled thresholds (search_one_pass)
   if (one_pass.use) {
     if (int rc = prep_first()) return rc;
     bool done = false;
