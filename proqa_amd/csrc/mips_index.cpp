@@ -257,9 +257,12 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
 
 // candidate store for launches of up to `chunks` corpus chunks x `n_qtiles` query tiles
 int ensure_store(proqa_index* idx, unsigned chunks, unsigned n_qtiles, int64_t nq_pad, unsigned lane_cap) {
-  if (chunks <= idx->store_chunks && n_qtiles == idx->store_qtiles && lane_cap <= idx->store_lane_cap) return PROQA_OK;
+  // (a launch with fewer query tiles than the store was sized for fits: the spill slots are addressed with the launch's
+  // own tile count, the lane lists with the workspace's padded query count)
+  if (chunks <= idx->store_chunks && n_qtiles <= idx->store_qtiles && lane_cap <= idx->store_lane_cap) return PROQA_OK;
   const unsigned c = std::max(chunks, idx->store_chunks);
   lane_cap = std::max(lane_cap, idx->store_lane_cap);
+  n_qtiles = std::max(n_qtiles, idx->store_qtiles);
   free_store(idx);
   const size_t lists = (size_t)c * nq_pad * 2;
   const size_t slots = (size_t)c * n_qtiles * kFilterWaves;
@@ -549,10 +552,11 @@ struct OnePassPlan {
   long long n_sample = 0;   // sample rows
   int sort_cap = 0;         // keys the final merge holds
   unsigned want_chunks = 0;
+  long long max_queries = 0;   // per launch, within kOnePassMaxStoreBytes of candidate store
 };
 
 const bool kOnePass = !(getenv("PROQA_ONE_PASS") && atoi(getenv("PROQA_ONE_PASS")) == 0);   // developer A/B switch
-constexpr size_t kOnePassMaxStoreBytes = 48ull << 30;
+constexpr size_t kOnePassMaxStoreBytes = 24ull << 30;   // a batch whose store would be larger is searched in groups
 
 OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool latency_bound) {
   OnePassPlan p;
@@ -579,8 +583,12 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool la
   if (p.n_sample > idx->n / 4) return p;                       // k is a large part of the shard
   p.want_chunks = round_up<unsigned>((unsigned)std::ceil(expected / 16.0), 8);   // two lists per chunk, ~8 records each
   if ((long long)p.want_chunks * kStageRows > idx->n) return p;
-  const size_t store = (size_t)(p.want_chunks + 8) * nq_pad * 2 * kOnePassLaneCap * sizeof(WaveRecord);
-  if (store > kOnePassMaxStoreBytes) return p;                 // thousands of queries x large k: pages need less memory
+  // queries one launch can take within the store budget (whole query tiles)
+  const size_t per_query = (size_t)(p.want_chunks + 8) * 2 * kOnePassLaneCap * sizeof(WaveRecord);
+  size_t budget = kOnePassMaxStoreBytes;
+  if (const char* v = getenv("PROQA_ONE_PASS_STORE_MB")) budget = (size_t)atoll(v) << 20;   // tests: force the grouping
+  p.max_queries = (long long)(budget / per_query) / 512 * 512;
+  if (p.max_queries < 512 && nq_pad > p.max_queries) return p;
   p.use = true;
   return p;
 }
@@ -675,6 +683,27 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   const int64_t nq_pad = (int64_t)n_qtiles * tile_q;
   const int page_size = k <= kPageK ? kPageK : kBigPageK;
   OnePassPlan one_pass = plan_one_pass(idx, nq_pad, k, qw == 1);
+  if (one_pass.use && nq_pad > one_pass.max_queries) {
+    // thousands of queries x a large k: in groups whose candidate store stays within budget (each group is a whole
+    // search of its own; the corpus is small next to the scores, re-reading it per group costs nothing)
+    const size_t esize = dtype == PROQA_F16 ? 2 : 4;
+    proqa_search_stats sum = {};
+    const int64_t n_groups = ceil_div<int64_t>(nq, one_pass.max_queries);
+    const int64_t per_group = round_up<int64_t>(ceil_div<int64_t>(nq, n_groups), 512);   // even groups of whole tiles
+    for (int64_t q0 = 0; q0 < nq; q0 += per_group) {
+      const int64_t m = std::min<int64_t>(per_group, nq - q0);
+      if (int rc = search_device(idx, (const char*)xq_dev + (size_t)q0 * kDim * esize, m, dtype, k, idx_offset,
+                                 D_dev + (size_t)q0 * k, I_dev + (size_t)q0 * k, st))
+        return rc;
+      sum.rounds += idx->stats.rounds;
+      sum.fallback_rounds += idx->stats.fallback_rounds;
+      sum.candidates += idx->stats.candidates;
+      sum.filter_ms += idx->stats.filter_ms;
+      sum.total_ms += idx->stats.total_ms;
+    }
+    idx->stats = sum;
+    return PROQA_OK;
+  }
   if (int rc = ensure_workspace(idx, nq_pad, one_pass.use ? k : std::min(k, page_size))) return rc;
 
   PROQA_HIP(hipEventRecord(idx->ev[0], st));

@@ -431,6 +431,24 @@ def test_large_k_one_pass_is_exact(gpu_device, n, nq, k):
     np.testing.assert_array_equal(D, Do)
 
 
+def test_large_k_batches_beyond_the_store_budget_run_in_groups(gpu_device, monkeypatch):
+    """Thousands of queries x a large k would need tens of GB of candidate lists in one launch: the search runs in
+    groups of whole query tiles instead (here: a 1 GB budget, 1300 queries -> groups of 512)."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(5)
+    xb = _int_corpus(rng, 150000, lo=-8, hi=8)
+    xq = _int_corpus(rng, 1300, lo=-8, hi=8)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    monkeypatch.setenv("PROQA_ONE_PASS_STORE_MB", "1024")
+    D, I = index.search(xq, 5000)
+    st = index.last_stats()
+    assert st["fallback_rounds"] == 0 and st["rounds"] >= 3 * 5, st
+    Do, Io = search_oracle.topk_ip(xq, xb, 5000)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+
+
 def test_large_k_one_pass_falls_back_on_an_ordered_corpus(gpu_device):
     """Rows sorted by their score against the first query: whatever the sample sees of them misjudges that query's
     threshold (too tight: fewer than k rows pass; too loose: the lists overflow).  The search notices and repeats
