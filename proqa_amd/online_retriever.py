@@ -7,9 +7,8 @@ paragraph ids through `index2paraid` and gathers `para_embed[I]` (:116-117, :277
 commented-out alternative is the exact `IndexFlatIP` (:80-82).
 
 `OnlineRetriever` is that retrieval step on `proqa_amd.index.IndexFlatIP`: exact instead of
-approximate (a superset in quality of the IVF probe; over 18M rows 1.2 ms per question at k <= 80, 12 ms
-at k = 5000), same
-outputs.  The sampler's span matching / batching is training code and is not rebuilt here.
+approximate (a superset in quality of the IVF probe; over 18M rows 0.87 ms per question at k <= 80, 1.1 ms
+at k = 5000), same outputs.  The sampler's span matching / batching is training code and is not rebuilt here.
 No CPU path.
 """
 import numpy as np
@@ -21,7 +20,9 @@ from .index import IndexFlatIP
 class OnlineRetriever:
     def __init__(self, para_embed, index2paraid=None, device=None):
         """para_embed: [N,128] float16/float32 array (the np.load'ed index, qa/train_retrieve_qa.py:115);
-        index2paraid: the idx_id.json mapping {"<row>": paragraph id} or None."""
+        index2paraid: the idx_id.json mapping {"<row>": paragraph id} (the reference's format), a row-ordered
+        sequence of paragraph ids (ten times cheaper per lookup: at k = 5000 the dict route costs ~3 ms per question,
+        more than the encode and the search together), or None."""
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         para_embed = np.ascontiguousarray(para_embed)
         with torch.cuda.device(self.device):      # proqa_index_create binds the index to the current device
@@ -53,5 +54,11 @@ class OnlineRetriever:
         para_embed_idx = para_embed_idx[para_embed_idx >= 0]         # fewer than k rows in the index
         para_idx = None
         if self.index2paraid is not None:
-            para_idx = [self.index2paraid[str(int(i))] for i in para_embed_idx]
+            # (tolist() first: str() of a Python int is four times cheaper than of a numpy scalar, and at k = 5000 this
+            # loop is otherwise the slowest part of the call)
+            rows = para_embed_idx.tolist()
+            if isinstance(self.index2paraid, dict):
+                para_idx = list(map(self.index2paraid.__getitem__, map(str, rows)))
+            else:
+                para_idx = list(map(self.index2paraid.__getitem__, rows))
         return para_embed_idx, para_idx, self.para_embed[para_embed_idx]

@@ -510,6 +510,8 @@ def test_online_retriever_is_the_exact_search(gpu_device):
         np.testing.assert_array_equal(idx, Io[0])
         assert ids[:3] == [f"doc-{i}" for i in Io[0][:3]] and len(ids) == 5000
         np.testing.assert_array_equal(emb, xb[Io[0]])
+    r_list = OnlineRetriever(xb, [f"doc-{i}" for i in range(len(xb))], device=gpu_device)   # row-ordered ids instead of the dict
+    assert r_list.retrieve(q, 5000)[1] == ids
     idx, ids, emb = r.retrieve(q, 20000)                      # more than the index holds
     assert len(idx) == 9000 and emb.shape == (9000, 128)
 
