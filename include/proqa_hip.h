@@ -101,6 +101,14 @@ int proqa_index_search(proqa_index* idx, const void* xq, int64_t nq, int dtype, 
 int proqa_index_search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k,
                               int64_t idx_offset, float* D_dev, int64_t* I_dev, void* stream);
 
+/* rows of the index by id, device pointers (faiss reconstruct_batch; the gather `para_embed[I]` of
+ * /root/reference/qa/online_sampler.py:117,277 without leaving the GPU): out_dev [n, d] of out_dtype.  PROQA_F16 gives
+ * the stored fp16 rows; PROQA_F32 the float32 copies of an exact-float32 index, else exact upcasts of the fp16 rows --
+ * in both cases the values add() was given, unless rounding was allowed.  ids are idx_offset + local row as reported
+ * by the search; ids outside the index (the -1 of a short result) give zero rows.  Asynchronous on `stream`. */
+int proqa_index_reconstruct_batch_device(proqa_index* idx, const int64_t* ids_dev, int64_t n, int64_t idx_offset,
+                                         void* out_dev, int out_dtype, void* stream);
+
 /* statistics of the last search on this handle (for tests and the benchmark) */
 typedef struct proqa_search_stats {
   int32_t rounds;            /* filter+merge rounds launched */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "proqa_index_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "proqa_index_search_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
                                           c_void_p, c_void_p, c_void_p]),
+    "proqa_index_reconstruct_batch_device": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     "proqa_index_last_stats": (c_int, [c_void_p, ctypes.POINTER(SearchStats)]),
     "proqa_index_set_profiling": (c_int, [c_void_p, c_int]),
     "proqa_index_configure": (c_int, [c_void_p, c_int, c_int]),

@@ -1008,6 +1008,17 @@ int proqa_index_search(proqa_index* idx, const void* xq, int64_t nq, int dtype, 
   return PROQA_OK;
 }
 
+int proqa_index_reconstruct_batch_device(proqa_index* idx, const int64_t* ids_dev, int64_t n, int64_t idx_offset, void* out_dev,
+                                         int out_dtype, void* stream) {
+  if (!idx) return fail(PROQA_EINVAL, "index_reconstruct_batch: idx is NULL");
+  if (n < 0 || (n > 0 && (!ids_dev || !out_dev))) return fail(PROQA_EINVAL, "index_reconstruct_batch: n=%lld or NULL argument", (long long)n);
+  if (out_dtype != PROQA_F16 && out_dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_reconstruct_batch: bad dtype %d", out_dtype);
+  if (int rc = ensure_device(idx)) return rc;
+  PROQA_HIP(launch_gather_index_rows(idx->xb, idx->exact ? idx->xb32 : nullptr, idx->n, (const long long*)ids_dev, n, idx_offset,
+                                     out_dev, out_dtype == PROQA_F32, (hipStream_t)stream));
+  return PROQA_OK;
+}
+
 int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int64_t nq,
                             int k, float* D_dev, int64_t* I_dev, void* stream) {
   if (!D_parts_dev || !I_parts_dev || !D_dev || !I_dev || n_parts <= 0 || nq < 0 || k <= 0)

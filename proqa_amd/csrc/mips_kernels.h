@@ -106,6 +106,10 @@ hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigne
                                unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,
                                float* ub_filter, hipStream_t st);
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st);
+// out[r] = row ids[r] - idx_offset of the index (zero row when outside [0, n_index)); fp16 rows, or float32 (xb32 when the
+// index keeps float32 copies, else upcasts of the fp16 rows)
+hipError_t launch_gather_index_rows(const void* xb16, const float* xb32, long long n_index, const long long* ids, long long n,
+                                    long long idx_offset, void* out, bool out_f32, hipStream_t st);
 // *flag = 1 if any of the nq lists holds fewer than `want` keys
 hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag, hipStream_t st);
 // exact top-k of rows [0, n_rows) (n_rows <= kBootstrapMaxRows, k <= kBootstrapMaxK) for every query: run_keys / run_n /

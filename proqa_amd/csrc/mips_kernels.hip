@@ -1017,6 +1017,36 @@ __global__ void finalize_topk(const unsigned long long* run_keys, const unsigned
   }
 }
 
+// rows of the index by id (faiss reconstruct_batch; qa/online_sampler.py:117 gathers para_embed[I] on the host): one
+// thread per 16 bytes of output.  ids outside [idx_offset, idx_offset + n) -- the -1 of a short result -- give zero rows.
+// out fp16: the stored fp16 rows; out fp32: the float32 copies of an exact-float32 index, else exact upcasts.
+__global__ void gather_index_rows(const _Float16* __restrict__ xb16, const float* __restrict__ xb32, long long n_index,
+                                  const long long* __restrict__ ids, long long n, long long idx_offset, void* out, int out_f32) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = out_f32 ? kDim / 4 : kDim / 8;      // 16-byte pieces per output row
+  if (t >= n * per_row) return;
+  const long long r = t / per_row;
+  const int c = (int)(t - r * per_row);
+  const long long row = ids[r] - idx_offset;
+  const bool live = row >= 0 && row < n_index;
+  if (!out_f32) {
+    f16x8 v = {0};
+    if (live) v = *(const f16x8*)(xb16 + row * kDim + c * 8);
+    *(f16x8*)((_Float16*)out + r * kDim + c * 8) = v;
+  } else {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      if (xb32) {
+        v = *(const f32x4*)(xb32 + row * kDim + c * 4);
+      } else {
+        const _Float16* src = xb16 + row * kDim + c * 4;
+        v = f32x4{(float)src[0], (float)src[1], (float)src[2], (float)src[3]};
+      }
+    }
+    *(f32x4*)((float*)out + r * kDim + c * 4) = v;
+  }
+}
+
 // one-pass search of a large k: a query that collected fewer than `want` rows above its estimated threshold
 __global__ void flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1313,6 +1343,15 @@ hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsi
     PROQA_SELECT_CASE(32);
 #undef PROQA_SELECT_CASE
   static_assert(kBootstrapMaxRows == 32 * kMergeThreads, "largest select");
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_index_rows(const void* xb16, const float* xb32, long long n_index, const long long* ids, long long n,
+                                    long long idx_offset, void* out, bool out_f32, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  const long long pieces = n * (out_f32 ? kDim / 4 : kDim / 8);
+  hipLaunchKernelGGL(gather_index_rows, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const _Float16*)xb16, xb32,
+                     n_index, ids, n, idx_offset, out, out_f32 ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -132,6 +132,22 @@ class IndexFlatIP:
                                                                _lib.current_stream_ptr()))
         return D, I
 
+    def reconstruct_batch_device(self, ids, dtype=None, idx_offset=0):
+        """Rows of the index by id (faiss reconstruct_batch) without leaving the GPU: ids int64 CUDA tensor of any shape
+        (e.g. the I of search_device) -> [*ids.shape, d] tensor of `dtype` (torch.float16, the stored rows, or
+        torch.float32); ids outside the index (-1 of a short result) give zero rows."""
+        import torch
+        if not ids.is_cuda or ids.dtype != torch.int64:
+            raise ValueError("reconstruct_batch_device expects an int64 CUDA tensor")
+        dtype = dtype or torch.float16
+        ids = ids.contiguous()
+        out = torch.empty(tuple(ids.shape) + (self.d,), dtype=dtype, device=ids.device)
+        with torch.cuda.device(ids.device):
+            _lib.check(self._lib.proqa_index_reconstruct_batch_device(self._h, ids.data_ptr(), ids.numel(), int(idx_offset),
+                                                                      out.data_ptr(), _torch_dtype_code(out),
+                                                                      _lib.current_stream_ptr()))
+        return out
+
     # -- introspection / tuning ---------------------------------------------------------
     def last_stats(self):
         st = _lib.SearchStats()

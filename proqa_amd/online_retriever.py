@@ -43,22 +43,28 @@ class OnlineRetriever:
 
     def retrieve(self, q_embed, k=5000):
         """q_embed [1,128] (numpy or CUDA tensor) -> (para_embed_idx int64 [k], para ids or None, para_embeds [k,128]),
-        the three values the sampler derives from `self.index.search(q_embed, k)`."""
+        the three values the sampler derives from `self.index.search(q_embed, k)`.  The rows are gathered from the
+        index's copy in HBM (reconstruct_batch_device; 5000 random 256-byte rows of a multi-GB host array cost ~1 ms)
+        and come back in para_embed's dtype with para_embed's values."""
         if isinstance(q_embed, torch.Tensor):
-            _, I = self.index.search_device(q_embed.reshape(1, -1).to(self.device), k)
-            I = I.cpu().numpy()
+            q = q_embed.reshape(1, -1).to(self.device)
         else:
-            with torch.cuda.device(self.device):
-                _, I = self.index.search(np.asarray(q_embed).reshape(1, -1), k)
-        para_embed_idx = I.reshape(-1)
-        para_embed_idx = para_embed_idx[para_embed_idx >= 0]         # fewer than k rows in the index
+            q = torch.from_numpy(np.ascontiguousarray(np.asarray(q_embed).reshape(1, -1))).to(self.device)
+        _, I = self.index.search_device(q, k)
+        I = I.reshape(-1)
+        want = torch.float16 if self.para_embed.dtype == np.float16 else torch.float32
+        rows = self.index.reconstruct_batch_device(I, want)
+        para_embed_idx = I.cpu().numpy()
+        live = para_embed_idx >= 0                                   # fewer than k rows in the index
+        para_embed_idx = para_embed_idx[live]
+        para_embeds = rows.cpu().numpy()[live].astype(self.para_embed.dtype, copy=False)
         para_idx = None
         if self.index2paraid is not None:
             # (tolist() first: str() of a Python int is four times cheaper than of a numpy scalar, and at k = 5000 this
             # loop is otherwise the slowest part of the call)
-            rows = para_embed_idx.tolist()
+            ids = para_embed_idx.tolist()
             if isinstance(self.index2paraid, dict):
-                para_idx = list(map(self.index2paraid.__getitem__, map(str, rows)))
+                para_idx = list(map(self.index2paraid.__getitem__, map(str, ids)))
             else:
-                para_idx = list(map(self.index2paraid.__getitem__, rows))
-        return para_embed_idx, para_idx, self.para_embed[para_embed_idx]
+                para_idx = list(map(self.index2paraid.__getitem__, ids))
+        return para_embed_idx, para_idx, para_embeds

@@ -495,6 +495,36 @@ def test_randomised_shapes_against_oracle(gpu_device):
         np.testing.assert_array_equal(D, Do)
 
 
+def test_reconstruct_batch_returns_the_rows_that_were_added(gpu_device):
+    """proqa_index_reconstruct_batch_device: rows by id, fp16 and float32, global ids of a shard, -1 -> zero row; an
+    exact-float32 index gives back its float32 values."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(3)
+    xb = rng.standard_normal((3000, 128)).astype(np.float16)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    ids = torch.from_numpy(rng.integers(0, 3000, (7, 45))).to(gpu_device)
+    ids[2, 3] = -1
+    got16 = index.reconstruct_batch_device(ids).cpu().numpy()
+    got32 = index.reconstruct_batch_device(ids, torch.float32).cpu().numpy()
+    ref = xb[ids.cpu().numpy().clip(0)]
+    ref[2, 3] = 0
+    assert got16.dtype == np.float16 and got16.shape == (7, 45, 128)
+    np.testing.assert_array_equal(got16, ref)
+    np.testing.assert_array_equal(got32, ref.astype(np.float32))
+    off = index.reconstruct_batch_device(ids + 1000, idx_offset=1000).cpu().numpy()    # a shard's global ids
+    np.testing.assert_array_equal(off, ref)                                             # id 999 lies below the shard: zero row
+    x32 = (rng.standard_normal((500, 128)) * (1 + 2.0 ** -14)).astype(np.float32)       # not representable in fp16
+    exact = IndexFlatIP(128)
+    exact.add(x32)
+    assert exact.exact_f32
+    pick = torch.tensor([0, 499, 17], device=gpu_device)
+    np.testing.assert_array_equal(exact.reconstruct_batch_device(pick, torch.float32).cpu().numpy(), x32[[0, 499, 17]])
+    with pytest.raises(ValueError):
+        index.reconstruct_batch_device(ids.to(torch.int32))
+
+
 def test_online_retriever_is_the_exact_search(gpu_device):
     """qa/online_sampler.py's per-question retrieval (k = 5000) on the exact index."""
     import torch
@@ -512,6 +542,11 @@ def test_online_retriever_is_the_exact_search(gpu_device):
         np.testing.assert_array_equal(emb, xb[Io[0]])
     r_list = OnlineRetriever(xb, [f"doc-{i}" for i in range(len(xb))], device=gpu_device)   # row-ordered ids instead of the dict
     assert r_list.retrieve(q, 5000)[1] == ids
+    r32 = OnlineRetriever(xb.astype(np.float32), None, device=gpu_device)                   # the reference's float32 array
+    idx32, none, emb32 = r32.retrieve(q.astype(np.float32), 5000)
+    assert none is None and emb32.dtype == np.float32
+    np.testing.assert_array_equal(idx32, Io[0])
+    np.testing.assert_array_equal(emb32, xb[Io[0]].astype(np.float32))
     idx, ids, emb = r.retrieve(q, 20000)                      # more than the index holds
     assert len(idx) == 9000 and emb.shape == (9000, 128)
 
