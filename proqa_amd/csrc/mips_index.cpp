@@ -399,6 +399,24 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   return PROQA_OK;
 }
 
+// Exact top-k of rows [0, rows) for every query in two launches (see bootstrap_scores / bootstrap_select): the state the
+// rounds would have after those rows.  Its overflow word is the last-but-one (the last belongs to the overflow-safe
+// re-scans).
+int run_bootstrap(proqa_index* idx, long long rows, unsigned nq_pad, int k, hipStream_t st) {
+  const size_t need = (size_t)idx->ws_nq_pad * round_up<long long>(rows, 32);
+  if (need > idx->boot_floats) {
+    PROQA_HIP(hipStreamSynchronize(st));
+    if (idx->boot_scores) PROQA_HIP(hipFree(idx->boot_scores));
+    idx->boot_scores = nullptr;
+    idx->boot_floats = 0;
+    PROQA_HIP(hipMalloc((void**)&idx->boot_scores, need * sizeof(float)));
+    idx->boot_floats = need;
+  }
+  PROQA_HIP(launch_bootstrap(idx->xb, idx->xq_pad, (int)rows, nq_pad, k, idx->boot_scores, idx->run_keys, idx->run_n, idx->tau,
+                             idx->stat_dev, idx->overflow + kMaxRounds - 2, st));
+  return PROQA_OK;
+}
+
 // One page of results (page_k <= kPageK best rows below the page bound): rounds of filter + merge
 // over geometrically growing slabs, then the overflow-safe re-scan of any round that overflowed.
 struct PageOut {
@@ -425,20 +443,8 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
   const int first = page_k > kPageK ? first_cap : std::min<int>(idx->first_slab_rows, first_cap);
   std::vector<Slab> slabs = plan_slabs(idx->n, first, growth_for(page_k, idx->growth, qw), boot);
   if ((int)slabs.size() + 2 > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
-  if (boot) {
-    const size_t need = (size_t)idx->ws_nq_pad * round_up<long long>(boot, 32);
-    if (need > idx->boot_floats) {
-      PROQA_HIP(hipStreamSynchronize(st));
-      if (idx->boot_scores) PROQA_HIP(hipFree(idx->boot_scores));
-      idx->boot_scores = nullptr;
-      idx->boot_floats = 0;
-      PROQA_HIP(hipMalloc((void**)&idx->boot_scores, need * sizeof(float)));
-      idx->boot_floats = need;
-    }
-    // its overflow word is the last-but-one (the last belongs to the overflow-safe re-scans)
-    PROQA_HIP(launch_bootstrap(idx->xb, idx->xq_pad, (int)boot, (unsigned)nq_pad, page_k, idx->boot_scores, idx->run_keys,
-                               idx->run_n, idx->tau, idx->stat_dev, idx->overflow + kMaxRounds - 2, st));
-  }
+  if (boot)
+    if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, page_k, st)) return rc;
   const bool prof = idx->profile && !bounded;  // the per-round brackets describe the first page
   for (size_t r = 0; r < slabs.size(); ++r) {
     hipEvent_t f0 = prof ? idx->ev_filter[2 * r] : nullptr;
@@ -612,19 +618,8 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   const int first_cap = (sort_capacity(r) - r) / kStageRows * kStageRows;
   std::vector<Slab> slabs = plan_slabs(pl.n_sample, std::min<int>(idx->first_slab_rows, first_cap), growth_for(r, idx->growth, qw), boot);
   if ((int)slabs.size() + 4 > kMaxRounds) return PROQA_OK;
-  if (boot) {
-    const size_t need = (size_t)idx->ws_nq_pad * round_up<long long>(boot, 32);
-    if (need > idx->boot_floats) {
-      PROQA_HIP(hipStreamSynchronize(st));
-      if (idx->boot_scores) PROQA_HIP(hipFree(idx->boot_scores));
-      idx->boot_scores = nullptr;
-      idx->boot_floats = 0;
-      PROQA_HIP(hipMalloc((void**)&idx->boot_scores, need * sizeof(float)));
-      idx->boot_floats = need;
-    }
-    PROQA_HIP(launch_bootstrap(idx->xb, idx->xq_pad, (int)boot, (unsigned)nq_pad, r, idx->boot_scores, idx->run_keys,
-                               idx->run_n, idx->tau, idx->stat_dev, idx->overflow + kMaxRounds - 2, st));
-  }
+  if (boot)
+    if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, r, st)) return rc;
   // spread the slabs over [boot, n): slab i keeps its length and starts i/m of the way through
   {
     const size_t m = slabs.size();
