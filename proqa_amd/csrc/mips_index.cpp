@@ -616,7 +616,11 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   if (idx->bootstrap_rows > 0 && r <= kBootstrapMaxK && r <= idx->bootstrap_rows / 4 && pl.n_sample >= 4ll * idx->bootstrap_rows)
     boot = std::min<long long>(idx->bootstrap_rows, kBootstrapMaxRows);
   const int first_cap = (sort_capacity(r) - r) / kStageRows * kStageRows;
-  std::vector<Slab> slabs = plan_slabs(pl.n_sample, std::min<int>(idx->first_slab_rows, first_cap), growth_for(r, idx->growth, qw), boot);
+  // the sample rounds run on this search's deep lane lists (24 records): their candidate budget is what one merge holds
+  // next to the r running keys, less 15 % for the spread, not the 640 of a search on 8-record lists
+  const double g_cap = idx->growth > 0 ? idx->growth : (qw == 1 ? 8 : 4);
+  const double growth = std::min(g_cap, 0.85 * (sort_capacity(r) - r) / r);
+  std::vector<Slab> slabs = plan_slabs(pl.n_sample, std::min<int>(idx->first_slab_rows, first_cap), growth, boot);
   if ((int)slabs.size() + 4 > kMaxRounds) return PROQA_OK;
   if (boot)
     if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, r, st)) return rc;
