@@ -66,22 +66,33 @@ def build(force=False, verbose=False):
     with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)          # released when the file is closed
         objs = []
+        todo = []
         for src in SOURCES:
             path = os.path.join(CSRC, src)
             obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
             objs.append(obj)
             if force or _stale(obj, [path] + headers):   # re-checked under the lock: another rank may have built it
-                tmp = f"{obj}.{os.getpid()}.tmp"
-                cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
-                       "-Wall", "-Wno-unused-function", "-c", path, "-o", tmp]
-                if verbose:
-                    print(" ".join(cmd), file=sys.stderr)
-                try:
-                    subprocess.run(cmd, check=True, env=env)
-                    os.replace(tmp, obj)
-                finally:
-                    if os.path.exists(tmp):
-                        os.remove(tmp)
+                todo.append((path, obj))
+
+        def compile_one(job):
+            path, obj = job
+            tmp = f"{obj}.{os.getpid()}.tmp"
+            cmd = [hipcc, "-x", "hip", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+                   "-Wall", "-Wno-unused-function", "-c", path, "-o", tmp]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            try:
+                subprocess.run(cmd, check=True, env=env)
+                os.replace(tmp, obj)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+
+        if todo:
+            # the sources are independent: a few compilers side by side (hipcc peaks at ~2 GB each)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(4, len(todo), os.cpu_count() or 1)) as pool:
+                list(pool.map(compile_one, todo))        # re-raises the first CalledProcessError
         if force or _stale(LIB_PATH, objs):
             tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
             cmd = ["g++", "-shared", "-o", tmp] + objs + ["-Wl,--no-as-needed", "-lpthread", "-lm", "-ldl"]
