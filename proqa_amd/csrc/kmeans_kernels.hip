@@ -233,14 +233,27 @@ __global__ __launch_bounds__(256) void segmented_mean(const _Float16* __restrict
   if (n == 0) return;  // empty cluster: the host re-seeds it (faiss splits a large cluster)
   const unsigned b = begin[c];
   float s0 = 0.f, s1 = 0.f;
+  // the additions are sequential (point order), the loads are not: 32 rows in flight per wave, so that a cluster that
+  // attracted a hundred times its share of the points (first iterations; hubs of real embeddings) is bound by memory
+  // throughput, not by one load latency per point
+  constexpr unsigned kInFlight = 32;
   for (unsigned i0 = 0; i0 < n; i0 += 64) {
     const unsigned mine = i0 + lane < n ? order[b + i0 + lane] : 0u;
     const unsigned m = min(64u, n - i0);
-    for (unsigned j = 0; j < m; ++j) {
-      const unsigned p = __shfl(mine, (int)j, 64);
-      const f16x2 v = *(const f16x2*)(x + (long long)p * kD + 2 * lane);
-      s0 += (float)v[0];
-      s1 += (float)v[1];
+    for (unsigned j0 = 0; j0 < m; j0 += kInFlight) {
+      f16x2 v[kInFlight];
+#pragma unroll
+      for (unsigned u = 0; u < kInFlight; ++u) {
+        const unsigned p = __shfl(mine, (int)min(j0 + u, m - 1), 64);   // past the end: the last row again, not added
+        v[u] = *(const f16x2*)(x + (long long)p * kD + 2 * lane);
+      }
+#pragma unroll
+      for (unsigned u = 0; u < kInFlight; ++u) {
+        if (j0 + u < m) {
+          s0 += (float)v[u][0];
+          s1 += (float)v[u][1];
+        }
+      }
     }
   }
   const float inv = (float)n;
