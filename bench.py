@@ -47,6 +47,7 @@ def parse():
                    help="passages of the corpus-scale encode leg (BASELINE.json configs[1]); 0 skips it")
     p.add_argument("--skip-float32", action="store_true", help="skip the exact-float32 index leg")
     p.add_argument("--skip-cpu", action="store_true")
+    p.add_argument("--skip-varlen", action="store_true", help="encode leg: full-length steps only (PMC traffic passes)")
     p.add_argument("--skip-extras", action="store_true",
                    help="skip the shard sweep and the measured-peak micro-benchmarks (profiler passes: keeps the kernel "
                         "statistics to the searches of the headline workload)")
@@ -213,11 +214,13 @@ def encode_leg(args, device, world, rank):
                                "fp16 weights/activations, fp32 accumulate, random N(0,0.02) weights", "batch": B,
                    "seq_len": S},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tf / PEAK_MFMA_F16_TFLOPS, "traffic": None,
+                     "frac": tf / PEAK_MFMA_F16_TFLOPS, "traffic": encode_traffic(B, S),
                      "gflop_per_passage_executed": executed, "gflop_per_passage_reference": ENCODE_GFLOP_PER_PASSAGE,
                      "note": "flops executed per step / step time (the last layer is evaluated on the [CLS] rows "
                              "only); the dense-layer GEMMs are rocBLAS calls made by libproqa_hip.so"},
     }
+    if args.skip_varlen:     # (the encoder's PMC traffic passes want full-size steps only)
+        return res
     # variable-length variant: lengths ~ U[32, S], right-padded as em_collate does;
     # the lengths are known on the host (predict() takes them from the collated batch), padding is skipped
     lens_host = torch.randint(32, S + 1, (B,), generator=torch.Generator().manual_seed(rank)).tolist()
@@ -525,6 +528,17 @@ def measured_peaks(device):
     out["note"] = ("float4 grid-stride copy / read of 2 GiB; 4 independent v_mfma_f32_32x32x16_f16 chains per wave from "
                    "registers, 8 waves per CU; best of repeated launches")
     return out
+
+
+def encode_traffic(batch, seq_len):
+    """HBM bytes one 512 x 128 encode step reads, all its kernels together (committed rocprofv3 PMC pass,
+    FETCH_SIZE x 2 per the gfx950 note); None for other shapes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        return t.get("encode_hbm_read_bytes_per_step") if (batch, seq_len) == tuple(t.get("encode_step_shape", ())) else None
+    except Exception:
+        return None
 
 
 def pmc_traffic(shard_fraction):

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
   // then stays in the XCD's 4 MiB L2 while the token slabs stream past); inside a group the tile index runs
   // feature-tile-fastest over (slab, feature tile), so the ~32 workgroups of the XCD that run side by side share
   // 8 weight tiles and 4 token slabs per K-step.  Index t enumerates (group, slab, feature tile in group).
+  // (groups of 6 or 12 measure the same)
   constexpr int kGroup = 8;
   auto tile_bases = [&](long long t, const char*& wbase, const char*& xbase, int& m0, int& n0) {
     const long long per_full_group = (long long)my_slabs * kGroup;
@@ -277,7 +278,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
         for (int i = 0; i < 4; ++i) {
           const int row = 8 * i + rd_row;
           const f16x8 o = *(const f16x8*)(stage + row * 128 + ((rd_q ^ ((row >> 1) & 7)) << 4));
-          *(f16x8*)(dst + (long long)row * N) = o;
+          // non-temporal: 403 MB of output per BertIntermediate launch would otherwise push the weight group and the
+          // token slabs out of the XCD's L2
+          __builtin_nontemporal_store(o, (f16x8*)(dst + (long long)row * N));
         }
       }
     }

@@ -19,7 +19,7 @@ def short(name):
         return "mips_filter_f16_qw1"      # the HBM-bound small-batch instantiation (bench.py scan_small_batch)
     for key in ("mips_filter_f16", "topk_merge", "merge_lists", "bootstrap_scores", "bootstrap_select", "prep_queries",
                 "finalize_topk", "gemm_tn_f16", "attention_fwd", "attention_cls_fwd", "bias_gelu", "bias_residual_layernorm",
-                "embed_layernorm", "pool_project", "cls_dense_mfma", "stream_copy", "stream_read", "mfma_loop", "Cijk_"):
+                "embed_layernorm", "pool_project", "cls_dense_mfma", "small_dense_mfma", "gather_rows_kernel", "stream_copy", "stream_read", "mfma_loop", "Cijk_"):
         if key in name:
             return key if key != "Cijk_" else "hipblaslt_gemm(" + name.split("_MT")[1].split("_")[0] + ")" if "_MT" in name else "hipblaslt_gemm"
     return None
@@ -144,11 +144,40 @@ if tot_cycles:
     derived_enc["whole_encoder"] = {"mfma_pipe_busy_of_sq_busy": tot_busy / (1024 * tot_cycles)}
 if derived_enc:
     summary["derived_encoder"] = derived_enc
+# encoder HBM traffic per full-size step (collect_profiles.sh: enc_pmc_fetch / enc_pmc_write, bench.py --skip-varlen):
+# all encoder kernels of the pass together, over the number of steps (= embed_layernorm launches)
+enc_traffic = {}
+for sub, counter in (("enc_pmc_fetch", "FETCH_SIZE"), ("enc_pmc_write", "WRITE_SIZE")):
+    path = os.path.join(root, sub, "bench_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    total, steps, per_kernel = 0.0, set(), collections.defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        n = short(r["Kernel_Name"])
+        if r["Counter_Name"] != counter or not n or n.startswith("mips_") or n.startswith("bootstrap") or \
+                n in ("topk_merge", "prep_queries", "finalize_topk", "merge_lists"):
+            continue
+        total += float(r["Counter_Value"])
+        per_kernel[n] += float(r["Counter_Value"])
+        if n == "embed_layernorm":
+            steps.add(r["Dispatch_Id"])
+    if steps:
+        scale = 2 * 1024 if counter == "FETCH_SIZE" else 1024     # KB; gfx950: FETCH_SIZE counts half
+        key = "read" if counter == "FETCH_SIZE" else "write_uncalibrated"
+        enc_traffic["steps_profiled_" + key] = len(steps)
+        enc_traffic["hbm_%s_bytes_per_step" % key] = total * scale / len(steps)
+        enc_traffic["hbm_%s_bytes_per_step_by_kernel" % key] = {k: v * scale / len(steps) for k, v in per_kernel.items()}
+if enc_traffic:
+    summary["derived_encoder_traffic"] = enc_traffic
 json.dump(summary, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
 if "hbm_read_bytes_per_search" in derived:
-    json.dump({"hbm_bytes_per_search": derived["hbm_read_bytes_per_search"],
+    traffic = {"hbm_bytes_per_search": derived["hbm_read_bytes_per_search"],
                "note": "mips_filter_f16: 2 x FETCH_SIZE (gfx950 correction) summed over the rounds of one search; "
-                       "algorithmic bytes are N*256 = 4.608e9"},
-              open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
+                       "algorithmic bytes are N*256 = 4.608e9"}
+    if "hbm_read_bytes_per_step" in enc_traffic:
+        traffic["encode_hbm_read_bytes_per_step"] = enc_traffic["hbm_read_bytes_per_step"]
+        traffic["encode_step_shape"] = [512, 128]
+        traffic["encode_note"] = "all kernels of one 512 x 128 bert-base encode step, 2 x FETCH_SIZE"
+    json.dump(traffic, open(os.path.join(root, "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(derived, indent=1))
 print(json.dumps(summary.get('derived_encoder', {}), indent=1))
