@@ -607,7 +607,8 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   // the big launch's store first, so that the sample rounds do not allocate a small one that is thrown away
   {
     const LaunchGeom g = geometry(idx->n, n_qtiles, false, k, shape.want_chunks);
-    if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad, shape.lane_cap)) return rc;
+    if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad, shape.lane_cap))
+      return rc == PROQA_ENOMEM ? PROQA_OK : rc;   // no room for the deep lists beside the caller's tensors: page by page
   }
   PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
   // (1) thresholds from the sample.  Overflow in here is harmless: it loosens the estimate.
