@@ -589,6 +589,12 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool la
   if (p.n_sample > idx->n / 4) return p;                       // k is a large part of the shard
   p.want_chunks = round_up<unsigned>((unsigned)std::ceil(expected / 16.0), 8);   // two lists per chunk, ~8 records each
   if ((long long)p.want_chunks * kStageRows > idx->n) return p;
+  {
+    // chunks are whole stages: a shard of few stages per chunk may end up with fewer chunks than asked for
+    const long long rpc = round_up<long long>(ceil_div<long long>(idx->n, p.want_chunks), kStageRows);
+    const long long chunks = ceil_div<long long>(idx->n, rpc);
+    if (expected / (2.0 * chunks) > 12.0) return p;            // lists of 24 would spill: pages
+  }
   // queries one launch can take within the store budget (whole query tiles)
   const size_t per_query = (size_t)(p.want_chunks + 8) * 2 * kOnePassLaneCap * sizeof(WaveRecord);
   size_t budget = kOnePassMaxStoreBytes;
