@@ -347,6 +347,11 @@ def corpus_leg(args, device, world, rank, model, sd):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: everything else that writes to file descriptor 1 (RCCL prints a
+    # five-line version banner there when a communicator is created) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -498,7 +503,8 @@ def main():
         line["encode"] = enc
 
     if rank == 0:
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
