@@ -135,6 +135,11 @@ int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
  * segmented radix sort in HBM (temporary buffers are allocated for the call). */
 int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts,
                             int64_t nq, int k, float* D_dev, int64_t* I_dev, void* stream);
+/* The same merge over parts that are not back to back: part p's [nq, k] scores / ids start stride_d / stride_i ELEMENTS
+ * after part p-1's -- the receive buffer of ONE all-gather whose per-rank block holds the ids followed by the scores
+ * is merged where it lies (D_parts = buffer + ids bytes, stride_d = block bytes / 4, stride_i = block bytes / 8). */
+int proqa_topk_merge_strided_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int64_t nq, int k,
+                                    int64_t stride_d, int64_t stride_i, float* D_dev, int64_t* I_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Encoder: BertForRetriever.get_embed (retrieval/retriever.py:33-43 + transformers BertModel)

@@ -86,6 +86,8 @@ SIGNATURES = {
     "proqa_index_configure_bootstrap": (c_int, [c_void_p, c_int]),
     "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p]),
+    "proqa_topk_merge_strided_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int64, c_int64, c_void_p,
+                                                c_void_p, c_void_p]),
     "proqa_encoder_create": (c_int, [ctypes.POINTER(BertWeights), ctypes.POINTER(c_void_p)]),
     "proqa_encoder_free": (c_int, [c_void_p]),
     "proqa_encoder_set_gemm_tuning": (c_int, [c_void_p, c_int]),

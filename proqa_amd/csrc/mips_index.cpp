@@ -1025,15 +1025,23 @@ int proqa_index_reconstruct_batch_device(proqa_index* idx, const int64_t* ids_de
   return PROQA_OK;
 }
 
-int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int64_t nq,
-                            int k, float* D_dev, int64_t* I_dev, void* stream) {
+int proqa_topk_merge_strided_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int64_t nq, int k,
+                                    int64_t stride_d, int64_t stride_i, float* D_dev, int64_t* I_dev, void* stream) {
   if (!D_parts_dev || !I_parts_dev || !D_dev || !I_dev || n_parts <= 0 || nq < 0 || k <= 0)
     return fail(PROQA_EINVAL, "topk_merge_device: bad argument");
   if ((long long)n_parts * k >= (1ll << 27))
     return fail(PROQA_EINVAL, "topk_merge_device: n_parts*k=%lld is too large", (long long)n_parts * k);
-  PROQA_HIP(launch_merge_lists(D_parts_dev, (const long long*)I_parts_dev, n_parts, nq, k, (long long)nq * k, (long long)nq * k, D_dev,
-                               (long long*)I_dev, as_stream(stream)));
+  if (stride_d < nq * k || stride_i < nq * k)
+    return fail(PROQA_EINVAL, "topk_merge_device: part strides %lld / %lld are shorter than a part (%lld)", (long long)stride_d,
+                (long long)stride_i, (long long)(nq * k));
+  PROQA_HIP(launch_merge_lists(D_parts_dev, (const long long*)I_parts_dev, n_parts, nq, k, (long long)stride_d, (long long)stride_i,
+                               D_dev, (long long*)I_dev, as_stream(stream)));
   return PROQA_OK;
+}
+
+int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts, int64_t nq,
+                            int k, float* D_dev, int64_t* I_dev, void* stream) {
+  return proqa_topk_merge_strided_device(D_parts_dev, I_parts_dev, n_parts, nq, k, nq * k, nq * k, D_dev, I_dev, stream);
 }
 
 }  // extern "C"

@@ -112,8 +112,8 @@ class IndexFlatIP:
         _lib.check(self._lib.proqa_index_adopt_device(self._h, xb.data_ptr(), xb.shape[0]))
         self._adopted = xb
 
-    def search_device(self, xq, k, idx_offset=0):
-        """CUDA tensor in, CUDA tensors out: (D float32 [nq,k], I int64 [nq,k])."""
+    def search_device(self, xq, k, idx_offset=0, out=None):
+        """CUDA tensor in, CUDA tensors out: (D float32 [nq,k], I int64 [nq,k]); `out` = (D, I) to write into."""
         import torch
         if not xq.is_cuda:
             raise ValueError("search_device expects a CUDA tensor")
@@ -121,8 +121,14 @@ class IndexFlatIP:
         if xq.dim() != 2 or xq.shape[1] != self.d:
             raise ValueError(f"xq must have shape [nq, {self.d}], got {tuple(xq.shape)}")
         nq = xq.shape[0]
-        D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
-        I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        if out is not None:
+            D, I = out
+            if (tuple(D.shape), D.dtype, tuple(I.shape), I.dtype) != ((nq, k), torch.float32, (nq, k), torch.int64) or \
+                    not (D.is_contiguous() and I.is_contiguous() and D.device == xq.device and I.device == xq.device):
+                raise ValueError("out must be contiguous (float32 [nq,k], int64 [nq,k]) tensors on xq's device")
+        else:
+            D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
         with torch.cuda.device(xq.device):
             for q0 in range(0, max(nq, 1), QUERY_BATCH):
                 part = xq[q0:q0 + QUERY_BATCH]
@@ -297,15 +303,19 @@ class ShardedIndexFlatIP:
         import torch
         if self._comm is not None:
             return self._search_cabi(xq, k)
+        exchange = self.world_size > 1 or force_collective
+        if exchange and not self.dist.is_initialized():
+            raise RuntimeError('force_collective with transport="torch" needs an initialised torch.distributed process '
+                               'group (transport="cabi" brings its own RCCL communicator)')
+        if exchange and self._local_search is None and self._merge is merge_topk_device and \
+                self.dist.get_backend(self.group) == "nccl":
+            return self._search_in_place(xq, k)
         if self._local_search is not None:
             D, I = self._local_search(xq, k, self.lo)
         else:
             D, I = self._index.search_device(xq, k, idx_offset=self.lo)
-        if self.world_size == 1 and not force_collective:
+        if not exchange:
             return D, I
-        if not self.dist.is_initialized():
-            raise RuntimeError('force_collective with transport="torch" needs an initialised torch.distributed process '
-                               'group (transport="cabi" brings its own RCCL communicator)')
         # ONE collective: ids (int64) and scores (float32) travel as one byte buffer per rank;
         # rank-ordered slices of the gathered buffer are exactly the [n_parts, nq, k] layout the merge consumes
         n_i, n_d = I.numel() * 8, D.numel() * 4
@@ -318,6 +328,32 @@ class ShardedIndexFlatIP:
         I_all = gathered[:, :n_i].contiguous().view(torch.int64).reshape((self.world_size,) + tuple(I.shape))
         D_all = gathered[:, n_i:].contiguous().view(torch.float32).reshape((self.world_size,) + tuple(D.shape))
         return self._merge(D_all, I_all)
+
+    def _search_in_place(self, xq, k):
+        """The RCCL exchange without staging copies: the local search writes its ids and scores straight into this
+        rank's block [ids | scores | pad to 16 B] of the send buffer, ONE all_gather_into_tensor, and the strided merge
+        (proqa_topk_merge_strided_device) reads the receive buffer where it lies."""
+        import torch
+        nq = xq.shape[0]
+        n_i, n_d = nq * k * 8, nq * k * 4
+        block = (n_i + n_d + 15) // 16 * 16
+        mine = torch.empty(block, dtype=torch.uint8, device=xq.device)
+        I = mine[:n_i].view(torch.int64).view(nq, k)
+        D = mine[n_i:n_i + n_d].view(torch.float32).view(nq, k)
+        self._index.search_device(xq, k, idx_offset=self.lo, out=(D, I))
+        gathered = torch.empty((self.world_size, block), dtype=torch.uint8, device=xq.device)
+        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        D_out = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+        I_out = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        with torch.cuda.device(xq.device):
+            _lib.check(self._lib_handle().proqa_topk_merge_strided_device(
+                gathered.data_ptr() + n_i, gathered.data_ptr(), self.world_size, nq, int(k), block // 4, block // 8,
+                D_out.data_ptr(), I_out.data_ptr(), _lib.current_stream_ptr()))
+        return D_out, I_out
+
+    @staticmethod
+    def _lib_handle():
+        return _lib.load()
 
     def _search_cabi(self, xq, k):
         """proqa_sharded_search_device: local search, RCCL all-gather and merge inside the library."""

@@ -377,6 +377,44 @@ def test_full_size_properties(gpu_device):
     assert torch.equal(Im, I) and torch.equal(Dm, D)
 
 
+@pytest.mark.parametrize("n_parts,nq,k", [(2, 33, 80), (8, 257, 80), (3, 5, 1), (8, 9, 5000), (5, 21, 333)])
+def test_strided_merge_of_a_gathered_buffer(gpu_device, n_parts, nq, k):
+    """The receive buffer of the one all-gather -- per rank a block [ids int64 | scores float32 | pad to 16 B] -- merged
+    where it lies (proqa_topk_merge_strided_device; what the RCCL paths do on more than one rank) equals the merge
+    of the same parts copied into dense [n_parts, nq, k] arrays, and the oracle over the union."""
+    import torch
+    from proqa_amd import _lib
+    from proqa_amd.index import merge_topk_device
+    rng = np.random.default_rng(n_parts * 1000 + k)
+    # per-part lists as a shard would report them: scores descending with ties, global ids ascending with the part
+    Dp = np.sort(rng.integers(-50, 50, (n_parts, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    Ip = np.stack([np.sort(rng.permutation(100000)[:nq * k].reshape(nq, k), axis=1) + 100000 * p for p in range(n_parts)])
+    for p in range(n_parts):          # (score desc, id asc) inside every list
+        for q in range(nq):
+            order = np.lexsort((Ip[p, q], -Dp[p, q]))
+            Dp[p, q], Ip[p, q] = Dp[p, q][order], Ip[p, q][order]
+    n_i, n_d = nq * k * 8, nq * k * 4
+    block = (n_i + n_d + 15) // 16 * 16
+    buf = np.zeros((n_parts, block), np.uint8)
+    for p in range(n_parts):
+        buf[p, :n_i] = Ip[p].astype(np.int64).view(np.uint8).reshape(-1)
+        buf[p, n_i:n_i + n_d] = Dp[p].view(np.uint8).reshape(-1)
+    g = torch.from_numpy(buf).to(gpu_device)
+    D = torch.empty((nq, k), dtype=torch.float32, device=gpu_device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=gpu_device)
+    lib = _lib.load()
+    _lib.check(lib.proqa_topk_merge_strided_device(g.data_ptr() + n_i, g.data_ptr(), n_parts, nq, k, block // 4, block // 8,
+                                                   D.data_ptr(), I.data_ptr(), _lib.current_stream_ptr()))
+    Dd, Id = merge_topk_device(torch.from_numpy(Dp).to(gpu_device), torch.from_numpy(Ip.astype(np.int64)).to(gpu_device))
+    assert torch.equal(D, Dd) and torch.equal(I, Id)
+    allD = Dp.transpose(1, 0, 2).reshape(nq, -1)
+    allI = Ip.transpose(1, 0, 2).reshape(nq, -1)
+    for q in range(nq):
+        order = np.lexsort((allI[q], -allD[q]))[:k]
+        np.testing.assert_array_equal(I[q].cpu().numpy(), allI[q][order])
+        np.testing.assert_array_equal(D[q].cpu().numpy(), allD[q][order])
+
+
 @pytest.mark.parametrize("n,nq,k", [(30000, 70, 2500), (20000, 300, 1025), (3000, 20, 10000), (60000, 33, 10000)])
 def test_large_k_paged_search(gpu_device, n, nq, k):
     """k > 1024 (retrieval/trec_process.py:76 asks for k=10000) is served page by page; integer
