@@ -345,8 +345,33 @@ def corpus_leg(args, device, world, rank, model, sd):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line and the child's exit code.  Nothing in this process has
+    touched the GPU at this point (no HIP call before the child exists, and no exec of a process that initialised it)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank child exited with code {proc.returncode}"
+                         f"{'' if lines else ' and printed no result line'}\n")
+        raise SystemExit(proc.returncode or 1)
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    raise SystemExit(0)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     # stdout carries exactly ONE line, the JSON result: everything else that writes to file descriptor 1 (RCCL prints a
     # five-line version banner there when a communicator is created) goes to stderr
     sys.stdout.flush()
@@ -355,9 +380,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if "WORLD_SIZE" in os.environ and world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} under a launcher with WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -398,6 +422,25 @@ def main():
     tflops = flops / filter_s / 1e12
     hbm_gbs = (hi - lo) * D * 2 / filter_s / 1e9
 
+    # what ran where: every rank reports its process, GPU and shard (the record proves N ranks on N devices); the
+    # digests of the merged result let two runs of the same workload (e.g. --gpus 1 and --gpus 2) be compared bit for bit
+    import hashlib
+    Dm, Im = result["DI"]
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "pid": os.getpid(), "device": local_rank, "gpu": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "rows": [lo, hi]}
+    ranks = [me]
+    if dist.is_initialized():
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    comm_info = None
+    if getattr(sharded, "_comm", None) is not None:
+        import ctypes
+        from proqa_amd import _lib
+        ws_, rk_ = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().proqa_comm_info(sharded._comm, ctypes.byref(ws_), ctypes.byref(rk_)))
+        comm_info = {"world_size": ws_.value, "rank": rk_.value}
+
     line = {
         "metric": "queries/sec top-80 MIPS over 18M x 128 index", "value": qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -410,7 +453,12 @@ def main():
                                 f"one all-gather of per-rank top-{k} lists, transport={args.transport}, "
                                 f"backend={dist.get_backend() if dist.is_initialized() else 'rccl (library communicator)'}"),
                    "rounds": st["rounds"], "fallback_rounds": st["fallback_rounds"],
-                   "candidates_per_query": st["candidates"] / max(nq, 1)},
+                   "candidates_per_query": st["candidates"] / max(nq, 1),
+                   "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                   "backend": dist.get_backend() if dist.is_initialized() else None,
+                   "library_communicator": comm_info, "ranks": ranks},
+        "result": {"ids_sha256": hashlib.sha256(Im.cpu().numpy().tobytes()).hexdigest(),
+                   "scores_sha256": hashlib.sha256(Dm.cpu().numpy().tobytes()).hexdigest()},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_MFMA_F16_TFLOPS, "traffic": pmc_traffic((hi - lo) / n),
                      "kernel": "mips_filter_f16", "filter_ms_per_search": st["filter_ms"],

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROQA_ABI_VERSION 2
+#define PROQA_ABI_VERSION 3
 
 /* element types of embedding matrices (the .npy index is '<f2' under --fp16, else '<f4':
  * retrieval/get_embed.py:139) */
@@ -100,6 +100,19 @@ int proqa_index_search(proqa_index* idx, const void* xq, int64_t nq, int dtype, 
  * row-sharded corpus yields global ids.  Synchronises `stream` before returning. */
 int proqa_index_search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k,
                               int64_t idx_offset, float* D_dev, int64_t* I_dev, void* stream);
+
+/* Two-step form of proqa_index_search_device for a caller that has more work to put on the stream behind the search
+ * (the sharded search enqueues its all-gather and merge there).  _begin enqueues the whole search and returns WITHOUT
+ * synchronising whenever it can (k <= 1024 outside the one-pass range; other searches run to completion inside
+ * _begin).  Once the stream reaches that point D_dev / I_dev hold the result, provided no round overflowed its candidate
+ * lists (a data-dependent, rare event): status_dev (optional device word, written on the stream) is then 0; 1 means
+ * _finish is going to rewrite D_dev / I_dev.  _finish synchronises the stream, runs the overflow-safe re-scan if it is
+ * needed (*rewritten = 1; D_dev / I_dev are final when it returns) and completes proqa_index_last_stats.  xq_dev, D_dev,
+ * I_dev and status_dev stay valid, and no other call is made on the handle, until _finish has returned.
+ * Reference call site: the one faiss search of retrieval/eval_retrieval.py:102-104 (faiss has no asynchronous form). */
+int proqa_index_search_begin_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
+                                    float* D_dev, int64_t* I_dev, uint32_t* status_dev, void* stream);
+int proqa_index_search_finish(proqa_index* idx, int* rewritten);
 
 /* rows of the index by id, device pointers (faiss reconstruct_batch; the gather `para_embed[I]` of
  * /root/reference/qa/online_sampler.py:117,277 without leaving the GPU): out_dev [n, d] of out_dtype.  PROQA_F16 gives
@@ -324,9 +337,23 @@ int proqa_comm_info(const proqa_comm* comm, int* world_size, int* rank);
 int proqa_comm_free(proqa_comm* comm);
 /* every rank calls with the SAME queries (device pointers), nq, dtype and k, and with idx_offset = its first global
  * row; ranks must hold ascending row ranges in rank order.  D_dev / I_dev [nq, k] receive the merged result on every
- * rank.  The collective runs even for world_size 1. */
+ * rank.  The collective runs even for world_size 1.  The local search, the all-gather and the merge are enqueued back to
+ * back (proqa_index_search_begin_device) and the host waits once, at the end; each rank's block carries a status word, so
+ * that a rank whose lists overflowed triggers ONE more exchange on every rank, and a rank whose local search fails still
+ * enters the collective: every rank then returns an error instead of waiting for it forever.  One stream per communicator
+ * at a time (the exchange buffers belong to the communicator). */
 int proqa_sharded_search_device(proqa_index* idx, proqa_comm* comm, const void* xq_dev, int64_t nq, int dtype,
                                 int k, int64_t idx_offset, float* D_dev, int64_t* I_dev, void* stream);
+/* The pieces of that call for a caller that brings its own collective (proqa_amd.index.ShardedIndexFlatIP over
+ * torch.distributed): the per-rank block the all-gather exchanges is [ids int64 nq*k | scores float nq*k | status word],
+ * every part padded to 16 bytes (_block_layout); the rank-local search writes ids, scores and the status word straight
+ * into its block (proqa_index_search_begin_device), and _merge_gathered merges the n_parts blocks of the receive buffer
+ * where they lie and drops every block's status word into status_host (n_parts words of PINNED host memory, e.g.
+ * hipHostMalloc; read them after synchronising the stream; NULL skips it): 0 = that rank's list stands, 1 = it is being
+ * rewritten by proqa_index_search_finish (exchange once more), 0xFFFFFFFF = that rank failed. */
+int proqa_sharded_block_layout(int64_t nq, int k, size_t* ids_bytes, size_t* scores_bytes, size_t* block_bytes);
+int proqa_topk_merge_gathered_device(const void* gathered_dev, int n_parts, int64_t nq, int k, uint32_t* status_host,
+                                     float* D_dev, int64_t* I_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Measured ceilings of this GPU (bench.py "peak_measured"; SURVEY.md section 8d asks for them next to the spec

@@ -79,6 +79,9 @@ SIGNATURES = {
     "proqa_index_search": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "proqa_index_search_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
                                           c_void_p, c_void_p, c_void_p]),
+    "proqa_index_search_begin_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
+                                                c_void_p, c_void_p, c_void_p, c_void_p]),
+    "proqa_index_search_finish": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "proqa_index_reconstruct_batch_device": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p]),
     "proqa_index_last_stats": (c_int, [c_void_p, ctypes.POINTER(SearchStats)]),
     "proqa_index_set_profiling": (c_int, [c_void_p, c_int]),
@@ -128,6 +131,9 @@ SIGNATURES = {
     "proqa_comm_free": (c_int, [c_void_p]),
     "proqa_sharded_search_device": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p,
                                             c_void_p, c_void_p]),
+    "proqa_sharded_block_layout": (c_int, [c_int64, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t),
+                                           ctypes.POINTER(c_size_t)]),
+    "proqa_topk_merge_gathered_device": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "proqa_microbench_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "proqa_microbench_mfma": (c_int, [ctypes.c_double, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
 }
@@ -186,7 +192,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.proqa_abi_version() != 2:
+        if lib.proqa_abi_version() != 3:
             raise RuntimeError("libproqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
         return lib

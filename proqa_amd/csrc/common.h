@@ -32,6 +32,39 @@ inline int hip_fail(hipError_t e, const char* what, const char* file, int line) 
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Makes `want` the current HIP device for the lifetime of the guard and restores the caller's device afterwards: a
+// handle that lives on another GPU than the caller's current one must not change the device under the caller (its
+// later allocations and stream look-ups would land on the wrong GPU).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int want) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != want) {
+      err = hipSetDevice(want);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define PROQA_ON_DEVICE(dev)                   \
+  ::proqa::DeviceGuard _device_guard(dev);     \
+  PROQA_HIP(_device_guard.err)
+
+// hipMalloc whose failure is an expected, recoverable condition (the caller falls back or reports PROQA_ENOMEM): HIP's
+// last-error slot is sticky until read, so it is cleared here -- otherwise the next launch wrapper's hipGetLastError()
+// would report this allocation failure as its own.
+inline hipError_t try_malloc(void** p, size_t bytes) {
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e;
+}
+
 template <typename T>
 inline T ceil_div(T a, T b) {
   return (a + b - 1) / b;

@@ -271,9 +271,7 @@ int proqa_encoder_forward(proqa_encoder* e, const int64_t* ids_dev, const int32_
   const bool packed = (flags & PROQA_ENC_PACKED) && n_valid_tokens > 0 && n_valid_tokens * 10 < n_padded * 9;
   const bool cls_only = (flags & PROQA_ENC_CLS_ONLY_LAST) != 0;
   // the weights, the workspace and the BLAS handle live on the device the encoder was created on
-  int dev = 0;
-  PROQA_HIP(hipGetDevice(&dev));
-  if (dev != e->device) PROQA_HIP(hipSetDevice(e->device));
+  PROQA_ON_DEVICE(e->device);   // (restored on return: the caller's current device is not changed under it)
   hipStream_t st = as_stream(stream);
   if (int rc = ensure_workspace(e, batch, round_up<int64_t>(n_padded, kRowTile), st)) return rc;
   Workspace& ws = e->ws;

@@ -61,13 +61,12 @@ struct proqa_index {
   unsigned* lane_cnt = nullptr;
   proqa::WaveRecord* spill_log = nullptr;
   unsigned* spill_cnt = nullptr;
-  unsigned store_chunks = 0;               // chunks the store is sized for (at ws_nq_pad queries)
-  unsigned store_qtiles = 0;
-  unsigned store_lane_cap = 0;             // records per lane list it is sized for
+  size_t store_records = 0;                // what the store holds: lane-list records, lane lists, spill slots
+  size_t store_lists = 0;
+  size_t store_slots = 0;
   unsigned* overflow = nullptr;            // [kMaxRounds] device
-  unsigned* overflow_host = nullptr;       // pinned mirror
+  proqa::SearchMirror* mirror = nullptr;   // pinned host memory the finalize kernel reports into (overflow words, candidates)
   unsigned long long* stat_dev = nullptr;  // [ws_nq_pad] candidates per query (part of the workspace)
-  unsigned long long* stat_host = nullptr; // pinned mirror, kStatHostEntries
   void* stage_dev = nullptr;               // staging for host-pointer add/search
   size_t stage_bytes = 0;
   void* stage_pinned = nullptr;
@@ -86,12 +85,28 @@ struct proqa_index {
   int first_slab_rows = 256;
   int growth = 0;                          // 0 = automatic (see growth_for)
   proqa_search_stats stats = {};
+  // a search enqueued by proqa_index_search_begin_device whose host-side completion is still due
+  struct Pending {
+    bool active = false;
+    int qw = 0;
+    unsigned n_qtiles = 0;
+    int64_t nq = 0, nq_pad = 0;
+    int k = 0, dtype = 0;
+    const void* xq_dev = nullptr;
+    float* D = nullptr;
+    long long* I = nullptr;
+    long long idx_offset = 0;
+    hipStream_t st = nullptr;
+    uint32_t* status_dev = nullptr;
+    std::vector<proqa::Slab> slabs;
+    long long boot = 0;
+  } pending;
 };
 
 namespace proqa {
 namespace {
 
-constexpr int kMaxRounds = 96;
+constexpr int kMaxRounds = kOverflowWords;   // 96
 
 // developer switches, read once: PROQA_DEBUG_CAND prints the cumulative candidate count after every
 // round (adds a host sync per round), PROQA_DEBUG_ROUNDS prints per-round filter times when profiling
@@ -103,13 +118,6 @@ const unsigned kFilterFlags = getenv("PROQA_FILTER_FLAGS") ? (unsigned)atoi(gete
 const int kWideQw = getenv("PROQA_FILTER_QW") && (atoi(getenv("PROQA_FILTER_QW")) == 4 || atoi(getenv("PROQA_FILTER_QW")) == 1)
                         ? atoi(getenv("PROQA_FILTER_QW")) : 2;
 const bool kDebugRounds = debug_flag("PROQA_DEBUG_ROUNDS");
-
-int ensure_device(proqa_index* idx) {
-  int dev = 0;
-  PROQA_HIP(hipGetDevice(&dev));
-  if (dev != idx->device) PROQA_HIP(hipSetDevice(idx->device));
-  return PROQA_OK;
-}
 
 // counters of the last float32 -> fp16 conversion: {values fp16 cannot hold exactly, values beyond its range}
 int read_inexact(proqa_index* idx, const char* what, hipStream_t st, unsigned* n_inexact) {
@@ -128,7 +136,7 @@ int reserve_rows32(proqa_index* idx, int64_t rows) {
   int64_t cap = std::max<int64_t>(rows, std::max(idx->capacity, idx->capacity32 + idx->capacity32 / 2));
   cap = round_up<int64_t>(cap, kStageRows);
   float* p = nullptr;
-  hipError_t e = hipMalloc((void**)&p, (size_t)cap * kDim * 4);
+  hipError_t e = try_malloc((void**)&p, (size_t)cap * kDim * 4);
   if (e != hipSuccess) return fail(PROQA_ENOMEM, "hipMalloc of %lld float32 index rows failed: %s", (long long)cap,
                                    hipGetErrorString(e));
   if (idx->n > 0 && idx->xb32)
@@ -173,7 +181,7 @@ int reserve_rows(proqa_index* idx, int64_t rows) {
   int64_t cap = std::max<int64_t>(rows, idx->capacity + idx->capacity / 2);
   cap = round_up<int64_t>(cap, kStageRows);
   char* p = nullptr;
-  hipError_t e = hipMalloc((void**)&p, (size_t)cap * kDim * 2);
+  hipError_t e = try_malloc((void**)&p, (size_t)cap * kDim * 2);
   if (e != hipSuccess) return fail(PROQA_ENOMEM, "hipMalloc of %lld index rows failed: %s", (long long)cap,
                                    hipGetErrorString(e));
   if (idx->n > 0) PROQA_HIP(hipMemcpy(p, idx->xb, (size_t)idx->n * kDim * 2, hipMemcpyDeviceToDevice));
@@ -188,7 +196,7 @@ int ensure_stage(proqa_index* idx, size_t bytes) {
     if (idx->stage_dev) PROQA_HIP(hipFree(idx->stage_dev));
     idx->stage_dev = nullptr;
     idx->stage_bytes = 0;
-    hipError_t e = hipMalloc(&idx->stage_dev, bytes);
+    hipError_t e = try_malloc(&idx->stage_dev, bytes);
     if (e != hipSuccess) return fail(PROQA_ENOMEM, "hipMalloc staging %zu B: %s", bytes, hipGetErrorString(e));
     idx->stage_bytes = bytes;
   }
@@ -203,9 +211,9 @@ void free_store(proqa_index* idx) {
   idx->lane_cnt = nullptr;
   idx->spill_log = nullptr;
   idx->spill_cnt = nullptr;
-  idx->store_chunks = 0;
-  idx->store_qtiles = 0;
-  idx->store_lane_cap = 0;
+  idx->store_records = 0;
+  idx->store_lists = 0;
+  idx->store_slots = 0;
 }
 
 void free_workspace(proqa_index* idx) {
@@ -247,35 +255,37 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
   PROQA_HIP(hipMalloc((void**)&idx->margin, (size_t)q * sizeof(float)));
   PROQA_HIP(hipMalloc((void**)&idx->tau_filter, (size_t)q * sizeof(float)));
   PROQA_HIP(hipMalloc((void**)&idx->ub_filter, (size_t)q * sizeof(float)));
-  if (idx->stat_host) PROQA_HIP(hipHostFree(idx->stat_host));
-  idx->stat_host = nullptr;
-  PROQA_HIP(hipHostMalloc((void**)&idx->stat_host, (size_t)q * sizeof(unsigned long long), hipHostMallocDefault));
   idx->ws_nq_pad = q;
   idx->ws_k = kk;
   return PROQA_OK;
 }
 
-// candidate store for launches of up to `chunks` corpus chunks x `n_qtiles` query tiles
+// Candidate store for a launch of `chunks` corpus chunks x `n_qtiles` query tiles of `nq_pad` padded queries with
+// `lane_cap` records per lane list.  The lists are addressed with the LAUNCH's own query count (CandidateStore::nq_pad),
+// so the store is sized by what a launch needs, not by the largest batch the handle ever saw: it only grows, by record /
+// list / slot counts.
 int ensure_store(proqa_index* idx, unsigned chunks, unsigned n_qtiles, int64_t nq_pad, unsigned lane_cap) {
-  // (a launch with fewer query tiles than the store was sized for fits: the spill slots are addressed with the launch's
-  // own tile count, the lane lists with the workspace's padded query count)
-  if (chunks <= idx->store_chunks && n_qtiles <= idx->store_qtiles && lane_cap <= idx->store_lane_cap) return PROQA_OK;
-  const unsigned c = std::max(chunks, idx->store_chunks);
-  lane_cap = std::max(lane_cap, idx->store_lane_cap);
-  n_qtiles = std::max(n_qtiles, idx->store_qtiles);
+  const size_t lists = (size_t)chunks * nq_pad * 2;
+  const size_t records = lists * lane_cap;
+  const size_t slots = (size_t)chunks * n_qtiles * kFilterWaves;
+  if (records <= idx->store_records && lists <= idx->store_lists && slots <= idx->store_slots) return PROQA_OK;
+  const size_t want_records = std::max(records, idx->store_records), want_lists = std::max(lists, idx->store_lists),
+               want_slots = std::max(slots, idx->store_slots);
   free_store(idx);
-  const size_t lists = (size_t)c * nq_pad * 2;
-  const size_t slots = (size_t)c * n_qtiles * kFilterWaves;
-  hipError_t e = hipMalloc((void**)&idx->lane_log, lists * lane_cap * sizeof(WaveRecord));
+  // developer/test switch, read on this (rare) growth path only: a store above the limit fails the way a full GPU fails
+  // it -- by a hipMalloc that really fails (1 EiB), so that HIP's sticky error state is the real one
+  const char* lim = getenv("PROQA_DEBUG_STORE_LIMIT_MB");
+  const bool refuse = lim && want_records * sizeof(WaveRecord) > ((size_t)atoll(lim) << 20);
+  hipError_t e = try_malloc((void**)&idx->lane_log, refuse ? (size_t)1 << 60 : want_records * sizeof(WaveRecord));
   if (e != hipSuccess)
     return fail(PROQA_ENOMEM, "search: candidate store of %zu lists x %u records: %s (fewer queries per call need less)", lists,
                 lane_cap, hipGetErrorString(e));
-  idx->store_lane_cap = lane_cap;
-  PROQA_HIP(hipMalloc((void**)&idx->lane_cnt, lists * sizeof(unsigned)));
-  PROQA_HIP(hipMalloc((void**)&idx->spill_log, slots * kSpillCap * sizeof(WaveRecord)));
-  PROQA_HIP(hipMalloc((void**)&idx->spill_cnt, slots * sizeof(unsigned)));
-  idx->store_chunks = c;
-  idx->store_qtiles = n_qtiles;
+  idx->store_records = want_records;
+  PROQA_HIP(hipMalloc((void**)&idx->lane_cnt, want_lists * sizeof(unsigned)));
+  idx->store_lists = want_lists;
+  PROQA_HIP(hipMalloc((void**)&idx->spill_log, want_slots * kSpillCap * sizeof(WaveRecord)));
+  PROQA_HIP(hipMalloc((void**)&idx->spill_cnt, want_slots * sizeof(unsigned)));
+  idx->store_slots = want_slots;
   return PROQA_OK;
 }
 
@@ -359,9 +369,8 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
               bool inclusive, bool dense, bool bounded, unsigned* overflow_word, hipStream_t st, hipEvent_t f0,
               hipEvent_t f1, const RoundShape& shape = RoundShape()) {
   const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense, k, shape.want_chunks);
-  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad,
-                            shape.lane_cap ? shape.lane_cap : lane_capacity(k)))
-    return rc;
+  const unsigned lane_cap = shape.lane_cap ? shape.lane_cap : lane_capacity(k);
+  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, lane_cap)) return rc;
   FilterArgs fa;
   fa.xq = idx->xq_pad;
   fa.xb = idx->xb;
@@ -371,7 +380,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   // exact-float32 mode: the fp16 filter tests against thresholds moved by the error margin
   fa.tau = idx->exact ? idx->tau_filter : idx->tau;
   fa.ub = bounded ? (idx->exact ? idx->ub_filter : idx->ub) : nullptr;
-  fa.store = store_of(idx, (unsigned)idx->ws_nq_pad, n_qtiles, idx->store_lane_cap);
+  fa.store = store_of(idx, nq_pad, n_qtiles, lane_cap);
   fa.overflow = overflow_word;
   fa.flags = kFilterFlags;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
@@ -427,9 +436,17 @@ struct PageOut {
   int out_offset;  // first result slot of this page
 };
 
-int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
-                const PageOut& out, hipStream_t st, int* fallback_out, bool use_bootstrap, bool* bootstrap_overflow) {
-  PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
+// page_enqueue puts the whole page on the stream -- bootstrap, rounds, the (optimistic) result, the copies of the overflow
+// words -- and does not wait; page_complete runs after the stream has been synchronised: it re-scans what overflowed.
+// `status_dev` (optional device word): 1 if page_complete is going to rewrite the result, else 0.
+struct PagePlan {
+  std::vector<Slab> slabs;
+  long long boot = 0;
+};
+
+int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
+                 const PageOut& out, hipStream_t st, bool use_bootstrap, PagePlan* plan, uint32_t* status_dev) {
+  // (the round words idx->overflow were zeroed by the prep_queries launch that precedes every page)
   // Bootstrap: exact top-k of the first rows in two launches instead of the first three or four (dense) rounds.
   // Not for pages after the first (bounded), exact-float32 mode (its scores are re-computed from float32 rows),
   // k beyond the select kernel's bound, or an index too small to need it.
@@ -441,7 +458,9 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
   // (big pages: as many rows as the merge holds -- their growth per round is small, so the rounds should start high)
   const int first_cap = (sort_capacity(page_k) - page_k) / kStageRows * kStageRows;
   const int first = page_k > kPageK ? first_cap : std::min<int>(idx->first_slab_rows, first_cap);
-  std::vector<Slab> slabs = plan_slabs(idx->n, first, growth_for(page_k, idx->growth, qw), boot);
+  plan->slabs = plan_slabs(idx->n, first, growth_for(page_k, idx->growth, qw), boot);
+  plan->boot = boot;
+  const std::vector<Slab>& slabs = plan->slabs;
   if ((int)slabs.size() + 2 > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
   if (boot)
     if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, page_k, st)) return rc;
@@ -456,24 +475,29 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
       return rc;
     if (kDebugCand) {
       (void)hipStreamSynchronize(st);
-      (void)hipMemcpy(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      std::vector<unsigned long long> per_query((size_t)nq);
+      (void)hipMemcpy(per_query.data(), idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
       unsigned long long c = 0;
-      for (int64_t i = 0; i < nq; ++i) c += idx->stat_host[i];
+      for (int64_t i = 0; i < nq; ++i) c += per_query[i];
       fprintf(stderr, "after round %zu: cumulative candidates %llu\n", r, c);
     }
   }
   // results are written optimistically before the one host sync of the page; they are rewritten
-  // below only if a round overflowed and had to be re-scanned
+  // by page_complete only if a round overflowed and had to be re-scanned
+  // (the finalize kernel also writes the overflow words and the candidate count into the pinned mirror and the status
+  // word: no copy command between the search and what the caller enqueues behind it)
   PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, out.idx_offset, out.D, out.I, out.out_stride,
-                            out.out_offset, st));
-  PROQA_HIP(hipMemcpyAsync(idx->overflow_host, idx->overflow, kMaxRounds * sizeof(unsigned),
-                           hipMemcpyDeviceToHost, st));
-  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, st));
+                            out.out_offset, idx->overflow, status_dev, idx->mirror, idx->stat_dev, st));
   PROQA_HIP(hipEventRecord(idx->ev[1], st));
-  PROQA_HIP(hipStreamSynchronize(st));
+  return PROQA_OK;
+}
 
-  if (boot && idx->overflow_host[kMaxRounds - 2]) {   // adversarial order: the caller repeats the page without it
+// the stream has been synchronised since page_enqueue
+int page_complete(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
+                  const PageOut& out, hipStream_t st, const PagePlan& plan, int* fallback_out, bool* bootstrap_overflow) {
+  const std::vector<Slab>& slabs = plan.slabs;
+  const bool prof = idx->profile && !bounded;
+  if (plan.boot && idx->mirror->overflow[kMaxRounds - 2]) {   // adversarial order: the caller repeats the page without it
     *bootstrap_overflow = true;
     return PROQA_OK;
   }
@@ -488,7 +512,7 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
   const long long leaf_rows = (long long)((sort_capacity(page_k) - page_k) / kStageRows) * kStageRows;
   unsigned* word = idx->overflow + kMaxRounds - 1;
   for (size_t r = 0; r < slabs.size(); ++r) {
-    if (!idx->overflow_host[r]) continue;
+    if (!idx->mirror->overflow[r]) continue;
     std::vector<Slab> todo;
     auto push_quarters = [&](const Slab& sl) {   // pushed in reverse: the stack pops them in row order
       const long long q = round_up<long long>(ceil_div<long long>(sl.r1 - sl.r0, 4), kStageRows);
@@ -507,16 +531,14 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
         return rc;
       ++*fallback_out;
       if (leaf) continue;
-      PROQA_HIP(hipMemcpyAsync(idx->overflow_host + kMaxRounds - 1, word, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      PROQA_HIP(hipMemcpyAsync(&idx->mirror->overflow[kMaxRounds - 1], word, sizeof(unsigned), hipMemcpyDeviceToHost, st));
       PROQA_HIP(hipStreamSynchronize(st));
-      if (idx->overflow_host[kMaxRounds - 1]) push_quarters(sub);
+      if (idx->mirror->overflow[kMaxRounds - 1]) push_quarters(sub);
     }
   }
   if (*fallback_out != fallback_before) {
     PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, out.idx_offset, out.D, out.I, out.out_stride,
-                              out.out_offset, st));
-    PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long),
-                             hipMemcpyDeviceToHost, st));
+                              out.out_offset, idx->overflow, nullptr, idx->mirror, idx->stat_dev, st));
     PROQA_HIP(hipEventRecord(idx->ev[1], st));
     PROQA_HIP(hipStreamSynchronize(st));
   }
@@ -540,6 +562,14 @@ int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t
     }
   }
   return PROQA_OK;
+}
+
+int search_page(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
+                const PageOut& out, hipStream_t st, int* fallback_out, bool use_bootstrap, bool* bootstrap_overflow) {
+  PagePlan plan;
+  if (int rc = page_enqueue(idx, qw, n_qtiles, nq, nq_pad, page_k, bounded, out, st, use_bootstrap, &plan, nullptr)) return rc;
+  PROQA_HIP(hipStreamSynchronize(st));
+  return page_complete(idx, qw, n_qtiles, nq, nq_pad, page_k, bounded, out, st, plan, fallback_out, bootstrap_overflow);
 }
 
 // ---- large k in one pass -----------------------------------------------------------------------------------------
@@ -613,11 +643,10 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   // the big launch's store first, so that the sample rounds do not allocate a small one that is thrown away
   {
     const LaunchGeom g = geometry(idx->n, n_qtiles, false, k, shape.want_chunks);
-    if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, idx->ws_nq_pad, shape.lane_cap))
+    if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, shape.lane_cap))
       return rc == PROQA_ENOMEM ? PROQA_OK : rc;   // no room for the deep lists beside the caller's tensors: page by page
   }
-  PROQA_HIP(hipMemsetAsync(idx->overflow, 0, kMaxRounds * sizeof(unsigned), st));
-  // (1) thresholds from the sample.  Overflow in here is harmless: it loosens the estimate.
+  // (1) thresholds from the sample (the round words were zeroed by prep_queries).  Overflow in here is harmless: it loosens the estimate.
   const int r = pl.r;
   long long boot = 0;
   if (idx->bootstrap_rows > 0 && r <= kBootstrapMaxK && r <= idx->bootstrap_rows / 4 && pl.n_sample >= 4ll * idx->bootstrap_rows)
@@ -663,24 +692,32 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
     return rc;
   PROQA_HIP(launch_flag_short_lists(idx->run_n, nq, (unsigned)k, word + 1, st));
   // (3) results, optimistically, before the one host sync
-  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, out.idx_offset, out.D, out.I, out.out_stride, 0, st));
-  PROQA_HIP(hipMemcpyAsync(idx->overflow_host, idx->overflow, kMaxRounds * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  PROQA_HIP(hipMemcpyAsync(idx->stat_host, idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, out.idx_offset, out.D, out.I, out.out_stride, 0, idx->overflow, nullptr,
+                            idx->mirror, idx->stat_dev, st));
   PROQA_HIP(hipEventRecord(idx->ev[1], st));
   PROQA_HIP(hipStreamSynchronize(st));
   idx->stats.rounds += (int)slabs.size() + 1;
-  *done = !idx->overflow_host[1] && !idx->overflow_host[2];
+  *done = !idx->mirror->overflow[1] && !idx->mirror->overflow[2];
   return PROQA_OK;
 }
 
+int finish_pending(proqa_index* idx, int* rewritten);
+
+// `defer`: a search of the one-page kind is only ENQUEUED (idx->pending describes it; finish_pending completes it);
+// every other kind runs to completion here.  `status_dev` (optional device word, written on the stream): 1 if the
+// completion will rewrite the result, else 0.
 int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
-                  float* D_dev, int64_t* I_dev, hipStream_t st) {
+                  float* D_dev, int64_t* I_dev, hipStream_t st, bool defer = false, uint32_t* status_dev = nullptr) {
+  if (idx->pending.active)   // a begun search nobody finished (an error path of the caller): complete it, drop its result
+    if (int rc = finish_pending(idx, nullptr)) return rc;
   if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
   if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "search: bad dtype %d", dtype);
   if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
   idx->stats = {};
   if (nq == 0) return PROQA_OK;
-  if (int rc = ensure_device(idx)) return rc;
+  PROQA_ON_DEVICE(idx->device);
+  // (every path but the deferred one ends with a final result: the status word is cleared up front on the stream)
+  if (status_dev) PROQA_HIP(hipMemsetAsync(status_dev, 0, sizeof(uint32_t), st));
 
   // wave tile: 2 query blocks of 32 per wave (512 queries per workgroup) unless the batch is small
   const int qw = nq > 256 ? kWideQw : 1;
@@ -720,7 +757,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
     const bool check_q = dtype == PROQA_F32;
     if (check_q) PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), st));
     PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
-                                  nullptr, true, check_q ? idx->inexact : nullptr, st));
+                                  nullptr, true, check_q ? idx->inexact : nullptr, idx->overflow, st));
     if (check_q) {
       unsigned bad = 0;
       if (int rc = read_inexact(idx, "index_search (queries)", st, &bad)) return rc;
@@ -738,7 +775,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
                                    st, &done))
         return rc;
     if (done) {
-      for (int64_t i = 0; i < nq; ++i) idx->stats.candidates += (int64_t)idx->stat_host[i];
+      idx->stats.candidates += (int64_t)idx->mirror->candidates;
       (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
       return PROQA_OK;
     }
@@ -747,6 +784,33 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   // k <= kPageK: one page.  Larger k that did not go (or get) through the one-pass search is served page by
   // page: page p re-runs the search restricted to keys strictly below the last key of page p-1.
   const int n_pages = ceil_div<int>(k, page_size);
+  if (defer && n_pages == 1 && !fallback) {
+    // the common search (k <= kPageK): everything goes on the stream, nothing is waited for
+    if (int rc = prep_first()) return rc;
+    if (idx->exact)
+      PROQA_HIP(launch_query_margins(xq_dev, dtype, nq, idx->ws_nq_pad, idx->norm_stats, idx->xq32, idx->margin,
+                                     idx->tau, idx->tau_filter, st));
+    PagePlan plan;
+    if (int rc = page_enqueue(idx, qw, n_qtiles, nq, nq_pad, k, false, PageOut{D_dev, (long long*)I_dev, idx_offset, k, 0}, st, true,
+                              &plan, status_dev))
+      return rc;
+    proqa_index::Pending& pe = idx->pending;
+    pe.active = true;
+    pe.qw = qw;
+    pe.n_qtiles = n_qtiles;
+    pe.nq = nq;
+    pe.nq_pad = nq_pad;
+    pe.k = k;
+    pe.dtype = dtype;
+    pe.xq_dev = xq_dev;
+    pe.D = D_dev;
+    pe.I = (long long*)I_dev;
+    pe.idx_offset = idx_offset;
+    pe.st = st;
+    pe.slabs.swap(plan.slabs);
+    pe.boot = plan.boot;
+    return PROQA_OK;
+  }
   if (n_pages > 1) PROQA_HIP(hipMemsetAsync(idx->done, 0, (size_t)idx->ws_nq_pad, st));
   for (int p = 0; p < n_pages; ++p) {
     const int page_k = std::min(page_size, k - p * page_size);
@@ -754,7 +818,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
       if (int rc = prep_first()) return rc;
     } else {
       PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
-                                    idx->done, false, nullptr, st));
+                                    idx->done, false, nullptr, idx->overflow, st));
     }
     if (idx->exact)
       PROQA_HIP(launch_query_margins(xq_dev, dtype, nq, idx->ws_nq_pad, idx->norm_stats, idx->xq32, idx->margin,
@@ -765,7 +829,7 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
     if (boot_overflow) {
       // the per-query state is rebuilt from scratch (p == 0 here: later pages never bootstrap)
       PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
-                                    nullptr, true, nullptr, st));
+                                    nullptr, true, nullptr, idx->overflow, st));
       ++fallback;
       if (int rc = search_page(idx, qw, n_qtiles, nq, nq_pad, page_k, false, out, st, &fallback, false, &boot_overflow))
         return rc;
@@ -777,8 +841,38 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   if (n_pages > 1) PROQA_HIP(hipStreamSynchronize(st));  // the last advance_page
 
   idx->stats.fallback_rounds = fallback;
-  for (int64_t i = 0; i < nq; ++i) idx->stats.candidates += (int64_t)idx->stat_host[i];
+  idx->stats.candidates += (int64_t)idx->mirror->candidates;
   (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
+  return PROQA_OK;
+}
+
+// host-side completion of a deferred search: wait for the stream, re-scan what overflowed (rewriting D / I)
+int finish_pending(proqa_index* idx, int* rewritten) {
+  proqa_index::Pending& pe = idx->pending;
+  if (rewritten) *rewritten = 0;
+  if (!pe.active) return PROQA_OK;
+  pe.active = false;
+  PROQA_ON_DEVICE(idx->device);
+  PROQA_HIP(hipStreamSynchronize(pe.st));
+  PagePlan plan;
+  plan.slabs.swap(pe.slabs);
+  plan.boot = pe.boot;
+  const PageOut out{pe.D, pe.I, pe.idx_offset, pe.k, 0};
+  int fallback = 0;
+  bool boot_overflow = false;
+  if (int rc = page_complete(idx, pe.qw, pe.n_qtiles, pe.nq, pe.nq_pad, pe.k, false, out, pe.st, plan, &fallback, &boot_overflow))
+    return rc;
+  if (boot_overflow) {
+    PROQA_HIP(launch_prep_queries(pe.xq_dev, pe.dtype, pe.nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
+                                  nullptr, true, nullptr, idx->overflow, pe.st));
+    ++fallback;
+    if (int rc = search_page(idx, pe.qw, pe.n_qtiles, pe.nq, pe.nq_pad, pe.k, false, out, pe.st, &fallback, false, &boot_overflow))
+      return rc;
+  }
+  idx->stats.fallback_rounds = fallback;
+  idx->stats.candidates += (int64_t)idx->mirror->candidates;
+  (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
+  if (rewritten) *rewritten = fallback != 0;
   return PROQA_OK;
 }
 
@@ -788,6 +882,17 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
 using namespace proqa;
 
 extern "C" {
+
+int proqa_index_search_begin_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
+                                    float* D_dev, int64_t* I_dev, uint32_t* status_dev, void* stream) {
+  if (!idx || (nq > 0 && (!xq_dev || !D_dev || !I_dev))) return fail(PROQA_EINVAL, "index_search_begin_device: NULL argument");
+  return search_device(idx, xq_dev, nq, dtype, k, idx_offset, D_dev, I_dev, as_stream(stream), true, status_dev);
+}
+
+int proqa_index_search_finish(proqa_index* idx, int* rewritten) {
+  if (!idx) return fail(PROQA_EINVAL, "index_search_finish: NULL handle");
+  return finish_pending(idx, rewritten);
+}
 
 int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out) {
   if (!out) return fail(PROQA_EINVAL, "index_create: out is NULL");
@@ -802,7 +907,8 @@ int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out) {
   for (auto& e : idx->ev) PROQA_HIP(hipEventCreate(&e));
   PROQA_HIP(hipMalloc((void**)&idx->overflow, kMaxRounds * sizeof(unsigned)));
   PROQA_HIP(hipMalloc((void**)&idx->inexact, 2 * sizeof(unsigned)));
-  PROQA_HIP(hipHostMalloc((void**)&idx->overflow_host, kMaxRounds * sizeof(unsigned), hipHostMallocDefault));
+  PROQA_HIP(hipHostMalloc((void**)&idx->mirror, sizeof(SearchMirror), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(idx->mirror, 0, sizeof(SearchMirror));
   if (capacity_rows > 0) {
     if (int rc = reserve_rows(idx, capacity_rows)) {
       proqa_index_free(idx);
@@ -815,14 +921,14 @@ int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out) {
 
 int proqa_index_free(proqa_index* idx) {
   if (!idx) return PROQA_OK;
+  if (idx->pending.active) (void)hipStreamSynchronize(idx->pending.st);   // a begun search nobody finished
   free_workspace(idx);
   if (idx->xb && idx->owns_xb) (void)hipFree(idx->xb);
   if (idx->overflow) (void)hipFree(idx->overflow);
   if (idx->inexact) (void)hipFree(idx->inexact);
   if (idx->xb32) (void)hipFree(idx->xb32);
   if (idx->norm_stats) (void)hipFree(idx->norm_stats);
-  if (idx->overflow_host) (void)hipHostFree(idx->overflow_host);
-  if (idx->stat_host) (void)hipHostFree(idx->stat_host);
+  if (idx->mirror) (void)hipHostFree(idx->mirror);
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
   if (idx->boot_scores) (void)hipFree(idx->boot_scores);
   if (idx->stage_pinned) (void)hipHostFree(idx->stage_pinned);
@@ -901,7 +1007,7 @@ int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int 
   if (!idx || (!xb_dev && n > 0) || n < 0) return fail(PROQA_EINVAL, "index_add_device: bad argument");
   if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_add_device: bad dtype %d", dtype);
   if (n == 0) return PROQA_OK;
-  if (int rc = ensure_device(idx)) return rc;
+  PROQA_ON_DEVICE(idx->device);
   if (int rc = reserve_rows(idx, idx->n + n)) return rc;
   hipStream_t st = as_stream(stream);
   char* dst = idx->xb + (size_t)idx->n * kDim * 2;
@@ -937,7 +1043,7 @@ int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype) {
   if (!idx || (!xb && n > 0) || n < 0) return fail(PROQA_EINVAL, "index_add: bad argument");
   if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_add: bad dtype %d", dtype);
   if (n == 0) return PROQA_OK;
-  if (int rc = ensure_device(idx)) return rc;
+  PROQA_ON_DEVICE(idx->device);
   if (int rc = reserve_rows(idx, idx->n + n)) return rc;
   const size_t esz = dtype == PROQA_F16 ? 2 : 4;
   // upload in bounded pieces (the source may be an mmap of a multi-GB .npy)
@@ -982,7 +1088,7 @@ int proqa_index_search(proqa_index* idx, const void* xq, int64_t nq, int dtype, 
   if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_search: bad dtype %d", dtype);
   if (nq == 0) return PROQA_OK;
   if (k <= 0) return fail(PROQA_EINVAL, "index_search: k=%d", k);
-  if (int rc = ensure_device(idx)) return rc;
+  PROQA_ON_DEVICE(idx->device);
   // host buffers cross through one pinned staging area on the index's own stream: queries up, the search, results
   // down, ONE synchronisation (pageable hipMemcpy calls on the null stream would each stage and synchronise)
   const size_t esz = dtype == PROQA_F16 ? 2 : 4;
@@ -1019,7 +1125,7 @@ int proqa_index_reconstruct_batch_device(proqa_index* idx, const int64_t* ids_de
   if (!idx) return fail(PROQA_EINVAL, "index_reconstruct_batch: idx is NULL");
   if (n < 0 || (n > 0 && (!ids_dev || !out_dev))) return fail(PROQA_EINVAL, "index_reconstruct_batch: n=%lld or NULL argument", (long long)n);
   if (out_dtype != PROQA_F16 && out_dtype != PROQA_F32) return fail(PROQA_EINVAL, "index_reconstruct_batch: bad dtype %d", out_dtype);
-  if (int rc = ensure_device(idx)) return rc;
+  PROQA_ON_DEVICE(idx->device);
   PROQA_HIP(launch_gather_index_rows(idx->xb, idx->exact ? idx->xb32 : nullptr, idx->n, (const long long*)ids_dev, n, idx_offset,
                                      out_dev, out_dtype == PROQA_F32, (hipStream_t)stream));
   return PROQA_OK;

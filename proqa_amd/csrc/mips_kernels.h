@@ -117,16 +117,29 @@ hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned
 hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,
                             unsigned long long* run_keys, unsigned* run_n, float* tau, unsigned long long* stat,
                             unsigned* overflow, hipStream_t st);
+// overflow (optional): the kOverflowWords round words of the page that follows are zeroed
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                               bool reset_stat, unsigned* inexact, hipStream_t st);
-// writes page results: D/I[q * out_stride + out_offset + j], j < page_k
+                               bool reset_stat, unsigned* inexact, unsigned* overflow, hipStream_t st);
+// What a search's one host synchronisation reads, written by the finalize kernel straight into pinned host memory (no
+// copy command on the stream): the overflow words of the rounds and the candidates summed over the queries.
+constexpr int kOverflowWords = 96;   // = kMaxRounds of mips_index.cpp
+struct SearchMirror {
+  unsigned overflow[kOverflowWords];
+  unsigned long long candidates;
+};
+// writes page results: D/I[q * out_stride + out_offset + j], j < page_k.  overflow: the kOverflowWords round words (device);
+// status (optional device word) = 1 if any is set, else 0; mirror (optional, pinned host memory) receives the words and the
+// sum of stat[0, nq)
 hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                            long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
+                           const unsigned* overflow, unsigned* status, SearchMirror* mirror, const unsigned long long* stat,
                            hipStream_t st);
-// part p's [nq, k] scores / ids start stride_d / stride_i ELEMENTS after part p-1's (nq*k for dense [n_parts, nq, k] arrays)
+// part p's [nq, k] scores / ids start stride_d / stride_i ELEMENTS after part p-1's (nq*k for dense [n_parts, nq, k] arrays);
+// status_host (optional, pinned host memory, n_parts words) receives status_src[p * status_stride] of every part
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
-                              int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st);
+                              int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st,
+                              const unsigned* status_src = nullptr, long long status_stride = 0, unsigned* status_host = nullptr);
 hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, unsigned* inexact, hipStream_t st);
 // exact-float32 mode helpers
 hipError_t launch_upconvert_f16_to_f32(const void* src, float* dst, long long n, hipStream_t st);

@@ -976,8 +976,9 @@ __global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* _
 // pad + convert queries to the fp16 [Qpad,128] operand layout, reset per-query state
 __global__ void prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, _Float16* xq_pad,
                              float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                             int reset_stat, unsigned* inexact, int debug_nohit) {
+                             int reset_stat, unsigned* inexact, int debug_nohit, unsigned* overflow) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (overflow && i < kOverflowWords) overflow[i] = 0u;   // the round words of the page that follows (no memset command)
   const long long n = nq_pad * kDim;
   if (i < n) {
     const long long q = i / kDim;
@@ -1000,8 +1001,38 @@ __global__ void prep_queries(const void* xq, int dtype, long long nq, long long 
   }
 }
 
-__global__ void finalize_topk(const unsigned long long* run_keys, const unsigned* run_n, long long nq,
-                              int k, long long idx_offset, float* D, long long* I, int out_stride, int out_offset) {
+// Block 0 also reports to the host what the search's one synchronisation needs, so that no copy command sits on the
+// stream between the search and whatever is enqueued behind it: `mirror` (pinned, device-visible host memory, or NULL)
+// receives the overflow words of the rounds and the candidate count summed over the queries; `status` (optional device
+// word) = 1 if any overflow word is set -- the host is then going to re-scan and rewrite this result (a deferred search
+// hands the word to whoever consumes the result on the stream) -- else 0.
+__global__ __launch_bounds__(256) void finalize_topk(const unsigned long long* run_keys, const unsigned* run_n, long long nq,
+                                                     int k, long long idx_offset, float* D, long long* I, int out_stride,
+                                                     int out_offset, const unsigned* overflow, unsigned* status,
+                                                     SearchMirror* mirror, const unsigned long long* stat) {
+  if (blockIdx.x == 0 && (status || mirror)) {
+    __shared__ unsigned long long s_part[4];
+    bool any = false;
+    for (int w = threadIdx.x; w < kOverflowWords; w += 256) {
+      const unsigned v = overflow[w];
+      if (mirror) mirror->overflow[w] = v;
+      any = any || v != 0u;
+    }
+    const int any_all = __syncthreads_or(any ? 1 : 0);
+    if (threadIdx.x == 0 && status) *status = any_all ? 1u : 0u;
+    if (mirror) {
+      unsigned long long c = 0;
+      for (long long i = threadIdx.x; i < nq; i += 256) c += stat[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+      if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        mirror->candidates = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __threadfence_system();
+      }
+    }
+  }
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq * k) return;
   const long long q = i / k;
@@ -1184,11 +1215,17 @@ template <int NK>
 __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __restrict__ D_parts,
                                                             const long long* __restrict__ I_parts,
                                                             int n_parts, long long nq, int k, long long stride_d, long long stride_i,
-                                                            float* __restrict__ D, long long* __restrict__ I) {
+                                                            float* __restrict__ D, long long* __restrict__ I,
+                                                            const unsigned* __restrict__ status_src, long long status_stride,
+                                                            unsigned* __restrict__ status_host) {
   // part p's [nq, k] scores / ids start stride_d / stride_i elements after part p-1's (nq*k for dense arrays)
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // max(256, pow2 >= n_parts*k) keys
   const long long q = blockIdx.x;
   const int tid = threadIdx.x;
+  if (status_host && q == 0) {   // sharded search: every part's status word, straight into pinned host memory
+    for (int p = tid; p < n_parts; p += kMergeThreads) status_host[p] = status_src[(size_t)p * status_stride];
+    __threadfence_system();
+  }
   const unsigned total = (unsigned)n_parts * (unsigned)k;
   for (unsigned i = tid; i < total; i += kMergeThreads) {
     const unsigned p = i / k, j = i - p * k;
@@ -1213,6 +1250,11 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __rest
       I[q * k + j] = -1;
     }
   }
+}
+
+__global__ void copy_status_words(const unsigned* __restrict__ src, long long stride, int n, unsigned* __restrict__ host) {
+  for (int p = threadIdx.x; p < n; p += blockDim.x) host[p] = src[(size_t)p * stride];
+  __threadfence_system();
 }
 
 // Large merges (n_parts*k keys do not fit one workgroup's LDS, e.g. k = 10000 x 8 shards for
@@ -1384,26 +1426,28 @@ static const bool kDebugNoHit = getenv("PROQA_DEBUG_NOHIT") != nullptr;
 
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                               bool reset_stat, unsigned* inexact, hipStream_t st) {
+                               bool reset_stat, unsigned* inexact, unsigned* overflow, hipStream_t st) {
   const long long n = nq_pad * kDim;
   hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
                      (_Float16*)xq_pad, tau, run_n, stat, done, reset_stat ? 1 : 0, inexact,
-                     kDebugNoHit ? 1 : 0);
+                     kDebugNoHit ? 1 : 0, overflow);
   return hipGetLastError();
 }
 
 hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                            long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
+                           const unsigned* overflow, unsigned* status, SearchMirror* mirror, const unsigned long long* stat,
                            hipStream_t st) {
   const long long n = nq * page_k;
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(finalize_topk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, run_keys, run_n,
-                     nq, page_k, idx_offset, D, I, out_stride, out_offset);
+                     nq, page_k, idx_offset, D, I, out_stride, out_offset, overflow, status, mirror, stat);
   return hipGetLastError();
 }
 
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
-                              int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st) {
+                              int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st,
+                              const unsigned* status_src, long long status_stride, unsigned* status_host) {
   if (nq == 0) return hipSuccess;
   const long long per_q = (long long)n_parts * k;
   if (per_q <= kMaxMergeListKeys) {
@@ -1417,7 +1461,7 @@ hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, in
       e = hipFuncSetAttribute((const void*)merge_lists<NK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
     if (e == hipSuccess)                                                                                            \
       hipLaunchKernelGGL(merge_lists<NK>, dim3((unsigned)nq), dim3(kMergeThreads), lds, st, D_parts, I_parts,       \
-                         n_parts, nq, k, stride_d, stride_i, D, I);                                                       \
+                         n_parts, nq, k, stride_d, stride_i, D, I, status_src, status_stride, status_host);               \
     break;
     switch (P / kMergeThreads) {
       PROQA_MERGE_CASE(1)
@@ -1433,6 +1477,8 @@ hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, in
     static_assert(kMaxMergeListKeys == 64 * kMergeThreads, "largest list merge");
     return e != hipSuccess ? e : hipGetLastError();
   }
+  if (status_host)
+    hipLaunchKernelGGL(copy_status_words, dim3(1), dim3(256), 0, st, status_src, status_stride, n_parts, status_host);
   // segmented radix sort in HBM, in query chunks of <= 2^27 keys (1 GiB per key buffer)
   const long long chunk_q = std::max<long long>(1, std::min<long long>(nq, (1ll << 27) / per_q));
   unsigned long long *keys_in = nullptr, *keys_out = nullptr;

@@ -330,36 +330,63 @@ class ShardedIndexFlatIP:
         return self._merge(D_all, I_all)
 
     def _search_in_place(self, xq, k):
-        """The RCCL exchange without staging copies: the local search writes its ids and scores straight into this
-        rank's block [ids | scores | pad to 16 B] of the send buffer, ONE all_gather_into_tensor, and the strided merge
-        (proqa_topk_merge_strided_device) reads the receive buffer where it lies."""
+        """The RCCL exchange without staging copies and without a host round trip in the middle: the local search is
+        only ENQUEUED (proqa_index_search_begin_device) and writes its ids and scores straight into this rank's block
+        [ids | scores | status word, 16 B] of the send buffer; ONE all_gather_into_tensor and the strided merge
+        (proqa_topk_merge_strided_device), which reads the receive buffer where it lies, go onto the stream right behind
+        it; the host waits once, at the end (proqa_index_search_finish).  The status words of all ranks come back with
+        the blocks: a rank whose candidate lists overflowed (status 1) rewrites its list in _finish and every rank runs
+        the exchange once more; a rank whose local search failed (status 0xFFFFFFFF) still enters the collective, and
+        every rank raises instead of waiting for it."""
         import torch
+        lib = _lib.load()
+        xq = xq.contiguous()
         nq = xq.shape[0]
-        n_i, n_d = nq * k * 8, nq * k * 4
-        block = (n_i + n_d + 15) // 16 * 16
-        # the local search ends with a host sync: whatever the host does after it is exposed, so the send / receive
-        # buffers are kept from call to call and the outputs are allocated before the search starts
+        sizes = [ctypes.c_size_t() for _ in range(3)]
+        _lib.check(lib.proqa_sharded_block_layout(nq, int(k), *[ctypes.byref(v) for v in sizes]))
+        n_i, n_d, block = (v.value for v in sizes)
+        # the send / receive buffers are kept from call to call
         key = (nq, int(k), xq.device)
         if getattr(self, "_xchg_key", None) != key:
             self._xchg_key = key
             self._xchg_mine = torch.empty(block, dtype=torch.uint8, device=xq.device)
             self._xchg_gathered = torch.empty((self.world_size, block), dtype=torch.uint8, device=xq.device)
-        mine, gathered = self._xchg_mine, self._xchg_gathered
-        I = mine[:n_i].view(torch.int64).view(nq, k)
-        D = mine[n_i:n_i + n_d].view(torch.float32).view(nq, k)
+            self._xchg_status = torch.empty(self.world_size, dtype=torch.int32).pin_memory()
+        mine, gathered, status_host = self._xchg_mine, self._xchg_gathered, self._xchg_status
+        status_dev = mine.data_ptr() + n_i + n_d
         D_out = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
         I_out = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
-        self._index.search_device(xq, k, idx_offset=self.lo, out=(D, I))
-        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        failure = None
         with torch.cuda.device(xq.device):
-            _lib.check(self._lib_handle().proqa_topk_merge_strided_device(
-                gathered.data_ptr() + n_i, gathered.data_ptr(), self.world_size, nq, int(k), block // 4, block // 8,
-                D_out.data_ptr(), I_out.data_ptr(), _lib.current_stream_ptr()))
-        return D_out, I_out
-
-    @staticmethod
-    def _lib_handle():
-        return _lib.load()
+            try:
+                _lib.check(lib.proqa_index_search_begin_device(self._index._h, xq.data_ptr(), nq, _torch_dtype_code(xq), int(k),
+                                                               int(self.lo), mine.data_ptr() + n_i, mine.data_ptr(), status_dev,
+                                                               _lib.current_stream_ptr()))
+            except Exception as e:       # still enter the collective: the other ranks are already on their way into it
+                failure = e
+            for _attempt in range(2):
+                if failure is not None:
+                    mine[n_i + n_d:n_i + n_d + 4] = 0xFF
+                self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+                # (the merge kernel drops every rank's status word into the pinned host buffer: no copy on the stream)
+                _lib.check(lib.proqa_topk_merge_gathered_device(gathered.data_ptr(), self.world_size, nq, int(k),
+                                                                status_host.data_ptr(), D_out.data_ptr(), I_out.data_ptr(),
+                                                                _lib.current_stream_ptr()))
+                if failure is None:
+                    try:
+                        _lib.check(lib.proqa_index_search_finish(self._index._h, None))
+                    except Exception as e:
+                        failure = e
+                torch.cuda.current_stream().synchronize()
+                status = status_host.tolist()
+                if -1 in status:
+                    raise failure if failure is not None else RuntimeError(
+                        f"sharded search: rank {status.index(-1)} failed in its local search")
+                if not any(status):
+                    return D_out, I_out
+                if failure is None:
+                    mine[n_i + n_d:n_i + n_d + 4] = 0
+        raise RuntimeError("sharded search: the ranks did not agree on a final result")
 
     def _search_cabi(self, xq, k):
         """proqa_sharded_search_device: local search, RCCL all-gather and merge inside the library."""

@@ -1,0 +1,47 @@
+"""bench.py the way the driver runs it at N > 1: `python bench.py --gpus N` with no launcher around it starts its own
+ranks (a child torch.distributed.run) and prints rank 0's one JSON line.  The test box has one GPU, so the two ranks
+share it and exchange over gloo (RCCL refuses two ranks per device); the kernels, the sharding and the merge are the
+real ones, and the merged result must be the single-rank result bit for bit."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(gpus, extra_env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--rows", "400000", "--queries", "64",
+           "--steps", "2", "--warmup", "1", "--skip-encode", "--skip-float32", "--skip-cpu", "--skip-extras"]
+    env = dict(os.environ, **(extra_env or {}))
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]            # exactly one line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks(gpu_device):
+    one = _run(1)
+    two = _run(2, {"PROQA_DIST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["world_size"] == 2 and two["config"]["backend"] == "gloo"
+    ranks = two["config"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and ranks[0]["pid"] != ranks[1]["pid"]
+    assert ranks[0]["rows"] == [0, 200000] and ranks[1]["rows"] == [200000, 400000]
+    assert "sharded_step" in two and two["sharded_step"]["rows_per_rank"] == 200000
+    assert two["scaling"] == "strong" and two["value"] > 0
+    # sharded == unsharded, bit for bit (ids and scores of all 64 x 80 results)
+    assert two["result"] == one["result"]
+
+
+def test_bench_refuses_a_launcher_of_another_size(gpu_device):
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "1000"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr

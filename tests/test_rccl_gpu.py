@@ -75,3 +75,91 @@ def test_cabi_sharded_search_without_torch_distributed(gpu_device):
         D2, I2 = index.search(torch.from_numpy(xq).cuda(), k)
         np.testing.assert_array_equal(I2.cpu().numpy(), np.where(Io >= 0, Io + n, Io))
         index.close()
+
+
+def _adversarial(n, nq):
+    """rows sorted by ascending score (with ties): every round's candidate lists overflow"""
+    xb = np.zeros((n, 128), np.float16)
+    xb[:, 0] = (np.arange(n) // 40).astype(np.float16)
+    xq = np.zeros((nq, 128), np.float16)
+    xq[:, 0] = 1
+    return xb, xq
+
+
+def test_cabi_exchange_is_repeated_after_an_overflow(gpu_device):
+    """The sharded search enqueues the all-gather and the merge behind a local search whose host check is still due.
+    Here that check finds overflowed rounds: the rank's status word (gathered with its block) says so, the local list
+    is rewritten by the overflow-safe re-scan and the exchange runs once more -- the result is the exact one."""
+    from oracle import search_oracle
+    from proqa_amd.index import ShardedIndexFlatIP
+    n, nq, k = 40000, 70, 80
+    xb, xq = _adversarial(n, nq)
+    index = ShardedIndexFlatIP(n, transport="cabi")
+    index.local_index.configure(first_slab_rows=128, growth=4)
+    index.add_local(xb)
+    D, I = index.search(torch.from_numpy(xq).cuda(), k)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do)
+    assert index.local_index.last_stats()["fallback_rounds"] > 0
+    # and a well-behaved search on the same handles afterwards
+    rng = np.random.default_rng(3)
+    xq2 = rng.integers(-4, 5, (33, 128)).astype(np.float16)
+    D2, I2 = index.search(torch.from_numpy(xq2).cuda(), k)
+    Do2, Io2 = search_oracle.topk_ip(xq2, xb, k)
+    np.testing.assert_array_equal(I2.cpu().numpy(), Io2)
+    index.close()
+
+
+def _nccl_overflow_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=1)
+    try:
+        from proqa_amd.index import ShardedIndexFlatIP
+        xb, xq = _adversarial(40000, 70)
+        index = ShardedIndexFlatIP(40000, transport="torch")
+        index.local_index.configure(first_slab_rows=128, growth=4)
+        index.add_local(xb)
+        D, I = index.search(torch.from_numpy(xq).cuda(), 80, force_collective=True)
+        np.save(os.path.join(out_dir, "D.npy"), D.cpu().numpy())
+        np.save(os.path.join(out_dir, "I.npy"), I.cpu().numpy())
+        np.save(os.path.join(out_dir, "fb.npy"), np.array([index.local_index.last_stats()["fallback_rounds"]]))
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_exchange_is_repeated_after_an_overflow(gpu_device, tmp_path):
+    from oracle import search_oracle
+    mp.spawn(_nccl_overflow_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    xb, xq = _adversarial(40000, 70)
+    Do, Io = search_oracle.topk_ip(xq, xb, 80)
+    np.testing.assert_array_equal(np.load(tmp_path / "I.npy"), Io)
+    np.testing.assert_array_equal(np.load(tmp_path / "D.npy"), Do)
+    assert np.load(tmp_path / "fb.npy")[0] > 0
+
+
+def test_a_failing_local_search_still_enters_the_collective(gpu_device):
+    """A rank whose local search fails poisons its status word and goes through the all-gather all the same: the call
+    returns the error (with more ranks: on every rank) instead of leaving the others waiting in the collective.  The
+    handles stay usable."""
+    import ctypes
+    from oracle import search_oracle
+    from proqa_amd import _lib
+    from proqa_amd.index import ShardedIndexFlatIP
+    xb, xq = _data(20000, 9)
+    index = ShardedIndexFlatIP(20000, transport="cabi")
+    index.add_local(xb)
+    xq_dev = torch.from_numpy(xq).cuda()
+    D = torch.empty((9, 80), dtype=torch.float32, device="cuda")
+    I = torch.empty((9, 80), dtype=torch.int64, device="cuda")
+    lib = _lib.load()
+    rc = lib.proqa_sharded_search_device(index.local_index._h, index._comm, xq_dev.data_ptr(), 9, 7, 80, 0,   # dtype 7
+                                         D.data_ptr(), I.data_ptr(), _lib.current_stream_ptr())
+    assert rc == -1 and b"dtype" in lib.proqa_last_error()
+    D2, I2 = index.search(xq_dev, 80)
+    Do, Io = search_oracle.topk_ip(xq, xb, 80)
+    np.testing.assert_array_equal(I2.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D2.cpu().numpy(), Do)
+    index.close()

@@ -737,3 +737,109 @@ def test_overflow_of_a_large_slab_costs_a_bounded_rescan(gpu_device):
     st = index.last_stats()
     assert st["fallback_rounds"] > 0
     assert st["fallback_rounds"] < 600 and dt < 0.5, (st, dt)
+
+
+@pytest.mark.gpu
+def test_begin_finish_equals_the_one_call_search(gpu_device):
+    """proqa_index_search_begin_device / _finish: the search is enqueued, other work goes onto the stream behind it, the
+    host checks once at the end.  Same result as the one-call form -- also when the check finds overflowed rounds and
+    rewrites the result (status word 1), and for searches that cannot be deferred (large k: they complete in _begin)."""
+    import ctypes
+    import torch
+    from proqa_amd import _lib
+    from proqa_amd.index import IndexFlatIP
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    cases = []
+    xb = _int_corpus(rng, 60000)
+    cases.append(("plain", xb, _int_corpus(rng, 300), 80, None))
+    cases.append(("small batch", xb, _int_corpus(rng, 5), 10, None))
+    cases.append(("large k", _int_corpus(rng, 100000, lo=-8, hi=8), _int_corpus(rng, 7, lo=-8, hi=8), 3000, None))
+    adv = np.zeros((40000, 128), np.float16)
+    adv[:, 0] = (np.arange(40000) // 40).astype(np.float16)
+    advq = np.zeros((70, 128), np.float16)
+    advq[:, 0] = 1
+    cases.append(("overflow", adv, advq, 80, (128, 4)))
+    for name, xb_c, xq_c, k, cfg in cases:
+        index = IndexFlatIP(128)
+        if cfg:
+            index.configure(*cfg)
+        index.add(xb_c)
+        xq_dev = torch.from_numpy(xq_c).cuda()
+        nq = xq_c.shape[0]
+        D = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+        I = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+        status = torch.full((4,), 77, dtype=torch.int32, device="cuda")
+        _lib.check(lib.proqa_index_search_begin_device(index._h, xq_dev.data_ptr(), nq, 0, k, 1000, D.data_ptr(), I.data_ptr(),
+                                                       status.data_ptr(), _lib.current_stream_ptr()))
+        early = I.clone()                      # work enqueued behind the search sees the (optimistic) result
+        status_seen = status.clone()
+        rewritten = ctypes.c_int(-1)
+        _lib.check(lib.proqa_index_search_finish(index._h, ctypes.byref(rewritten)))
+        Do, Io = search_oracle.topk_ip(xq_c, xb_c, k)
+        np.testing.assert_array_equal(I.cpu().numpy(), np.where(Io >= 0, Io + 1000, Io), err_msg=name)
+        np.testing.assert_array_equal(D.cpu().numpy(), Do, err_msg=name)
+        st = index.last_stats()
+        assert status_seen[0].item() == rewritten.value == (1 if name == "overflow" else 0), (name, status_seen, rewritten.value)
+        assert (st["fallback_rounds"] > 0) == (name == "overflow"), (name, st)
+        if name != "overflow":
+            assert torch.equal(early, I), name
+        assert st["rounds"] > 0 and st["candidates"] > 0, (name, st)
+        # a second _finish is a no-op; the one-call search still works on the handle
+        _lib.check(lib.proqa_index_search_finish(index._h, None))
+        D1, I1 = index.search(xq_c, k)
+        np.testing.assert_array_equal(I1, Io, err_msg=name)
+        index.close()
+
+
+@pytest.mark.gpu
+def test_one_pass_store_that_cannot_be_allocated_falls_back_to_pages(gpu_device, monkeypatch):
+    """The deep candidate store of the one-pass large-k search does not fit beside the caller's tensors (forced here: a
+    hipMalloc that really fails, leaving HIP's sticky error behind): the search must fall back to the paged path and
+    return the exact result, not report the allocation failure of a launch that never needed the memory."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(9)
+    xb = _int_corpus(rng, 300000, lo=-8, hi=8)
+    xq = _int_corpus(rng, 6, lo=-8, hi=8)
+    Do, Io = search_oracle.topk_ip(xq, xb, 5000)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    monkeypatch.setenv("PROQA_DEBUG_STORE_LIMIT_MB", "256")
+    D, I = index.search(xq, 5000)
+    st = index.last_stats()
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert st["fallback_rounds"] == 0 and st["rounds"] > 20, st      # pages, not the one pass (which is <= ~10 rounds)
+    monkeypatch.delenv("PROQA_DEBUG_STORE_LIMIT_MB")
+    D, I = index.search(xq, 5000)                                     # and the one pass once the memory is there
+    np.testing.assert_array_equal(I, Io)
+    assert index.last_stats()["rounds"] <= 12
+    index.close()
+
+
+@pytest.mark.gpu
+def test_candidate_store_follows_the_batch_not_the_largest_batch_seen(gpu_device):
+    """A one-question large-k search after a big batch on the same handle: the deep lane lists are sized (and addressed)
+    by the launch's own padded query count, so the store stays within what the one-pass plan budgeted."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(12)
+    xb = _int_corpus(rng, 400000, lo=-8, hi=8)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    big = _int_corpus(rng, 3000, lo=-8, hi=8)
+    D, I = index.search(big, 80)
+    Do, Io = search_oracle.topk_ip(big[:50], xb, 80)
+    np.testing.assert_array_equal(I[:50], Io)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    one = _int_corpus(rng, 1, lo=-8, hi=8)
+    D, I = index.search(one, 5000)
+    Do, Io = search_oracle.topk_ip(one, xb, 5000)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    used = free0 - torch.cuda.mem_get_info()[0]
+    # 256 padded queries x ~330 chunks x 2 lists x 24 records x 80 B ~ 0.33 GB; sized by the 3072-query workspace it was ~4 GB
+    assert used < 1.5 * (1 << 30), used
+    index.close()
