@@ -346,7 +346,7 @@ LaunchGeom geometry(long long slab_rows, unsigned n_qtiles, bool single_stage, i
   return {(int)rpc, (unsigned)chunks, (unsigned)(round_up<long long>(chunks, 8) * n_qtiles)};
 }
 
-CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtiles, unsigned lane_cap) {
+CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtiles, unsigned lane_cap, unsigned n_chunks) {
   CandidateStore st;
   st.lane_log = idx->lane_log;
   st.lane_cnt = idx->lane_cnt;
@@ -355,6 +355,7 @@ CandidateStore store_of(const proqa_index* idx, unsigned nq_pad, unsigned n_qtil
   st.nq_pad = nq_pad;
   st.n_qtiles = n_qtiles;
   st.lane_cap = lane_cap;
+  st.n_chunks = n_chunks;
   return st;
 }
 
@@ -380,7 +381,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   // exact-float32 mode: the fp16 filter tests against thresholds moved by the error margin
   fa.tau = idx->exact ? idx->tau_filter : idx->tau;
   fa.ub = bounded ? (idx->exact ? idx->ub_filter : idx->ub) : nullptr;
-  fa.store = store_of(idx, nq_pad, n_qtiles, lane_cap);
+  fa.store = store_of(idx, nq_pad, n_qtiles, lane_cap, round_up<unsigned>(g.chunks, 8));
   fa.overflow = overflow_word;
   fa.flags = kFilterFlags;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
@@ -404,6 +405,34 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.xb32 = idx->exact ? idx->xb32 : nullptr;
   ma.margin = idx->exact ? idx->margin : nullptr;
   ma.tau_filter = idx->exact ? idx->tau_filter : nullptr;
+  ma.dbg = nullptr;
+#ifdef PROQA_MERGE_STAMPS
+  {
+    static unsigned long long* dbg_buf = nullptr;
+    if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 16384 * 8 * 8);
+    ma.dbg = dbg_buf;
+    static int launches = 0;
+    if (getenv("PROQA_MERGE_STAMPS_DUMP") && ++launches % 64 == 63) {
+      PROQA_HIP(launch_merge(ma, nq_pad, st));
+      (void)hipStreamSynchronize(st);
+      std::vector<unsigned long long> h((size_t)nq_pad * 8);
+      (void)hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
+      for (int ph = 1; ph <= 6; ++ph) {
+        std::vector<long long> d;
+        for (unsigned q = 0; q < nq_pad && q < 2000; ++q) d.push_back((long long)(h[q * 8 + ph] - h[q * 8 + ph - 1]));
+        std::sort(d.begin(), d.end());
+        fprintf(stderr, "merge phase %d: median %lld  p10 %lld  p90 %lld (s_memtime ticks)\n", ph, d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+      }
+      std::vector<long long> e;
+      unsigned long long t0 = ~0ull;
+      for (unsigned q = 0; q < nq_pad && q < 2000; ++q) t0 = std::min(t0, h[q * 8]);
+      for (unsigned q = 0; q < nq_pad && q < 2000; ++q) e.push_back((long long)(h[q * 8] - t0));
+      std::sort(e.begin(), e.end());
+      fprintf(stderr, "merge start skew: median %lld max %lld\n", e[e.size() / 2], e.back());
+      return PROQA_OK;
+    }
+  }
+#endif
   PROQA_HIP(launch_merge(ma, nq_pad, st));
   return PROQA_OK;
 }
@@ -702,12 +731,22 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
 }
 
 int finish_pending(proqa_index* idx, int* rewritten);
+int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset, float* D_dev,
+                       int64_t* I_dev, hipStream_t st, bool defer, uint32_t* status_dev);
 
 // `defer`: a search of the one-page kind is only ENQUEUED (idx->pending describes it; finish_pending completes it);
 // every other kind runs to completion here.  `status_dev` (optional device word, written on the stream): 1 if the
 // completion will rewrite the result, else 0.
 int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
                   float* D_dev, int64_t* I_dev, hipStream_t st, bool defer = false, uint32_t* status_dev = nullptr) {
+  const int rc = search_device_impl(idx, xq_dev, nq, dtype, k, idx_offset, D_dev, I_dev, st, defer, status_dev);
+  // a search that ran to completion has a final result: its status word is 0 (the deferred kind writes the word itself)
+  if (rc == PROQA_OK && status_dev && !idx->pending.active) PROQA_HIP(hipMemsetAsync(status_dev, 0, sizeof(uint32_t), st));
+  return rc;
+}
+
+int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
+                       float* D_dev, int64_t* I_dev, hipStream_t st, bool defer, uint32_t* status_dev) {
   if (idx->pending.active)   // a begun search nobody finished (an error path of the caller): complete it, drop its result
     if (int rc = finish_pending(idx, nullptr)) return rc;
   if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
@@ -716,8 +755,6 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   idx->stats = {};
   if (nq == 0) return PROQA_OK;
   PROQA_ON_DEVICE(idx->device);
-  // (every path but the deferred one ends with a final result: the status word is cleared up front on the stream)
-  if (status_dev) PROQA_HIP(hipMemsetAsync(status_dev, 0, sizeof(uint32_t), st));
 
   // wave tile: 2 query blocks of 32 per wave (512 queries per workgroup) unless the batch is small
   const int qw = nq > 256 ? kWideQw : 1;

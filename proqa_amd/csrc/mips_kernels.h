@@ -51,8 +51,8 @@ static_assert(sizeof(WaveRecord) == 80, "record layout");
 
 // Candidate storage of one filter launch (all written without atomics):
 //   lane_log [chunk][q][half][kLaneCap]  private list of the lane that owns (q, half) in `chunk`
-//   lane_cnt [chunk][q][half]            its length
-//   spill_log[chunk][wave slot][kSpillCap], spill_cnt[chunk][wave slot]
+//   lane_cnt [q][chunk][half]            its length (query-major: one contiguous run per query for the merge)
+//   spill_log[chunk][wave slot][kSpillCap], spill_cnt[wave slot][chunk]
 //                                         shared by the 64 lanes of a wave once a private list is full
 // wave slot = (query tile, wave) = the 32*QW consecutive queries one wave owns.
 struct CandidateStore {
@@ -63,6 +63,7 @@ struct CandidateStore {
   unsigned nq_pad;
   unsigned n_qtiles;
   unsigned lane_cap;     // records per lane list of this search (kLaneCap or kBigLaneCap)
+  unsigned n_chunks;     // corpus chunks of this launch, rounded up to 8: stride of the query-major / slot-major counters
 };
 
 struct FilterArgs {
@@ -98,6 +99,7 @@ struct MergeArgs {
   const float* xb32;             // float32 corpus rows of this shard
   const float* margin;           // [nq_pad] bound on |float32 score - fp16 score| for any row
   float* tau_filter;             // [nq_pad] threshold of the next filter launch
+  unsigned long long* dbg;       // developer build (PROQA_MERGE_STAMPS): [nq_pad, 8] s_memtime stamps of the phases, or NULL
 };
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);

@@ -74,6 +74,15 @@ __device__ __forceinline__ float max2_f32(float a, float b) {
 __device__ __forceinline__ size_t lane_list_index(const CandidateStore& st, unsigned chunk, unsigned q, int half) {
   return ((size_t)chunk * st.nq_pad + q) * 2 + half;
 }
+// The list LENGTHS are kept query-major (and the spill counters slot-major): a query's merge reads the lengths of all its
+// lists -- one per chunk and half -- as one contiguous run instead of one cache line per chunk (a merge launch spent a
+// quarter of its time on these scattered 4-byte loads); the scatter moves to the filter's one store per lane at its end.
+__device__ __forceinline__ size_t lane_cnt_index(const CandidateStore& st, unsigned chunk, unsigned q, int half) {
+  return ((size_t)q * st.n_chunks + chunk) * 2 + half;
+}
+__device__ __forceinline__ size_t spill_cnt_index(const CandidateStore& st, unsigned chunk, unsigned qt, unsigned wave) {
+  return ((size_t)qt * kFilterWaves + wave) * st.n_chunks + chunk;
+}
 
 // ---------------------------------------------------------------------------------------
 // filter kernel
@@ -306,8 +315,8 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
     }
 #pragma unroll
     for (int blk = 0; blk < QW; ++blk)
-      a.store.lane_cnt[lane_list_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
-    if (lane == 0) a.store.spill_cnt[wave_slot] = 0u;
+      a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
+    if (lane == 0) a.store.spill_cnt[spill_cnt_index(a.store, chunk, qt, wave)] = 0u;
     return;
   }
 
@@ -358,8 +367,8 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk)
-    a.store.lane_cnt[lane_list_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
-  if (lane == 0) a.store.spill_cnt[wave_slot] = (unsigned)spill_n;
+    a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
+  if (lane == 0) a.store.spill_cnt[spill_cnt_index(a.store, chunk, qt, wave)] = (unsigned)spill_n;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -435,51 +444,92 @@ __device__ __forceinline__ void wave_append(bool pred, T item, T* arr, unsigned*
   if (pred && pos < cap) arr[pos] = item;
 }
 
-// Bitonic sort (descending) of 256*NK packed keys held NK per thread by a 256-thread workgroup; key (tid, j) is
+// v of lane (lane ^ M), M a power of two below 64, without touching the LDS crossbar (a merge launch was bound by its
+// ds_bpermute traffic: 32 waves per CU x ~180 of them each): DPP moves inside a row of 16 lanes, gfx950's
+// v_permlane16_swap / v_permlane32_swap across rows and halves.  M is a template parameter: a run-time switch over the
+// six forms costs more scalar branching than the exchange itself.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <unsigned M>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned x, int lane) {
+  static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "lane distance");
+  if constexpr (M == 1) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
+  } else if constexpr (M == 2) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
+  } else if constexpr (M == 4) {                                                       // banks 0,2 <- lane+4; banks 1,3 <- lane-4
+    const int r = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xf, 0x5, false);      // row_shl:4
+    return (unsigned)__builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xf, 0xa, false);   // row_shr:4
+  } else if constexpr (M == 8) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false);   // row_ror:8
+  } else if constexpr (M == 16) {
+    // {even rows of both, odd rows of both}: an odd row finds its partner row in the first, an even row in the second
+    const u32x2 sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    return (lane & 16) ? sw[0] : sw[1];
+  } else {
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);             // {lower half twice, upper half twice}
+    return (lane & 32) ? sw[0] : sw[1];
+  }
+}
+template <unsigned M>
+__device__ __forceinline__ unsigned long long xor_lane_u64(unsigned long long v, int lane) {
+  const unsigned lo = xor_lane_u32<M>((unsigned)v, lane), hi = xor_lane_u32<M>((unsigned)(v >> 32), lane);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// one compare-exchange stage between lanes M apart: every key of the thread against the partner thread's
+template <unsigned M, int NK>
+__device__ __forceinline__ void lane_stage(unsigned long long (&v)[NK], bool keep_max, int lane) {
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const unsigned long long o = xor_lane_u64<M>(v[j], lane);
+    v[j] = ((v[j] < o) == keep_max) ? o : v[j];
+  }
+}
+
+// Bitonic sort (descending) of T*NK packed keys held NK per thread by a T-thread workgroup; key (tid, j) is
 // element tid*NK + j of the sequence.  Strides below NK are compare-exchanges between a thread's own registers,
-// strides below 64*NK are lane shuffles inside a wave; only the two widest strides cross waves and go through
-// LDS (`xchg`, 256*NK keys), i.e. three barrier pairs per sort instead of one barrier per stage.
+// strides below 64*NK are lane exchanges inside a wave (xor_lane_u64); only the two (three for T = 512) widest strides
+// cross waves and go through LDS (`xchg`, T*NK keys), i.e. three barrier pairs per sort instead of one barrier per stage.
 template <int NK, int T = kMergeThreads>
 __device__ __forceinline__ void sort_keys_desc(unsigned long long (&v)[NK], unsigned long long* xchg, int tid) {
   constexpr unsigned P = (unsigned)T * NK;
+  const int lane = tid & 63;
   for (unsigned size = 2; size <= P; size <<= 1) {
-    for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-      if (stride >= (unsigned)NK) {
-        // partner key (tid ^ m, j): all keys of a thread share the block direction (size > stride >= NK)
-        const unsigned m = stride / NK;
-        const bool desc = (((unsigned)tid * NK) & size) == 0;
+    const unsigned top = size >> 1;   // the first (widest) stride of this merge phase
+    if (top >= (unsigned)NK) {
+      // partner key (tid ^ m, j), m = stride / NK: all keys of a thread share the block direction (size > stride >= NK)
+      const bool desc = (((unsigned)tid * NK) & size) == 0;
+      for (unsigned m = top / NK; m >= 64u; m >>= 1) {
         const bool keep_max = (((unsigned)tid & m) == 0) == desc;
-        if (m >= 64u) {
 #pragma unroll
-          for (int j = 0; j < NK; ++j) xchg[j * T + tid] = v[j];
-          __syncthreads();
+        for (int j = 0; j < NK; ++j) xchg[j * T + tid] = v[j];
+        __syncthreads();
 #pragma unroll
-          for (int j = 0; j < NK; ++j) {
-            const unsigned long long o = xchg[j * T + (tid ^ m)];
-            v[j] = ((v[j] < o) == keep_max) ? o : v[j];
-          }
-          __syncthreads();
-        } else {
-#pragma unroll
-          for (int j = 0; j < NK; ++j) {
-            const unsigned long long o = __shfl_xor(v[j], (int)m, 64);
-            v[j] = ((v[j] < o) == keep_max) ? o : v[j];
-          }
+        for (int j = 0; j < NK; ++j) {
+          const unsigned long long o = xchg[j * T + (tid ^ m)];
+          v[j] = ((v[j] < o) == keep_max) ? o : v[j];
         }
-      } else {
+        __syncthreads();
+      }
+      const unsigned m_top = top / NK < 32u ? top / NK : 32u;   // wave-uniform
+      if (m_top >= 32u) lane_stage<32, NK>(v, ((tid & 32) == 0) == desc, lane);
+      if (m_top >= 16u) lane_stage<16, NK>(v, ((tid & 16) == 0) == desc, lane);
+      if (m_top >= 8u) lane_stage<8, NK>(v, ((tid & 8) == 0) == desc, lane);
+      if (m_top >= 4u) lane_stage<4, NK>(v, ((tid & 4) == 0) == desc, lane);
+      if (m_top >= 2u) lane_stage<2, NK>(v, ((tid & 2) == 0) == desc, lane);
+      lane_stage<1, NK>(v, ((tid & 1) == 0) == desc, lane);
+    }
 #pragma unroll
-        for (int s = NK / 2; s >= 1; s >>= 1) {
-          if (stride == (unsigned)s) {
+    for (int s = NK / 2; s >= 1; s >>= 1) {
+      if (top >= (unsigned)s) {
 #pragma unroll
-            for (int j = 0; j < NK; ++j) {
-              if ((j & s) == 0) {
-                const bool desc = ((((unsigned)tid * NK) + j) & size) == 0;
-                const unsigned long long x = v[j], y = v[j + s];
-                const bool sw = (x < y) == desc;
-                v[j] = sw ? y : x;
-                v[j + s] = sw ? x : y;
-              }
-            }
+        for (int j = 0; j < NK; ++j) {
+          if ((j & s) == 0) {
+            const bool desc = ((((unsigned)tid * NK) + j) & size) == 0;
+            const unsigned long long x = v[j], y = v[j + s];
+            const bool sw = (x < y) == desc;
+            v[j] = sw ? y : x;
+            v[j + s] = sw ? x : y;
           }
         }
       }
@@ -487,14 +537,14 @@ __device__ __forceinline__ void sort_keys_desc(unsigned long long (&v)[NK], unsi
   }
 }
 
-// Last phase of a bitonic sort on 256*NK keys that already form a bitonic sequence (first half descending, second half
-// ascending): log2(256 NK) compare-exchange stages instead of a whole sort.  The keys are held STRIPED: v[j] is element
-// j*256 + tid, so the strides >= 256 pair registers of one thread, the strides 128 and 64 cross waves (LDS), the rest
-// are lane shuffles.  Result: element j*256 + tid of the descending sequence.
+// Last phase of a bitonic sort on T*NK keys that already form a bitonic sequence (first half descending, second half
+// ascending): log2(T NK) compare-exchange stages instead of a whole sort.  The keys are held STRIPED: v[j] is element
+// j*T + tid, so the strides >= T pair registers of one thread, the strides >= 64 below that cross waves (LDS), the rest
+// are lane exchanges.  Result: element j*T + tid of the descending sequence.
 template <int NK, int T = kMergeThreads>
 __device__ __forceinline__ void bitonic_merge_striped_desc(unsigned long long (&v)[NK], unsigned long long* xchg, int tid) {
 #pragma unroll
-  for (int sj = NK / 2; sj >= 1; sj >>= 1) {       // strides sj * 256
+  for (int sj = NK / 2; sj >= 1; sj >>= 1) {       // strides sj * T
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
       if ((j & sj) == 0) {
@@ -505,26 +555,25 @@ __device__ __forceinline__ void bitonic_merge_striped_desc(unsigned long long (&
       }
     }
   }
-  for (unsigned m = T / 2; m > 0; m >>= 1) {   // strides m < 256: partner thread tid ^ m, same register
+  for (unsigned m = T / 2; m >= 64u; m >>= 1) {   // strides 64 <= m < T: partner thread tid ^ m, same register
     const bool keep_max = ((unsigned)tid & m) == 0;
-    if (m >= 64u) {
 #pragma unroll
-      for (int j = 0; j < NK; ++j) xchg[j * T + tid] = v[j];
-      __syncthreads();
+    for (int j = 0; j < NK; ++j) xchg[j * T + tid] = v[j];
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        const unsigned long long o = xchg[j * T + (tid ^ m)];
-        v[j] = ((v[j] < o) == keep_max) ? o : v[j];
-      }
-      __syncthreads();
-    } else {
-#pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        const unsigned long long o = __shfl_xor(v[j], (int)m, 64);
-        v[j] = ((v[j] < o) == keep_max) ? o : v[j];
-      }
+    for (int j = 0; j < NK; ++j) {
+      const unsigned long long o = xchg[j * T + (tid ^ m)];
+      v[j] = ((v[j] < o) == keep_max) ? o : v[j];
     }
+    __syncthreads();
   }
+  const int lane = tid & 63;
+  lane_stage<32, NK>(v, (tid & 32) == 0, lane);
+  lane_stage<16, NK>(v, (tid & 16) == 0, lane);
+  lane_stage<8, NK>(v, (tid & 8) == 0, lane);
+  lane_stage<4, NK>(v, (tid & 4) == 0, lane);
+  lane_stage<2, NK>(v, (tid & 2) == 0, lane);
+  lane_stage<1, NK>(v, (tid & 1) == 0, lane);
 }
 
 // Sort keys[0, total) (LDS, total <= 256*NK; the tail is padded with 0, which is below every real key) and
@@ -541,6 +590,11 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
   sort_keys_desc<NK, T>(v, keys, tid);
 }
 
+#ifdef PROQA_MERGE_STAMPS
+#define PROQA_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PROQA_STAMP(i) do {} while (0)
+#endif
 // EXACT = exact-float32 mode (own instantiation: its LDS list and registers stay out of the fp16 kernel)
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
 // T = threads: 256, or 512 for the largest CAP (one workgroup per CU there: the second wave per SIMD hides the latencies)
@@ -558,6 +612,7 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
   const unsigned q = blockIdx.x;
   const int tid = threadIdx.x;
   const CandidateStore& st = a.store;
+  PROQA_STAMP(0);
   ExactCtx ex = {nullptr, nullptr};
   float* xq32_lds = nullptr;
   if constexpr (EXACT) {
@@ -575,20 +630,36 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
   const bool inclusive = a.inclusive != 0;
   const unsigned long long bound = a.bound_keys ? a.bound_keys[q] : ~0ull;
 
-  // the running list is needed last: fetch its first 256 keys (all of it for the usual k) first
-  const unsigned nrun = a.run_n[q];
-  const unsigned long long run_pref = (unsigned)tid < nrun ? a.run_keys[(size_t)q * a.k + tid] : 0ull;
-
   // the wave slot that owns q in every chunk
   const unsigned tile_q = filter_tile_queries((int)a.qw);
   const unsigned qt = q / tile_q;
   const unsigned wave = (q - qt * tile_q) / (a.qw * 32);
+  const unsigned spill_stride = st.n_qtiles * kFilterWaves;                              // per chunk
+
+  // Everything that does not depend on another load is requested up front, in ONE round trip to memory: the length of the
+  // running list, its first T keys (all of it for the usual k; read whether or not they are valid yet -- the slots exist --
+  // and masked below), and the list lengths / spill counters of the first pass (the only pass unless a launch has more
+  // than T chunks).  The records themselves are the second, and last, dependent round trip.
+  const unsigned nrun = a.run_n[q];
+  unsigned long long run_pref = (unsigned)tid < (unsigned)a.k ? a.run_keys[(size_t)q * a.k + tid] : 0ull;
+  unsigned cnt_first[2], n_spill_first;
+  {
+    const unsigned n_here = n_lists < 2u * T ? n_lists : 2u * T;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const unsigned t = (unsigned)tid + e * T;
+      cnt_first[e] = t < n_here ? st.lane_cnt[lane_cnt_index(st, t >> 1, q, (int)(t & 1))] : 0u;
+    }
+    n_spill_first = (unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_cnt_index(st, (unsigned)tid, qt, wave)] : 0u;
+  }
+  run_pref = (unsigned)tid < nrun ? run_pref : 0ull;
 
   if (tid == 0) s_n_keys = 0;
 
   for (unsigned base = 0; base < n_lists; base += 2 * T) {
     if (tid == 0) s_n_work = 0;
     __syncthreads();
+  PROQA_STAMP(1);
     // list lengths of this query (chunk-major, half-minor; two lists per thread) and the spill counter of
     // one chunk per thread: three independent loads, then one work item per logged record
     const unsigned n_here = (n_lists - base) < 2u * T ? (n_lists - base) : 2u * T;
@@ -599,11 +670,11 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
       const unsigned t = (unsigned)tid + e * T;
       const unsigned l = base + t;
       li[e] = lane_list_index(st, l >> 1, q, (int)(l & 1));
-      cnt[e] = t < n_here ? st.lane_cnt[li[e]] : 0u;
+      cnt[e] = base == 0 ? cnt_first[e] : (t < n_here ? st.lane_cnt[lane_cnt_index(st, l >> 1, q, (int)(l & 1))] : 0u);
     }
     const unsigned spill_slot0 = ((base >> 1) * st.n_qtiles + qt) * kFilterWaves + wave;   // chunk base/2
-    const unsigned spill_stride = st.n_qtiles * kFilterWaves;                              // per chunk
-    const unsigned n_spill = (unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_slot0 + (unsigned)tid * spill_stride] : 0u;
+    const unsigned n_spill = base == 0 ? n_spill_first
+                                       : ((unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_cnt_index(st, (base >> 1) + (unsigned)tid, qt, wave)] : 0u);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       if (cnt[e]) {
@@ -631,24 +702,60 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
       }
     }
     __syncthreads();
+  PROQA_STAMP(2);
     const unsigned n_work = s_n_work < kWorkCap ? s_n_work : kWorkCap;
-    // two records per thread in flight
-    for (unsigned w0 = tid; w0 < n_work; w0 += 2 * T) {
-      const unsigned w1 = w0 + T;
-      const bool two = w1 < n_work;
-      const unsigned i0 = s_work[w0], i1 = two ? s_work[w1] : i0;
-      const unsigned l0 = base + (i0 >> 6), l1 = base + (i1 >> 6);
-      const uint4* r0 = (const uint4*)(st.lane_log + lane_list_index(st, l0 >> 1, q, (int)(l0 & 1)) * lane_cap + (i0 & 63u));
-      const uint4* r1 = (const uint4*)(st.lane_log + lane_list_index(st, l1 >> 1, q, (int)(l1 & 1)) * lane_cap + (i1 & 63u));
-      uint4 b0[5], b1[5];
+    // FIVE lanes per record, one 16-byte piece each (12 records per wave and load instruction, two instructions in
+    // flight): the pieces of a record -- and the records of a list, which are neighbours in the queue -- are adjacent in
+    // memory, so a wave's load touches a few cache lines instead of one or two per lane (one thread per record made the
+    // gather as expensive as the sort).  The header lane hands row0 / rows_left / tau to the four score lanes.
+    {
+      const int lane = tid & 63;
+      const int grp = lane / 5, piece = lane - grp * 5;
+      const bool lane_on = grp < 12;
+      constexpr unsigned kPerWg = 12 * (T / 64);
+      auto fetch = [&](unsigned w, bool& live) -> uint4 {
+        live = lane_on && w < n_work;
+        if (!live) return make_uint4(0u, 0u, 0u, 0u);
+        const unsigned item = s_work[w];
+        const unsigned l = base + (item >> 6);
+        const uint4* r = (const uint4*)(st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * lane_cap + (item & 63u));
+        return r[piece];
+      };
+      auto keep = [&](const uint4& v, bool live) {
+        const int head = lane - piece;
+        const unsigned row0 = (unsigned)__shfl((int)v.y, head, 64);
+        const int rows_left = __shfl((int)v.z, head, 64);
+        const float tau = __uint_as_float((unsigned)__shfl((int)v.w, head, 64));
+        if (!live || piece == 0) return;
+        const int g = piece - 1;
+        const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 #pragma unroll
-      for (int g = 0; g < 5; ++g) b0[g] = r0[g];
-#pragma unroll
-      for (int g = 0; g < 5; ++g) b1[g] = r1[g];
-      keep_scores_regs(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
-      if (two) keep_scores_regs(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+        for (int e = 0; e < 4; ++e) {
+          if ((inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
+            const unsigned row = row0 + (unsigned)(e + 8 * g);
+            if (ex.nom) {  // exact-float32 mode: the fp16 score only nominates the row
+              const unsigned pos = atomicAdd(ex.n_nom, 1u);  // LDS
+              if (pos < (unsigned)CAP) ex.nom[pos] = row;
+              continue;
+            }
+            const unsigned long long key = pack_key(sc[e], row);
+            if (key < bound) {  // paged search: ties with the bound score that were already reported
+              const unsigned pos = atomicAdd(&s_n_keys, 1u);  // LDS
+              if (pos < (unsigned)CAP) keys[pos] = key;
+            }
+          }
+        }
+      };
+      for (unsigned wb = (unsigned)(tid >> 6) * 12; wb < n_work; wb += 2 * kPerWg) {   // wave-uniform trip count
+        bool live0, live1;
+        const uint4 v0 = fetch(wb + grp, live0);
+        const uint4 v1 = fetch(wb + kPerWg + grp, live1);
+        keep(v0, live0);
+        if (wb + kPerWg < n_work) keep(v1, live1);
+      }
     }
     __syncthreads();
+  PROQA_STAMP(3);
   }
 
   if constexpr (EXACT) {
@@ -749,12 +856,14 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
   for (unsigned i = T + tid; i < nrun; i += T) keys[n_cand + i] = a.run_keys[(size_t)q * a.k + i];
   const unsigned total = n_cand + nrun;
   __syncthreads();
+  PROQA_STAMP(4);
 
   // sort descending; forward rounds keep the first k keys as they are, inclusive rounds (rows re-scanned
   // by the overflow-safe path may already be in the running list) drop exact duplicates first
   auto finish = [&](auto& v) {
     constexpr int NK = sizeof(v) / sizeof(v[0]);
     load_and_sort<NK, T>(v, keys, total, tid);
+  PROQA_STAMP(5);
     if (!inclusive) {
       const unsigned keep = total < (unsigned)a.k ? total : (unsigned)a.k;
 #pragma unroll
@@ -804,6 +913,7 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
       finish(v);
     }
   }
+  PROQA_STAMP(6);
   if (!inclusive) return;
   __syncthreads();
   if (tid == 0) {  // rare path, serial
@@ -1252,6 +1362,71 @@ __global__ __launch_bounds__(kMergeThreads) void merge_lists(const float* __rest
   }
 }
 
+// The same merge for the common small case (n_parts * k <= kRankMergeKeys, e.g. 8 shards x top-80), using that every
+// part is already sorted: no sort at all.  The output rank of entry j of part p is j plus, for every other part, the
+// number of its keys that order before this one -- a binary search per part (keys are unique: the gathered position is
+// their low word).  One barrier after the load, every surviving entry is written straight to its rank; a single part
+// degenerates to a copy.  Entries with id < 0 (a shard with fewer than k rows) sit at the tail of their part.
+constexpr int kRankMergeKeys = 4096;
+constexpr int kRankMergeParts = 64;
+__global__ __launch_bounds__(kMergeThreads) void merge_sorted_lists(const float* __restrict__ D_parts,
+                                                                    const long long* __restrict__ I_parts, int n_parts,
+                                                                    long long nq, int k, long long stride_d, long long stride_i,
+                                                                    float* __restrict__ D, long long* __restrict__ I,
+                                                                    const unsigned* __restrict__ status_src,
+                                                                    long long status_stride, unsigned* __restrict__ status_host) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // n_parts * k
+  __shared__ unsigned s_n[kRankMergeParts];
+  const long long q = blockIdx.x;
+  const int tid = threadIdx.x;
+  if (status_host && q == 0) {   // sharded search: every part's status word, straight into pinned host memory
+    for (int p = tid; p < n_parts; p += kMergeThreads) status_host[p] = status_src[(size_t)p * status_stride];
+    __threadfence_system();
+  }
+  const unsigned total = (unsigned)n_parts * (unsigned)k;
+  for (unsigned i = tid; i < total; i += kMergeThreads) {
+    const unsigned p = i / k, j = i - p * k;
+    const size_t off = (size_t)q * k + j;
+    keys[i] = I_parts[(size_t)p * stride_i + off] >= 0 ? pack_key(D_parts[(size_t)p * stride_d + off], i) : 0ull;
+  }
+  __syncthreads();
+  if (tid < n_parts) {   // valid entries of part `tid`: the first zero key
+    unsigned lo = 0, hi = (unsigned)k;
+    while (lo < hi) {
+      const unsigned mid = (lo + hi) >> 1;
+      if (keys[(unsigned)tid * k + mid] != 0ull) lo = mid + 1; else hi = mid;
+    }
+    s_n[tid] = lo;
+  }
+  __syncthreads();
+  unsigned n_valid = 0;
+  for (int p = 0; p < n_parts; ++p) n_valid += s_n[p];
+  for (unsigned i = tid; i < total; i += kMergeThreads) {
+    const unsigned long long x = keys[i];
+    if (x == 0ull) continue;
+    const unsigned p = i / k, j = i - p * k;
+    unsigned r = j;
+    for (int pp = 0; pp < n_parts && r < (unsigned)k; ++pp) {
+      if ((unsigned)pp == p) continue;
+      const unsigned long long* part = keys + (unsigned)pp * k;   // descending: count the keys above x
+      unsigned lo = 0, hi = s_n[pp];
+      while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if (part[mid] > x) lo = mid + 1; else hi = mid;
+      }
+      r += lo;
+    }
+    if (r < (unsigned)k) {
+      D[q * k + r] = float_from_ord((unsigned)(x >> 32));
+      I[q * k + r] = I_parts[(size_t)p * stride_i + (size_t)q * k + j];
+    }
+  }
+  for (unsigned j = n_valid + tid; j < (unsigned)k; j += kMergeThreads) {
+    D[q * k + j] = -3.4028234663852886e38f;
+    I[q * k + j] = -1;
+  }
+}
+
 __global__ void copy_status_words(const unsigned* __restrict__ src, long long stride, int n, unsigned* __restrict__ host) {
   for (int p = threadIdx.x; p < n; p += blockDim.x) host[p] = src[(size_t)p * stride];
   __threadfence_system();
@@ -1450,6 +1625,11 @@ hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, in
                               const unsigned* status_src, long long status_stride, unsigned* status_host) {
   if (nq == 0) return hipSuccess;
   const long long per_q = (long long)n_parts * k;
+  if (per_q <= kRankMergeKeys && n_parts <= kRankMergeParts) {
+    hipLaunchKernelGGL(merge_sorted_lists, dim3((unsigned)nq), dim3(kMergeThreads), (size_t)per_q * 8, st, D_parts, I_parts,
+                       n_parts, nq, k, stride_d, stride_i, D, I, status_src, status_stride, status_host);
+    return hipGetLastError();
+  }
   if (per_q <= kMaxMergeListKeys) {
     unsigned P = kMergeThreads;
     while (P < (unsigned)per_q) P <<= 1;

@@ -804,12 +804,12 @@ def test_one_pass_store_that_cannot_be_allocated_falls_back_to_pages(gpu_device,
     Do, Io = search_oracle.topk_ip(xq, xb, 5000)
     index = IndexFlatIP(128)
     index.add(xb)
-    monkeypatch.setenv("PROQA_DEBUG_STORE_LIMIT_MB", "256")
+    monkeypatch.setenv("PROQA_DEBUG_STORE_LIMIT_MB", "400")
     D, I = index.search(xq, 5000)
     st = index.last_stats()
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
-    assert st["fallback_rounds"] == 0 and st["rounds"] > 20, st      # pages, not the one pass (which is <= ~10 rounds)
+    assert st["fallback_rounds"] == 1 and st["rounds"] > 20, st      # the one pass gave up (counted once), then pages
     monkeypatch.delenv("PROQA_DEBUG_STORE_LIMIT_MB")
     D, I = index.search(xq, 5000)                                     # and the one pass once the memory is there
     np.testing.assert_array_equal(I, Io)
