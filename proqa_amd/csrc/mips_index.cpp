@@ -412,7 +412,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 16384 * 8 * 8);
     ma.dbg = dbg_buf;
     static int launches = 0;
-    if (getenv("PROQA_MERGE_STAMPS_DUMP") && ++launches % 64 == 63) {
+    if (getenv("PROQA_MERGE_STAMPS_DUMP") && ++launches % 16 == 15) {
       PROQA_HIP(launch_merge(ma, nq_pad, st));
       (void)hipStreamSynchronize(st);
       std::vector<unsigned long long> h((size_t)nq_pad * 8);

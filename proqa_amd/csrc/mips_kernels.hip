@@ -746,12 +746,17 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
           }
         }
       };
-      for (unsigned wb = (unsigned)(tid >> 6) * 12; wb < n_work; wb += 2 * kPerWg) {   // wave-uniform trip count
-        bool live0, live1;
-        const uint4 v0 = fetch(wb + grp, live0);
-        const uint4 v1 = fetch(wb + kPerWg + grp, live1);
-        keep(v0, live0);
-        if (wb + kPerWg < n_work) keep(v1, live1);
+      // loads in flight per lane (4 x 48 records per workgroup and trip: a round's ~320 records take two trips; eight in
+      // flight spill registers at 8 waves per SIMD and measured slower)
+      constexpr int kDepth = 4;
+      for (unsigned wb = (unsigned)(tid >> 6) * 12; wb < n_work; wb += kDepth * kPerWg) {   // wave-uniform trip count
+        bool live[kDepth];
+        uint4 v[kDepth];
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) v[d] = fetch(wb + d * kPerWg + grp, live[d]);
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d)
+          if (wb + d * kPerWg < n_work) keep(v[d], live[d]);
       }
     }
     __syncthreads();
