@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--skip-encode", action="store_true")
     p.add_argument("--corpus-passages", type=int, default=1_000_000,
                    help="passages of the corpus-scale encode leg (BASELINE.json configs[1]); 0 skips it")
+    p.add_argument("--cli-passages", type=int, default=200_000,
+                   help="text passages of the command-line encode leg (encode.cli_text); 0 skips it")
     p.add_argument("--skip-float32", action="store_true", help="skip the exact-float32 index leg")
     p.add_argument("--skip-cpu", action="store_true")
     p.add_argument("--skip-varlen", action="store_true", help="encode leg: full-length steps only (PMC traffic passes)")
@@ -271,7 +273,104 @@ def encode_leg(args, device, world, rank):
                                          f"BertForRetriever.get_embed (oracle/bert_torch_cpu.py), best of 3 passes"}
     if args.corpus_passages > 0:
         res["corpus_1m"] = corpus_leg(args, device, world, rank, model, sd)
+    if args.cli_passages > 0 and world == 1:
+        del model
+        torch.cuda.empty_cache()
+        res["cli_text"] = cli_text_leg(args, device, sd)
     return res
+
+
+def cli_text_leg(args, device, sd):
+    """Encode throughput through the product's own command line on TEXT ("report separately with real
+    text"): 200 000 synthetic ~100-word passages in a JSON-lines file -> proqa_amd.get_embed.main (JSONL read, WordPiece
+    tokenisation in --eval-workers DataLoader workers, collate, upload, encode, D2H, np.save), the reference's
+    retrieval/get_embed.py:29-139 end to end.  Reported: passages/s of the whole call and of its encode loop, the rate the
+    loader alone reaches (tokenise-only), and the fraction of the loop the GPU sat idle (HIP events around get_embed)."""
+    import shutil
+    import tempfile
+    from torch.utils.data import DataLoader
+    from proqa_amd import get_embed as ge
+    from proqa_amd.datasets import EmDataset, EmTextView, TokenizeCollate
+    from proqa_amd.retriever import BERT_BASE
+    n_pass = args.cli_passages
+    d = tempfile.mkdtemp(prefix="proqa_cli_")
+    try:
+        rng = np.random.default_rng(7)
+        letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+
+        def word():
+            return "".join(rng.choice(letters, size=int(rng.integers(3, 10))))
+        # a bert-base-shaped vocabulary: the special tokens where bert-base-uncased has them, single characters and
+        # their continuations, then whole words and word continuations up to 30 522 entries
+        vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"] + [f"[unused{i}]" for i in range(99, 994)]
+        chars = [chr(c) for c in range(33, 127) if not chr(c).isupper()]
+        vocab += chars + ["##" + c for c in chars if c.isalnum()]
+        words = set()
+        while len(words) < 16000:
+            words.add(word())
+        words = sorted(words)
+        pieces = set()
+        while len(vocab) + len(words) + len(pieces) < BERT_BASE["vocab_size"]:
+            pieces.add("##" + word()[:int(rng.integers(2, 5))])
+        vocab += words + sorted(pieces)
+        assert len(vocab) == BERT_BASE["vocab_size"] and len(set(vocab)) == len(vocab)
+        model_dir = os.path.join(d, "bert-base-synthetic")
+        os.makedirs(model_dir)
+        with open(os.path.join(model_dir, "vocab.txt"), "w") as f:
+            f.write("\n".join(vocab) + "\n")
+        with open(os.path.join(model_dir, "config.json"), "w") as f:
+            json.dump(dict(BERT_BASE, model_type="bert"), f)
+        torch.save(sd, os.path.join(d, "ckpt.pt"))
+        warr = np.array(words)
+        oov = np.array([word() + word() for _ in range(20000)])          # out-of-vocabulary: split into several pieces
+        with open(os.path.join(d, "paras.txt"), "w") as f:
+            for i0 in range(0, n_pass, 10000):
+                m = min(10000, n_pass - i0)
+                known = warr[rng.integers(0, len(warr), (m, 88))]
+                unknown = oov[rng.integers(0, len(oov), (m, 12))]
+                for r in range(m):
+                    text = " ".join(known[r]) + " " + " ".join(unknown[r])
+                    f.write(json.dumps({"id": f"p{i0 + r}", "text": text.capitalize() + "."}) + "\n")
+        cores = host_cores()
+        argv = ["--do_predict", "--predict_batch_size", str(args.encode_batch), "--bert_model_name", model_dir, "--fp16",
+                "--predict_file", os.path.join(d, "paras.txt"), "--init_checkpoint", os.path.join(d, "ckpt.pt"),
+                "--embed_save_path", os.path.join(d, "para_embed.npy"), "--eval-workers", str(cores),
+                "--max_seq_length", str(args.seq_len)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out_path = ge.main(argv)
+        dt = time.perf_counter() - t0
+        st = dict(ge.LAST_RUN_STATS)
+        emb = np.load(out_path, mmap_mode="r")
+        assert emb.shape == (n_pass, 128) and emb.dtype == np.float16
+        # the loader alone: the same dataset / collate / worker count, nothing consumed on the GPU
+        from transformers import BertTokenizer
+        tok = BertTokenizer.from_pretrained(model_dir)
+        ds = EmDataset(tok, os.path.join(d, "paras.txt"), 30, args.seq_len, False)
+        n_tok = min(n_pass, 60000)
+        view = torch.utils.data.Subset(EmTextView(ds), range(n_tok))
+        loader = DataLoader(view, batch_size=args.encode_batch, collate_fn=TokenizeCollate(tok, ds.max_length), pin_memory=True,
+                            num_workers=cores, **({"prefetch_factor": 4, "persistent_workers": True} if cores else {}))
+        t1 = time.perf_counter()
+        tokens = 0
+        for b in loader:
+            tokens += sum(b["seq_lens"])
+        t_tok = time.perf_counter() - t1
+        del loader
+        return {"metric": "passages/sec encoded from text through the get_embed.py command line", "value": n_pass / dt,
+                "unit": "passages/s", "passages": n_pass, "seconds": dt, "loader_workers": st.get("loader_workers"),
+                "host_cores": cores, "mean_tokens_per_passage": tokens / n_tok,
+                "encode_loop": {"passages_per_s": st["passages"] / st["loop_seconds"], "seconds": st["loop_seconds"],
+                                "gpu_busy_seconds": st["gpu_busy_seconds"],
+                                "gpu_idle_fraction": max(0.0, 1.0 - st["gpu_busy_seconds"] / st["loop_seconds"])},
+                "tokenise_only": {"passages_per_s": n_tok / t_tok, "passages": n_tok,
+                                  "note": "the same DataLoader (EmTextView + TokenizeCollate, pinned batches) with nothing "
+                                          "consumed on the GPU; includes the worker start-up"},
+                "workload": f"{n_pass} synthetic passages of 100 words (88 in-vocabulary, 12 split into word pieces) in a "
+                            f"JSON-lines file, bert-base-shaped 30 522-entry vocabulary, max_seq_length {args.seq_len}, batch "
+                            f"{args.encode_batch}; whole call = JSONL read + tokeniser + model/checkpoint load + encode + np.save"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def corpus_leg(args, device, world, rank, model, sd):
@@ -366,6 +465,97 @@ def launch_ranks(args):
     sys.stdout.write(lines[-1] + "\n")
     sys.stdout.flush()
     raise SystemExit(0)
+
+
+def kmeans_leg(args, device, xb):
+    """SURVEY section 8(f) row 1 on the driver's clock: retrieval/group_paras.py:20-53 at its default shape -- 10 000
+    centroids over 10M x 128 passage embeddings (1000 points per centroid: faiss' sub-sampling bound, so every point
+    trains) -- as Lloyd iterations of proqa_amd.group_paras.KMeans: 3 warm + 5 timed.  Roofline on kmeans_assign
+    (2 n k 272 flop per iteration: fp32 centroids as hi + lo fp16 parts, plus the norm step); the final assignment is
+    checked against the NumPy restatement of faiss' search on a sample of the points."""
+    from proqa_amd.group_paras import KMeans
+    n = min(10_000_000, xb.shape[0])
+    k = 10_000 if n >= 1_000_000 else max(8, n // 1000)
+    warm, timed_it = 3, 5
+    x = xb[:n]
+    km = KMeans(128, k, niter=warm + timed_it, max_points_per_centroid=n // k + 1, verbose=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    km.train(x)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    it_s = float(np.mean(km.iter_seconds[warm:]))
+    assign_s = float(np.mean(km.assign_ms[warm:])) / 1e3
+    flops = 2.0 * n * k * 272
+    tf = flops / assign_s / 1e12
+    out = {"metric": "k-means Lloyd iterations/sec (group_paras.py shape)", "value": 1.0 / it_s, "unit": "iterations/s",
+           "ms_per_iteration": it_s * 1e3, "points": n, "centroids": k, "iterations_warm": warm, "iterations_timed": timed_it,
+           "seconds_whole_train_call": total, "dtype": "f16 points x (hi + lo f16) centroids, f32 accumulate",
+           "objective": km.obj[-1],
+           "roofline": {"bound": "mfma", "kernel": "kmeans_assign", "achieved": tf, "peak": PEAK_MFMA_F16_TFLOPS,
+                        "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_F16_TFLOPS, "assign_ms": assign_s * 1e3,
+                        "note": "2 n k 272 flop per iteration / HIP-event time of the assign launch (mean of the timed iterations)"}}
+    if not args.skip_cpu:
+        from oracle import kmeans_oracle
+        ns = min(20_000, n)
+        sel = torch.linspace(0, n - 1, ns, device=device).long()
+        xs = x[sel].contiguous()
+        D, I = km.assign(xs)
+        cen = km.centroids.cpu().numpy()
+        xs_np = xs.cpu().numpy()
+        t1 = time.perf_counter()
+        Do, Io = [], []
+        for r0 in range(0, ns, 2000):                       # blocks: the float64 distance matrix is k columns wide
+            d_, i_ = kmeans_oracle.assign(xs_np[r0:r0 + 2000], cen, True)
+            Do.append(d_)
+            Io.append(i_)
+        cpu_s = time.perf_counter() - t1
+        Do, Io = np.concatenate(Do), np.concatenate(Io)
+        Dg, Ig = D.cpu().numpy(), I.cpu().numpy()
+        out["parity"] = {"sample": f"{ns} points x {k} centroids vs oracle/kmeans_oracle.py (float64 distances)",
+                         "assignment_agreement": float((Ig == Io).mean()),
+                         "objective_rel_diff": float(abs(Dg.astype(np.float64).sum() - Do.astype(np.float64).sum()) /
+                                                     max(Do.astype(np.float64).sum(), 1e-30))}
+        out["cpu_baseline"] = {"value": ns / cpu_s / n, "unit": "iterations/s (assign step only)", "cores": host_cores(),
+                               "kind": "port", "sample": f"nearest centroid of {ns} points among {k} (NumPy restatement of "
+                                                         f"faiss index.search(x, 1), {cpu_s:.1f} s), scaled to {n} points"}
+    return out
+
+
+def online_leg(args, device, index, n_rows):
+    """SURVEY section 8(f) row 4 on the driver's clock: the retrieval step of qa/online_sampler.py:104-121 for ONE question
+    -- encode with the query tower (bert-base shape, random weights), exact search over the resident index, row gather
+    (para_embed[I]) -- through proqa_amd.online_retriever.OnlineRetriever; k = 80 and k = 5000 (the sampler's training k).
+    Median of 50 questions each."""
+    from proqa_amd.online_retriever import OnlineRetriever
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
+    model = BertForRetriever(BERT_BASE, device=device)
+    model.load_state_dict(random_state_dict(BERT_BASE, seed=0))
+    r = OnlineRetriever(np.float16, None, device=device, index=index)
+    g = torch.Generator(device=device).manual_seed(5)
+    mask = torch.ones((1, 16), dtype=torch.bool, device=device)
+    out = {"metric": "ms per question: encode + exact top-k + row gather (online sampler step)", "unit": "ms",
+           "rows": n_rows, "question_tokens": 16, "questions": 50}
+    for k in (80, 5000):
+        enc, ret = [], []
+        for i in range(55):
+            tok = torch.randint(1000, 30522, (1, 16), generator=g, device=device)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            q = model.get_embed({"input_ids": tok, "input_mask": mask}, True, check_mask=False, seq_lens_host=[16])["embed"]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            idx, _, rows = r.retrieve(q, k)
+            t2 = time.perf_counter()
+            if i >= 5:
+                enc.append(t1 - t0)
+                ret.append(t2 - t1)
+        assert idx.shape == (min(k, n_rows),) and rows.shape == (min(k, n_rows), 128)
+        out[f"k{k}"] = {"ms_per_question": float(np.median(np.array(enc) + np.array(ret)) * 1e3),
+                        "encode_ms": float(np.median(enc) * 1e3), "retrieve_ms": float(np.median(ret) * 1e3)}
+    out["value"] = out["k5000"]["ms_per_question"]
+    out["higher_is_better"] = False
+    return out
 
 
 def main():
@@ -521,6 +711,10 @@ def main():
         torch.cuda.empty_cache()
         line["large_k"] = large
         line["peak_measured"] = measured_peaks(device)
+        # the other "next" rows of SURVEY section 8(f), on the same resident rows
+        line["kmeans"] = kmeans_leg(args, device, xb)
+        line["online"] = online_leg(args, device, sharded.local_index, hi - lo)
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.skip_cpu:   # CPU baselines: single-GPU runs only (contract)
         # CPU baseline + id parity on a bounded sample of the same workload

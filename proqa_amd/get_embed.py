@@ -21,7 +21,7 @@ from torch.utils.data import DataLoader, Subset
 
 from . import npy
 from .config import get_args
-from .datasets import EmDataset, em_collate
+from .datasets import EmDataset, EmTextView, TokenizeCollate
 from .retriever import BertForRetriever, config_from_dict
 from .utils import move_to_cuda
 
@@ -53,6 +53,21 @@ def _dist_env(args):
     return 1, 0, 0
 
 
+LAST_RUN_STATS = {}     # filled by main(): see predict(stats=...) (bench.py's encode.cli_text reads it)
+
+
+def usable_cpus():
+    """CPUs this process may use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 # Batches in flight.  Two streams overlapped one batch's HBM-bound kernels with the other's GEMMs for
 # ~2.5 %, but two hipBLASLt stream-K GEMMs running concurrently deadlock (their workgroups spin on
 # partial tiles of partners that cannot be scheduled) as soon as M is not a multiple of the tile --
@@ -66,9 +81,15 @@ def _right_padded(mask):
     return mask.shape[1] < 2 or not bool((mask[:, 1:] & ~mask[:, :-1]).any())
 
 
-def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=True):
+def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=True, stats=None):
     """The reference's hot loop: move batch to the GPU, get_embed, keep embeddings on device.
-    Batches alternate between N_STREAMS HIP streams (order of the results is kept)."""
+    Batches alternate between N_STREAMS HIP streams (order of the results is kept).
+    A batch may carry its valid lengths as the host list 'seq_lens' (TokenizeCollate does); a batch of the reference's
+    shape (ids + mask only) has them taken from the mask.
+    stats (optional dict): filled with 'batches', 'passages', 'gpu_busy_seconds' (HIP-event time of the get_embed calls)
+    and 'loop_seconds' (wall time of the loop incl. the wait for the last batch) -- what a run needs to tell whether the
+    host kept the GPU fed."""
+    import time
     model.eval()
     if fp16:
         model.half()
@@ -77,17 +98,31 @@ def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=Tru
     main = torch.cuda.current_stream(device)
     for s in streams:
         s.wait_stream(main)     # pool streams are non-blocking: order them after the weight preparation on `main`
+    events = []
+    t_loop = time.perf_counter()
     for i, batch in enumerate(eval_dataloader):
-        if not _right_padded(batch["input_mask"]):
-            raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
-        lens = batch["input_mask"].sum(dim=1).tolist()      # host-side: lets the encoder skip the padding
+        lens = batch.pop("seq_lens", None) if isinstance(batch, dict) else None
+        if lens is None:
+            if not _right_padded(batch["input_mask"]):
+                raise ValueError("input_mask must be right-padded (a prefix of True per row), as em_collate produces")
+            lens = batch["input_mask"].sum(dim=1).tolist()      # host-side: lets the encoder skip the padding
         s = streams[i % N_STREAMS]
         with torch.cuda.stream(s), torch.no_grad():
             batch_to_feed = move_to_cuda(batch)
+            if stats is not None:
+                events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+                events[-1][0].record()
             chunks.append(model.get_embed(batch_to_feed, is_query_embed, check_mask=False,
                                           seq_lens_host=lens)["embed"])
+            if stats is not None:
+                events[-1][1].record()
     for s in streams:
         main.wait_stream(s)
+    if stats is not None:
+        torch.cuda.synchronize(device)
+        stats.update(batches=len(chunks), passages=int(sum(c.shape[0] for c in chunks)),
+                     gpu_busy_seconds=sum(a.elapsed_time(b) for a, b in events) / 1e3,
+                     loop_seconds=time.perf_counter() - t_loop)
     if chunks:
         embeds = torch.cat(chunks)
     else:
@@ -136,9 +171,13 @@ def main(argv=None):
     dataset = EmDataset(tokenizer, args.predict_file, args.max_query_length, args.max_seq_length, is_query_embed)
     n_total = len(dataset)
     lo, hi = (n_total * rank) // world, (n_total * (rank + 1)) // world
-    part = dataset if world == 1 else Subset(dataset, range(lo, hi))
-    loader = DataLoader(part, batch_size=args.predict_batch_size, collate_fn=em_collate, pin_memory=True,
-                        num_workers=args.eval_workers)
+    # the loader hands over whole tokenised batches (datasets.TokenizeCollate: same ids / masks as EmDataset + em_collate);
+    # workers beyond the CPUs this process may use only cost memory and context switches
+    texts = EmTextView(dataset)
+    part = texts if world == 1 else Subset(texts, range(lo, hi))
+    workers = max(0, min(args.eval_workers, usable_cpus()))
+    loader = DataLoader(part, batch_size=args.predict_batch_size, collate_fn=TokenizeCollate(tokenizer, dataset.max_length),
+                        pin_memory=True, num_workers=workers, **({"prefetch_factor": 4, "persistent_workers": True} if workers else {}))
 
     assert args.init_checkpoint != ""
     model = load_saved(model, args.init_checkpoint)
@@ -150,7 +189,10 @@ def main(argv=None):
         want_half = args.embed_dtype in ("float16", "fp16", "f2")
     model.half() if want_half else model.float()
 
-    embeds = predict(args, model, loader, device, fp16=args.efficient_eval, is_query_embed=is_query_embed)
+    LAST_RUN_STATS.clear()
+    embeds = predict(args, model, loader, device, fp16=args.efficient_eval, is_query_embed=is_query_embed, stats=LAST_RUN_STATS)
+    LAST_RUN_STATS["loader_workers"] = workers
+    del loader
     local = embeds.cpu().numpy()
     out_path = npy.save_path(args.embed_save_path)
     if world == 1:

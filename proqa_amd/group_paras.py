@@ -49,6 +49,8 @@ class KMeans:
         self.l2 = not spherical_metric
         self.centroids = None
         self.obj = []
+        self.iter_seconds = []      # wall time of every Lloyd iteration (assign + objective + update + void split)
+        self.assign_ms = []         # HIP-event time of its nearest-centroid search alone
         self._lib = _lib.load()
         _lib.require_gpu()
 
@@ -108,13 +110,20 @@ class KMeans:
         counts = torch.empty(self.k, dtype=torch.int32, device=x.device)
         h = self._handle(nx)
         try:
+            import time
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             for it in range(self.niter):
+                t_it = time.perf_counter()
+                ev[0].record()
                 D, I = self._assign(h, x, centroids)
+                ev[1].record()
                 err = float(D.double().sum())
                 self.obj.append(err)
                 _lib.check(self._lib.proqa_kmeans_update_device(h, x.data_ptr(), nx, I.data_ptr(), centroids.data_ptr(),
                                                                 counts.data_ptr(), _lib.current_stream_ptr()))
                 nsplit = self._split_empty(centroids, counts, nx)
+                self.assign_ms.append(ev[0].elapsed_time(ev[1]))
+                self.iter_seconds.append(time.perf_counter() - t_it)
                 if self.verbose:
                     print(f"  Iteration {it} objective={err:g} nsplit={nsplit}")
         finally:
@@ -153,7 +162,9 @@ def clusering(data, niter=1000, verbose=True, ncentroids=1024, max_points_per_ce
             inexact += int((x[r0:r0 + step].float() != piece).sum())     # NaN counts as inexact: refused as well
     if inexact:
         raise ValueError(f"{inexact} float32 values are not representable in fp16; clustering them would round the "
-                         "points silently. Pass allow_fp16_rounding=True (--allow-fp16-rounding) to accept that.")
+                         "points silently.  Either pass allow_fp16_rounding=True (group_paras.py --allow-fp16-rounding) to "
+                         "accept the rounding, or cluster an fp16 index: get_embed.py --fp16 (or --embed_dtype float16) "
+                         "writes '<f2' embeddings, whose float32 upcast is exact.")
     km = KMeans(x.shape[1], ncentroids, niter=niter, max_points_per_centroid=max_points_per_centroid, verbose=verbose,
                 spherical_metric=spherical)
     with torch.cuda.device(device):

@@ -18,18 +18,25 @@ from .index import IndexFlatIP
 
 
 class OnlineRetriever:
-    def __init__(self, para_embed, index2paraid=None, device=None):
+    def __init__(self, para_embed, index2paraid=None, device=None, index=None):
         """para_embed: [N,128] float16/float32 array (the np.load'ed index, qa/train_retrieve_qa.py:115);
         index2paraid: the idx_id.json mapping {"<row>": paragraph id} (the reference's format), a row-ordered
         sequence of paragraph ids (ten times cheaper per lookup: at k = 5000 the dict route costs ~3 ms per question,
-        more than the encode and the search together), or None."""
+        more than the encode and the search together), or None.
+        index: an IndexFlatIP that already holds the rows in HBM (then para_embed may be None or just a dtype: the
+        rows the sampler gathers come from the index's copy either way)."""
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        para_embed = np.ascontiguousarray(para_embed)
-        with torch.cuda.device(self.device):      # proqa_index_create binds the index to the current device
-            self.index = IndexFlatIP(128, capacity=para_embed.shape[0])
-            step = 1 << 21
-            for r0 in range(0, para_embed.shape[0], step):
-                self.index.add(para_embed[r0:r0 + step])
+        if index is not None:
+            self.index = index
+            self.dtype = np.dtype(para_embed.dtype if hasattr(para_embed, "dtype") else (para_embed or np.float16))
+        else:
+            para_embed = np.ascontiguousarray(para_embed)
+            with torch.cuda.device(self.device):      # proqa_index_create binds the index to the current device
+                self.index = IndexFlatIP(128, capacity=para_embed.shape[0])
+                step = 1 << 21
+                for r0 in range(0, para_embed.shape[0], step):
+                    self.index.add(para_embed[r0:r0 + step])
+            self.dtype = para_embed.dtype
         self.para_embed = para_embed
         self.index2paraid = index2paraid
 
@@ -52,12 +59,12 @@ class OnlineRetriever:
             q = torch.from_numpy(np.ascontiguousarray(np.asarray(q_embed).reshape(1, -1))).to(self.device)
         _, I = self.index.search_device(q, k)
         I = I.reshape(-1)
-        want = torch.float16 if self.para_embed.dtype == np.float16 else torch.float32
+        want = torch.float16 if self.dtype == np.float16 else torch.float32
         rows = self.index.reconstruct_batch_device(I, want)
         para_embed_idx = I.cpu().numpy()
         live = para_embed_idx >= 0                                   # fewer than k rows in the index
         para_embed_idx = para_embed_idx[live]
-        para_embeds = rows.cpu().numpy()[live].astype(self.para_embed.dtype, copy=False)
+        para_embeds = rows.cpu().numpy()[live].astype(self.dtype, copy=False)
         para_idx = None
         if self.index2paraid is not None:
             # (tolist() first: str() of a Python int is four times cheaper than of a numpy scalar, and at k = 5000 this

@@ -5,13 +5,13 @@ set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/${1:-profile}
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --skip-cpu --steps 10 --corpus-passages 0 --skip-extras --skip-float32 > $OUT/bench_trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --skip-extras --skip-float32 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --skip-extras --skip-float32 > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --skip-extras --skip-float32 > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_grbm -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --skip-extras --skip-float32 > $OUT/pmc_grbm.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python3 bench.py --skip-cpu --steps 10 --corpus-passages 0 --cli-passages 0 --skip-extras --skip-float32 > $OUT/bench_trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --cli-passages 0 --skip-extras --skip-float32 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --cli-passages 0 --skip-extras --skip-float32 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --cli-passages 0 --skip-extras --skip-float32 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_grbm -o bench -- python3 bench.py --skip-cpu --skip-encode --steps 2 --warmup 1 --corpus-passages 0 --cli-passages 0 --skip-extras --skip-float32 > $OUT/pmc_grbm.log 2>&1
 # encoder: MFMA-pipe occupancy and clock per kernel (token-size search so that the encode leg dominates)
-ENC="--skip-cpu --rows 200000 --queries 64 --steps 1 --warmup 1 --encode-steps 3 --corpus-passages 0 --skip-extras --skip-float32"
+ENC="--skip-cpu --rows 200000 --queries 64 --steps 1 --warmup 1 --encode-steps 3 --corpus-passages 0 --cli-passages 0 --skip-extras --skip-float32"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/enc_pmc_sq -o bench -- python3 bench.py $ENC > $OUT/enc_pmc_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/enc_pmc_grbm -o bench -- python3 bench.py $ENC > $OUT/enc_pmc_grbm.log 2>&1
 # encoder HBM traffic: full-size steps only, FETCH_SIZE and WRITE_SIZE in passes of their own

@@ -4,7 +4,8 @@ BertForRetriever.get_embed against outputs of the reference's own model (encoder
 Tolerances (stated per north_star "within the tolerance ... written in the test"): activations
 and weights are fp16 with fp32 accumulation/statistics, the oracle is fp32.  One fp16 rounding
 is 2^-11 relative (4.9e-4); per-kernel checks allow 2e-3 + 2e-3*|ref|; the end-to-end embedding
-(|values| ~ 0.1-1 after tanh + projection) allows 1e-2 absolute and cosine >= 0.9995.
+(|values| ~ 0.1-1 after tanh + projection) allows 1.5e-3 absolute on the small golden model (measured 3.9e-4) and
+4e-3 absolute / cosine >= 0.9999 at bert-base depth (measured 1.3e-3): a regression that triples the error fails.
 """
 import ctypes
 import json
@@ -269,6 +270,12 @@ def cosine(a, b):
     return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
 
 
+# end-to-end embedding bounds (fp16 weights / activations against the fp32 oracle): ~3x what is measured
+TOL_GOLDEN = 1.5e-3      # 2-layer golden model: measured 3.9e-4
+TOL_BERT_BASE = 4e-3     # bert-base width, up to 12 layers: measured 1.3e-3
+COS_MIN = 0.9999
+
+
 def test_get_embed_matches_reference_outputs(gpu_device):
     """The reference call shape on the reference's own golden outputs (both towers)."""
     from proqa_amd.retriever import BertForRetriever
@@ -282,16 +289,16 @@ def test_get_embed_matches_reference_outputs(gpu_device):
         out = model.get_embed(batch, is_q)["embed"]
         assert out.shape == (32, 128) and out.dtype == torch.float16 and out.is_cuda
         got = out.float().cpu().numpy()
-        assert np.abs(got - z[key]).max() < 1e-2
-        assert cosine(got, z[key]).min() > 0.9995
+        assert np.abs(got - z[key]).max() < TOL_GOLDEN
+        assert cosine(got, z[key]).min() > COS_MIN
     # float() switches the emitted dtype like the reference's non-fp16 run
     out32 = model.float().get_embed(batch, False)["embed"]
     assert out32.dtype == torch.float32
-    assert np.abs(out32.cpu().numpy() - z["embed_c"]).max() < 1e-2
+    assert np.abs(out32.cpu().numpy() - z["embed_c"]).max() < TOL_GOLDEN
     # padding invariance: a row alone equals the same row inside a padded batch
     single = {"input_ids": batch["input_ids"][1:2, :3], "input_mask": batch["input_mask"][1:2, :3]}
     alone = model.get_embed(single, False)["embed"].cpu().numpy()
-    assert np.abs(alone - z["embed_c_row1_unpadded"]).max() < 1e-2
+    assert np.abs(alone - z["embed_c_row1_unpadded"]).max() < TOL_GOLDEN
     assert np.abs(alone[0] - out32[1].cpu().numpy()).max() < 2e-3
 
 
@@ -318,8 +325,8 @@ def test_bert_base_shape_against_oracle(gpu_device):
         for packed in (True, False):
             model.cls_only_last_layer, model.pack_tokens = cls_only, packed
             got[cls_only, packed] = model.get_embed(batch, False)["embed"].float().cpu().numpy()
-            assert np.abs(got[cls_only, packed] - ref).max() < 1e-2
-            assert cosine(got[cls_only, packed], ref).min() > 0.9995
+            assert np.abs(got[cls_only, packed] - ref).max() < TOL_BERT_BASE
+            assert cosine(got[cls_only, packed], ref).min() > COS_MIN
     for key, val in got.items():
         assert np.abs(val - got[True, True]).max() < 3e-3, key
     # lengths handed over from the host (predict()) instead of read back from the device
@@ -353,8 +360,8 @@ def test_question_sized_batches_against_oracle(gpu_device, lens):
             for packed in (True, False):
                 model.cls_only_last_layer, model.pack_tokens = cls_only, packed
                 got = model.get_embed(batch, is_query)["embed"].float().cpu().numpy()
-                assert np.abs(got - ref).max() < 1e-2, (is_query, cls_only, packed)
-                assert cosine(got, ref).min() > 0.9995
+                assert np.abs(got - ref).max() < TOL_BERT_BASE, (is_query, cls_only, packed)
+                assert cosine(got, ref).min() > COS_MIN
 
 
 def test_rejects_bad_inputs(gpu_device):
@@ -398,7 +405,54 @@ def test_ragged_full_length_batch(gpu_device):
     for cls_only in (True, False):
         model.cls_only_last_layer = cls_only
         got = model.get_embed(batch, False)["embed"].float().cpu().numpy()
-        assert np.abs(got - ref).max() < 1e-2
+        assert np.abs(got - ref).max() < TOL_BERT_BASE
+
+
+def test_configs1_batch_512_through_predict_and_npy(gpu_device, tmp_path):
+    """BASELINE.json configs[1] at its own shape: bert-base x 12 layers, batches of 512 x 128 through the product's loop
+    (get_embed.predict -> torch.cat -> D2H -> npy.save).  A 512-passage batch is 65 536 token rows: the fused dense + bias +
+    GELU kernel (proqa_gemm_tn_f16) and the [CLS]-only last layer really run, which the 6-passage test above does not
+    reach.  Three batches: full length, lengths ~U[32,128] (valid tokens packed), and the ragged 64-passage tail of a
+    1M-passage corpus (1M = 1953 x 512 + 64).  Rows are independent of their batch, so the NumPy oracle is run on 14 rows
+    spread over the batches only."""
+    from types import SimpleNamespace
+    from proqa_amd import npy
+    from proqa_amd.get_embed import predict
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
+    sd = {k: v.half().float() for k, v in random_state_dict(BERT_BASE, seed=0).items()}
+    model = BertForRetriever(BERT_BASE, device=gpu_device)
+    model.load_state_dict(sd)
+    model.half()
+    B, S = 512, 128
+    g = torch.Generator().manual_seed(4)
+    full = torch.randint(1000, 30522, (B, S), generator=g, dtype=torch.int64)
+    full[:, 0], full[:, -1] = 101, 102
+    lens = torch.randint(32, S + 1, (B,), generator=g)
+    vmask = torch.arange(S)[None, :] < lens[:, None]
+    vids = torch.where(vmask, torch.randint(1000, 30522, (B, S), generator=g, dtype=torch.int64), torch.zeros((), dtype=torch.int64))
+    vids[:, 0] = 101
+    vids[torch.arange(B), lens - 1] = 102
+    tail = torch.randint(1000, 30522, (64, S), generator=g, dtype=torch.int64)
+    tail[:, 0], tail[:, -1] = 101, 102
+    batches = [{"input_ids": full, "input_mask": torch.ones((B, S), dtype=torch.bool)},
+               {"input_ids": vids, "input_mask": vmask},
+               {"input_ids": tail, "input_mask": torch.ones((64, S), dtype=torch.bool)}]
+    embeds = predict(SimpleNamespace(), model, iter(batches), gpu_device, is_query_embed=False)
+    assert embeds.shape == (2 * B + 64, 128) and embeds.dtype == torch.float16
+    path = str(tmp_path / "para_embed.npy")
+    npy.save(path, embeds.cpu().numpy())
+    back = np.load(path)                                   # numpy reads what the product wrote
+    assert back.shape == (2 * B + 64, 128) and back.dtype == np.float16
+    rows = [0, 1, 63, 200, 255, 256, 400, 511,             # the full-length batch: both halves of every 256-row GEMM tile
+            B + 3, B + 77, B + 300, B + 511,               # the packed variable-length batch
+            2 * B, 2 * B + 63]                             # the ragged tail
+    all_ids = torch.cat([b["input_ids"] for b in batches]).numpy()
+    all_mask = torch.cat([b["input_mask"] for b in batches]).numpy()
+    sd_np = {k: v.numpy() for k, v in sd.items()}
+    ref = bert_oracle.get_embed(sd_np, all_ids[rows], all_mask[rows], False, 12, 12)
+    got = back[rows].astype(np.float32)
+    assert np.abs(got - ref).max() < TOL_BERT_BASE, np.abs(got - ref).max(axis=1)
+    assert cosine(got, ref).min() > COS_MIN
 
 
 def test_randomised_encoder_fuzz(gpu_device):

@@ -44,3 +44,83 @@ def test_collate_edge_cases():
     assert datasets.collate_tokens([a, b], 0).tolist() == [[1, 2, 3], [4, 0, 0]]
     assert datasets.collate_tokens([a, b], 9, left_pad=True).tolist() == [[1, 2, 3], [9, 9, 4]]
     assert datasets.collate_tokens([a], 0, eos_idx=3, move_eos_to_beginning=True).tolist() == [[3, 1, 2]]
+
+
+def _random_strings(n, seed):
+    import random
+    rng = random.Random(seed)
+    vocab = [w.strip() for w in open(os.path.join(GOLDEN, "vocab_small.txt"))]
+    words = [w for w in vocab if w.isalpha()]
+    odd = [0x20, 0x9, 0xa, 0xd, 0xa0, 0x2003, 0x200b, 0x3000, 0xad, 0x0, 0xfffd, 0x7f, 0x85]
+
+    def one():
+        out = []
+        for _ in range(rng.randrange(0, 70)):
+            r = rng.random()
+            if r < 0.5:
+                out.append(rng.choice(words))
+            elif r < 0.6:
+                out.append(rng.choice(words).upper())
+            elif r < 0.7:
+                out.append(chr(rng.choice(odd)))
+            elif r < 0.8:
+                out.append(chr(rng.randrange(0x20, 0x7f)))
+            elif r < 0.9:
+                out.append(chr(rng.randrange(0xa0, 0x3000)))
+            elif r < 0.95:
+                out.append(chr(rng.randrange(0x4e00, 0x9fff)))
+            else:
+                out.append("".join(chr(rng.randrange(0x300, 0x36f)) for _ in range(2)))
+        return " ".join(out) if rng.random() < 0.7 else "".join(out)
+
+    return [one() for _ in range(n)] + ["", " ", "a" * 300, "é" * 50, "İstanbul ǅ ß ﬁ", "[SEP] x [CLS]"]
+
+
+def test_batch_tokenising_collate_matches_reference_batches(tokenizer, tmp_path):
+    """get_embed.py's loader (EmTextView + TokenizeCollate: one tokenizer call per batch inside the workers) produces the
+    reference's batches: the golden ones, bit for bit, plus the valid lengths as a host list."""
+    with open(os.path.join(GOLDEN, "tokenize_golden.json")) as f:
+        gold = json.load(f)
+    for case in gold["cases"]:
+        key = "question" if case["is_query"] else "text"
+        path = tmp_path / "in.jsonl"
+        path.write_text("".join(json.dumps({key: t, "id": 0}) + "\n" for t in gold["texts"]))
+        ds = datasets.EmDataset(tokenizer, str(path), case["max_query_length"], case["max_length"], case["is_query"])
+        view = datasets.EmTextView(ds)
+        assert len(view) == len(gold["texts"]) and view[3] == gold["texts"][3]
+        batch = datasets.TokenizeCollate(tokenizer, ds.max_length)([view[i] for i in range(len(view))])
+        assert batch["input_ids"].dtype == torch.int64 and batch["input_mask"].dtype == torch.bool
+        assert batch["input_ids"].tolist() == case["input_ids"]
+        assert batch["input_mask"].int().tolist() == case["input_mask"]
+        assert batch["seq_lens"] == case["item_lengths"]
+    assert datasets.TokenizeCollate(tokenizer, 30)([]) == {}
+
+
+def test_batch_tokenising_collate_equals_the_per_item_path_on_random_strings(tokenizer, tmp_path):
+    """5000 random strings (words of the vocabulary, upper case, ASCII and non-ASCII symbols, CJK, combining marks,
+    control and odd space characters, literal special tokens): per batch of 64, ids / masks identical to EmDataset +
+    em_collate, for the query and the passage length limits; also through DataLoader workers (the collate is pickled)."""
+    from torch.utils.data import DataLoader
+    texts = _random_strings(5000, 17)
+    path = tmp_path / "rand.jsonl"
+    path.write_text("".join(json.dumps({"text": t, "question": t}) + "\n" for t in texts))
+    for is_query, limit in ((True, 30), (False, 512), (False, 16)):
+        ds = datasets.EmDataset(tokenizer, str(path), limit if is_query else 30, limit, is_query)
+        view = datasets.EmTextView(ds)
+        collate = datasets.TokenizeCollate(tokenizer, ds.max_length)
+        for b0 in range(0, len(ds), 64):
+            idx = range(b0, min(b0 + 64, len(ds)))
+            want = datasets.em_collate([ds[i] for i in idx])
+            got = collate([view[i] for i in idx])
+            assert torch.equal(got["input_ids"], want["input_ids"]), (is_query, limit, b0)
+            assert torch.equal(got["input_mask"], want["input_mask"]), (is_query, limit, b0)
+            assert got["seq_lens"] == want["input_mask"].sum(1).tolist()
+    loader = DataLoader(view, batch_size=100, collate_fn=collate, num_workers=2)
+    n = 0
+    for b, batch in enumerate(loader):
+        want = datasets.em_collate([ds[i] for i in range(b * 100, min(b * 100 + 100, len(ds)))])
+        assert torch.equal(batch["input_ids"], want["input_ids"])
+        n += batch["input_ids"].shape[0]
+        if b == 5:
+            break
+    assert n == 600

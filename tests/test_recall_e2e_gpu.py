@@ -1,5 +1,5 @@
 """Synthetic end-to-end run (BASELINE.json configs[4] / SURVEY section 8d config 5 stand-in): a
-20k-passage corpus with planted answers is encoded by get_embed.py on the GPU, searched by
+100k-passage corpus with planted answers is encoded by get_embed.py on the GPU, searched by
 eval_retrieval.py on the GPU, and the printed Recall@k lines are compared with the CPU NumPy search
 on the SAME embeddings + the (reference-pinned) host scorer: |delta| <= 1e-4 (north_star)."""
 import json
@@ -16,7 +16,7 @@ from oracle import search_oracle
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-N_DOCS, N_QA, TOPK = 20000, 150, 80
+N_DOCS, N_QA, TOPK = 100000, 150, 80
 
 
 @pytest.fixture(scope="module")
@@ -61,7 +61,7 @@ def test_recall_lines_match_cpu_path(gpu_device, corpus, capsys):
     from proqa_amd import eval_retrieval, gen_index_id_map, get_embed
     d = corpus
     common = ["--do_predict", "--bert_model_name", str(d / "small-bert"), "--fp16", "--init_checkpoint",
-              str(d / "ckpt.pt"), "--eval-workers", "0", "--predict_batch_size", "512"]
+              str(d / "ckpt.pt"), "--eval-workers", "8", "--predict_batch_size", "512"]
     para = get_embed.main(common + ["--predict_file", str(d / "paras.txt"), "--embed_save_path", str(d / "para_embed.npy")])
     qry = get_embed.main(common + ["--predict_file", str(d / "qa.txt"), "--is_query_embed", "--embed_save_path",
                                    str(d / "q_embed.npy")])
