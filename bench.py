@@ -283,14 +283,13 @@ def encode_leg(args, device, world, rank):
 def cli_text_leg(args, device, sd):
     """Encode throughput through the product's own command line on TEXT ("report separately with real
     text"): 200 000 synthetic ~100-word passages in a JSON-lines file -> proqa_amd.get_embed.main (JSONL read, WordPiece
-    tokenisation in --eval-workers DataLoader workers, collate, upload, encode, D2H, np.save), the reference's
+    tokenisation on --eval-workers threads, collate, upload, encode, D2H, np.save), the reference's
     retrieval/get_embed.py:29-139 end to end.  Reported: passages/s of the whole call and of its encode loop, the rate the
     loader alone reaches (tokenise-only), and the fraction of the loop the GPU sat idle (HIP events around get_embed)."""
     import shutil
     import tempfile
-    from torch.utils.data import DataLoader
     from proqa_amd import get_embed as ge
-    from proqa_amd.datasets import EmDataset, EmTextView, TokenizeCollate
+    from proqa_amd.datasets import EmDataset, EmTextView, TextBatchLoader, TokenizeCollate
     from proqa_amd.retriever import BERT_BASE
     n_pass = args.cli_passages
     d = tempfile.mkdtemp(prefix="proqa_cli_")
@@ -348,24 +347,23 @@ def cli_text_leg(args, device, sd):
         tok = BertTokenizer.from_pretrained(model_dir)
         ds = EmDataset(tok, os.path.join(d, "paras.txt"), 30, args.seq_len, False)
         n_tok = min(n_pass, 60000)
-        view = torch.utils.data.Subset(EmTextView(ds), range(n_tok))
-        loader = DataLoader(view, batch_size=args.encode_batch, collate_fn=TokenizeCollate(tok, ds.max_length), pin_memory=True,
-                            num_workers=cores, **({"prefetch_factor": 4, "persistent_workers": True} if cores else {}))
+        loader = TextBatchLoader(EmTextView(ds), args.encode_batch, TokenizeCollate(tok, ds.max_length, parallel=True), prefetch=8,
+                                 lo=0, hi=n_tok)
         t1 = time.perf_counter()
         tokens = 0
         for b in loader:
             tokens += sum(b["seq_lens"])
         t_tok = time.perf_counter() - t1
-        del loader
         return {"metric": "passages/sec encoded from text through the get_embed.py command line", "value": n_pass / dt,
                 "unit": "passages/s", "passages": n_pass, "seconds": dt, "loader_workers": st.get("loader_workers"),
                 "host_cores": cores, "mean_tokens_per_passage": tokens / n_tok,
                 "encode_loop": {"passages_per_s": st["passages"] / st["loop_seconds"], "seconds": st["loop_seconds"],
-                                "gpu_busy_seconds": st["gpu_busy_seconds"],
+                                "gpu_busy_seconds": st["gpu_busy_seconds"], "loader_wait_seconds": st["loader_wait_seconds"],
+                                "feed_seconds": st["feed_seconds"], "upload_seconds": st["upload_seconds"],
                                 "gpu_idle_fraction": max(0.0, 1.0 - st["gpu_busy_seconds"] / st["loop_seconds"])},
                 "tokenise_only": {"passages_per_s": n_tok / t_tok, "passages": n_tok,
-                                  "note": "the same DataLoader (EmTextView + TokenizeCollate, pinned batches) with nothing "
-                                          "consumed on the GPU; includes the worker start-up"},
+                                  "note": "the same loader (TextBatchLoader: one producer thread, the tokenizer's thread "
+                                          "pool of cores - 2) with nothing consumed on the GPU"},
                 "workload": f"{n_pass} synthetic passages of 100 words (88 in-vocabulary, 12 split into word pieces) in a "
                             f"JSON-lines file, bert-base-shaped 30 522-entry vocabulary, max_seq_length {args.seq_len}, batch "
                             f"{args.encode_batch}; whole call = JSONL read + tokeniser + model/checkpoint load + encode + np.save"}

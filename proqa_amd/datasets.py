@@ -94,9 +94,12 @@ class TokenizeCollate:
     copy (own truncation setting, one thread per DataLoader worker: the workers are the parallelism); any other tokenizer
     is called sentence by sentence, as the reference does."""
 
-    def __init__(self, tokenizer, max_length):
+    def __init__(self, tokenizer, max_length, parallel=False):
+        """parallel: let the tokenizer library spread a batch over its own thread pool (TextBatchLoader: one producer
+        thread in the process that feeds the GPU); off inside DataLoader workers, which are the parallelism there."""
         self.tokenizer = tokenizer
         self.max_length = int(max_length)
+        self.parallel = bool(parallel)
         self._backend_json = None
         backend = getattr(tokenizer, "backend_tokenizer", None) or getattr(tokenizer, "_tokenizer", None)
         if backend is not None and hasattr(backend, "encode_batch") and hasattr(backend, "to_str"):
@@ -113,10 +116,25 @@ class TokenizeCollate:
             return [self.tokenizer.encode(t, max_length=self.max_length, truncation=True) for t in texts]
         if self._backend is None:
             from tokenizers import Tokenizer
-            os.environ.setdefault("TOKENIZERS_PARALLELISM", "false")
+            os.environ["TOKENIZERS_PARALLELISM"] = "true" if self.parallel else "false"
             self._backend = Tokenizer.from_str(self._backend_json)
             self._backend.enable_truncation(max_length=self.max_length)
             self._backend.no_padding()
+        if os.environ.get("PROQA_LOADER_DEBUG"):
+            import time
+            t0 = time.perf_counter()
+            enc = self._backend.encode_batch(list(texts), add_special_tokens=True)
+            t1 = time.perf_counter()
+            out = [e.ids for e in enc]
+            t2 = time.perf_counter()
+            self._dbg = getattr(self, "_dbg", [0.0, 0.0, 0])
+            self._dbg[0] += t1 - t0
+            self._dbg[1] += t2 - t1
+            self._dbg[2] += 1
+            if self._dbg[2] % 100 == 0:
+                import sys
+                print(f"[loader] {self._dbg[2]} batches: encode_batch {self._dbg[0]:.2f} s, ids lists {self._dbg[1]:.2f} s", file=sys.stderr)
+            return out
         return [e.ids for e in self._backend.encode_batch(list(texts), add_special_tokens=True)]
 
     def __call__(self, texts):
@@ -130,3 +148,70 @@ class TokenizeCollate:
             row[:len(x)] = x
         mask = np.arange(width)[None, :] < np.asarray(lens)[:, None]
         return {"input_ids": torch.from_numpy(out), "input_mask": torch.from_numpy(mask), "seq_lens": lens}
+
+
+class TextBatchLoader:
+    """Tokenised batches of a sequence of sentences, produced by a background thread of THIS process.
+
+    The reference feeds its GPU from `DataLoader(num_workers=32)` processes (retrieval/get_embed.py:93-96).  Worker
+    processes cost a fork of a process that holds the model and a pickle + shared-memory hop per batch.  The WordPiece
+    tokenizer is native code that releases the GIL and spreads a
+    batch over its own threads, so one producer thread here keeps `prefetch` collated batches ahead of the consumer: no
+    processes, no copies between them.  The producer (and the tokenizer pool it starts) runs at a lower priority than the
+    thread feeding the GPU.  Yields what `collate` returns, in order; an exception in the producer is re-raised here."""
+
+    def __init__(self, texts, batch_size, collate, prefetch=8, lo=0, hi=None, producers=1):
+        """producers: threads that take turns on the batches (batch i belongs to producer i % producers; the consumer
+        reads their queues round-robin, so the order is kept).  One is the default: two concurrent batch calls share the
+        tokenizer's thread pool and measured slower (28 k vs 38 k passages/s on 14 threads)."""
+        self.texts, self.batch_size, self.collate, self.prefetch = texts, int(batch_size), collate, int(prefetch)
+        self.lo, self.hi = int(lo), len(texts) if hi is None else int(hi)
+        self.producers = max(1, int(producers))
+
+    def __len__(self):
+        return max(0, -(-(self.hi - self.lo) // self.batch_size))
+
+    def __iter__(self):
+        import copy
+        import queue
+        import threading
+        n_prod = self.producers
+        queues = [queue.Queue(maxsize=max(1, self.prefetch // n_prod)) for _ in range(n_prod)]
+        stop = threading.Event()
+        starts = list(range(self.lo, self.hi, self.batch_size))
+
+        def produce(p, collate):
+            try:
+                os.nice(10)          # Linux: per thread; the tokenizer's pool is started from here and inherits it
+            except OSError:
+                pass
+            q = queues[p]
+            try:
+                for b0 in starts[p::n_prod]:
+                    if stop.is_set():
+                        return
+                    item = collate([self.texts[i] for i in range(b0, min(b0 + self.batch_size, self.hi))])
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                q.put(None)
+            except BaseException as e:      # handed to the consumer
+                q.put(e)
+
+        for p in range(n_prod):
+            # (every producer its own collate object: TokenizeCollate keeps a private tokenizer handle)
+            collate = self.collate if p == 0 else copy.copy(self.collate)
+            threading.Thread(target=produce, args=(p, collate), name=f"proqa-tokenize-{p}", daemon=True).start()
+        try:
+            for b in range(len(starts)):
+                item = queues[b % n_prod].get()
+                if isinstance(item, BaseException):
+                    raise item
+                if item is None:            # cannot happen before the last batch of that producer
+                    raise RuntimeError("tokenizer thread ended early")
+                yield item
+        finally:
+            stop.set()

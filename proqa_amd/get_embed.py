@@ -17,11 +17,10 @@ import random
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader, Subset
 
 from . import npy
 from .config import get_args
-from .datasets import EmDataset, EmTextView, TokenizeCollate
+from .datasets import EmDataset, EmTextView, TextBatchLoader, TokenizeCollate
 from .retriever import BertForRetriever, config_from_dict
 from .utils import move_to_cuda
 
@@ -81,14 +80,52 @@ def _right_padded(mask):
     return mask.shape[1] < 2 or not bool((mask[:, 1:] & ~mask[:, :-1]).any())
 
 
+class _PinnedStager:
+    """Uploads host batches through a small ring of pinned buffers that are allocated once.
+
+    A loader with pin_memory=True pins every batch in a thread of this process with torch's (thread-pool) copy into a
+    freshly pinned allocation.  Here a batch is memcpy'd into a slot of the ring (0.6 MB, ~50 us) and uploaded from there;
+    a slot is reused once the upload that read it has completed."""
+
+    def __init__(self, device, slots=4):
+        self.device = device
+        self.slots = [dict(bufs={}, event=None) for _ in range(slots)]
+        self.next = 0
+
+    def upload(self, batch):
+        if all(not torch.is_tensor(v) or v.is_pinned() or v.is_cuda for v in batch.values()):
+            return move_to_cuda(batch)                      # the caller pinned it (or it is on the GPU already)
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        out = {}
+        for k, v in batch.items():
+            if not torch.is_tensor(v) or v.is_cuda:
+                out[k] = v
+                continue
+            buf = slot["bufs"].get(k)
+            if buf is None or buf.dtype != v.dtype or buf.numel() < v.numel():
+                buf = torch.empty(max(v.numel(), 1), dtype=v.dtype, pin_memory=True)
+                slot["bufs"][k] = buf
+            staged = buf[:v.numel()].view(v.shape)
+            # (a plain memcpy: torch's copy_ goes through its intra-op thread pool above 32k elements, and that pool is as
+            # wide as the machine -- 256 spinning threads on the GPU boxes exhaust the process's CPU quota within a batch)
+            np.copyto(staged.numpy(), v.contiguous().numpy())
+            out[k] = staged.to(self.device, non_blocking=True)
+        slot["event"] = torch.cuda.Event()
+        slot["event"].record()
+        return out
+
+
 def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=True, stats=None):
     """The reference's hot loop: move batch to the GPU, get_embed, keep embeddings on device.
     Batches alternate between N_STREAMS HIP streams (order of the results is kept).
     A batch may carry its valid lengths as the host list 'seq_lens' (TokenizeCollate does); a batch of the reference's
     shape (ids + mask only) has them taken from the mask.
-    stats (optional dict): filled with 'batches', 'passages', 'gpu_busy_seconds' (HIP-event time of the get_embed calls)
-    and 'loop_seconds' (wall time of the loop incl. the wait for the last batch) -- what a run needs to tell whether the
-    host kept the GPU fed."""
+    stats (optional dict): filled with 'batches', 'passages', 'gpu_busy_seconds' (HIP-event time of the get_embed calls),
+    'loop_seconds' (wall time of the loop incl. the wait for the last batch), 'loader_wait_seconds' (blocked in the
+    loader) and 'feed_seconds' (upload + launches) -- what a run needs to tell whether the host kept the GPU fed."""
     import time
     model.eval()
     if fp16:
@@ -99,8 +136,20 @@ def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=Tru
     for s in streams:
         s.wait_stream(main)     # pool streams are non-blocking: order them after the weight preparation on `main`
     events = []
+    stager = _PinnedStager(device)
     t_loop = time.perf_counter()
-    for i, batch in enumerate(eval_dataloader):
+    t_wait = t_feed = t_upload = 0.0
+    it = iter(eval_dataloader)
+    i = -1
+    while True:
+        t0 = time.perf_counter()
+        try:
+            batch = next(it)
+        except StopIteration:
+            break
+        i += 1
+        t1 = time.perf_counter()
+        t_wait += t1 - t0
         lens = batch.pop("seq_lens", None) if isinstance(batch, dict) else None
         if lens is None:
             if not _right_padded(batch["input_mask"]):
@@ -108,7 +157,8 @@ def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=Tru
             lens = batch["input_mask"].sum(dim=1).tolist()      # host-side: lets the encoder skip the padding
         s = streams[i % N_STREAMS]
         with torch.cuda.stream(s), torch.no_grad():
-            batch_to_feed = move_to_cuda(batch)
+            batch_to_feed = stager.upload(batch)
+            t_upload += time.perf_counter() - t1
             if stats is not None:
                 events.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
                 events[-1][0].record()
@@ -116,13 +166,14 @@ def predict(args, model, eval_dataloader, device, fp16=False, is_query_embed=Tru
                                           seq_lens_host=lens)["embed"])
             if stats is not None:
                 events[-1][1].record()
+        t_feed += time.perf_counter() - t1
     for s in streams:
         main.wait_stream(s)
     if stats is not None:
         torch.cuda.synchronize(device)
         stats.update(batches=len(chunks), passages=int(sum(c.shape[0] for c in chunks)),
                      gpu_busy_seconds=sum(a.elapsed_time(b) for a, b in events) / 1e3,
-                     loop_seconds=time.perf_counter() - t_loop)
+                     loop_seconds=time.perf_counter() - t_loop, loader_wait_seconds=t_wait, feed_seconds=t_feed, upload_seconds=t_upload)
     if chunks:
         embeds = torch.cat(chunks)
     else:
@@ -163,6 +214,8 @@ def main(argv=None):
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
 
+    # (read by the tokenizer library's thread pool when it is first used)
+    os.environ.setdefault("RAYON_NUM_THREADS", str(max(1, min(args.eval_workers, usable_cpus() - 2))))
     from transformers import BertTokenizer
     bert_config = load_bert_config(args.bert_model_name)
     model = BertForRetriever(bert_config, args, device=device)
@@ -171,13 +224,18 @@ def main(argv=None):
     dataset = EmDataset(tokenizer, args.predict_file, args.max_query_length, args.max_seq_length, is_query_embed)
     n_total = len(dataset)
     lo, hi = (n_total * rank) // world, (n_total * (rank + 1)) // world
-    # the loader hands over whole tokenised batches (datasets.TokenizeCollate: same ids / masks as EmDataset + em_collate);
-    # workers beyond the CPUs this process may use only cost memory and context switches
+    # The loader hands over whole tokenised batches (datasets.TokenizeCollate: same ids / masks as EmDataset + em_collate)
+    # from a background thread of this process (datasets.TextBatchLoader); --eval-workers is the size of the tokenizer's
+    # thread pool, capped two below the CPUs this process may use: one for the thread that launches the kernels, one for
+    # the producer.  --eval-workers 0 tokenises in the consumer thread, batch by batch.
     texts = EmTextView(dataset)
-    part = texts if world == 1 else Subset(texts, range(lo, hi))
-    workers = max(0, min(args.eval_workers, usable_cpus()))
-    loader = DataLoader(part, batch_size=args.predict_batch_size, collate_fn=TokenizeCollate(tokenizer, dataset.max_length),
-                        pin_memory=True, num_workers=workers, **({"prefetch_factor": 4, "persistent_workers": True} if workers else {}))
+    workers = max(0, min(args.eval_workers, usable_cpus() - 2))
+    collate = TokenizeCollate(tokenizer, dataset.max_length, parallel=workers > 1)
+    if workers > 0:
+        loader = TextBatchLoader(texts, args.predict_batch_size, collate, prefetch=8, lo=lo, hi=hi)
+    else:
+        loader = (collate([texts[i] for i in range(b0, min(b0 + args.predict_batch_size, hi))])
+                  for b0 in range(lo, hi, args.predict_batch_size))
 
     assert args.init_checkpoint != ""
     model = load_saved(model, args.init_checkpoint)

@@ -28,7 +28,11 @@ class OnlineRetriever:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if index is not None:
             self.index = index
-            self.dtype = np.dtype(para_embed.dtype if hasattr(para_embed, "dtype") else (para_embed or np.float16))
+            if para_embed is None or isinstance(para_embed, (type, np.dtype, str)):
+                self.dtype = np.dtype(para_embed or np.float16)      # just the dtype of the rows to hand back
+                para_embed = None
+            else:
+                self.dtype = np.asarray(para_embed).dtype
         else:
             para_embed = np.ascontiguousarray(para_embed)
             with torch.cuda.device(self.device):      # proqa_index_create binds the index to the current device

@@ -124,3 +124,34 @@ def test_batch_tokenising_collate_equals_the_per_item_path_on_random_strings(tok
         if b == 5:
             break
     assert n == 600
+
+
+def test_text_batch_loader_yields_the_batches_in_order(tokenizer, tmp_path):
+    """get_embed.py's loader: a producer thread of the same process, batches in file order, a row range for sharded runs,
+    producer exceptions re-raised in the consumer."""
+    texts = _random_strings(700, 3)
+    path = tmp_path / "rand.jsonl"
+    path.write_text("".join(json.dumps({"text": t}) + "\n" for t in texts))
+    ds = datasets.EmDataset(tokenizer, str(path), 30, 64, False)
+    view = datasets.EmTextView(ds)
+    collate = datasets.TokenizeCollate(tokenizer, ds.max_length, parallel=True)
+    loader = datasets.TextBatchLoader(view, 100, collate, prefetch=2, lo=50, hi=len(view))
+    assert len(loader) == (len(view) - 50 + 99) // 100
+    n = 50
+    for batch in loader:
+        m = batch["input_ids"].shape[0]
+        want = datasets.em_collate([ds[i] for i in range(n, n + m)])
+        assert torch.equal(batch["input_ids"], want["input_ids"]) and torch.equal(batch["input_mask"], want["input_mask"])
+        n += m
+    assert n == len(view)
+    assert list(datasets.TextBatchLoader(view, 100, collate, lo=10, hi=10)) == []
+
+    def broken(_texts):
+        raise RuntimeError("tokenizer blew up")
+
+    with pytest.raises(RuntimeError, match="blew up"):
+        list(datasets.TextBatchLoader(view, 100, broken))
+    # a consumer that stops early does not leave the producer blocked on a full queue
+    it = iter(datasets.TextBatchLoader(view, 10, collate, prefetch=1))
+    next(it)
+    it.close()
