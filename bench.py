@@ -649,6 +649,7 @@ def main():
                    "scores_sha256": hashlib.sha256(Dm.cpu().numpy().tobytes()).hexdigest()},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_MFMA_F16_TFLOPS, "traffic": pmc_traffic((hi - lo) / n),
+                     "traffic_measured_on_commit": pmc_traffic_commit(),
                      "kernel": "mips_filter_f16", "filter_ms_per_search": st["filter_ms"],
                      "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / PEAK_HBM_GBS},
     }
@@ -794,6 +795,16 @@ def pmc_traffic(shard_fraction):
     try:
         with open(path) as f:
             return json.load(f).get("hbm_bytes_per_search") * shard_fraction
+    except Exception:
+        return None
+
+
+def pmc_traffic_commit():
+    """The commit profiles/pmc_traffic.json was measured on (stamped when the profile set is refreshed): `traffic` is a
+    committed counter reading, not a measurement of this run, and goes stale when a kernel changes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get("measured_on_commit")
     except Exception:
         return None
 

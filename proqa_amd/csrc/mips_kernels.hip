@@ -967,18 +967,24 @@ __global__ __launch_bounds__(kBootWaves * 64) void bootstrap_scores(const char* 
   f16x8 qf[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) qf[j] = *(const f16x8*)(bp + (2 * j + half) * 16);
-#pragma unroll 1
+  // the row fragments of all the wave's tiles are requested up front: ONE memory round trip per wave instead of one per
+  // tile (the launch runs two waves per SIMD: nothing else hides the latency)
+  f16x8 af[kBootTilesPerWave][8];
+#pragma unroll
+  for (int t = 0; t < kBootTilesPerWave; ++t) {
+    const int row0 = ((blockIdx.x * kBootTilesPerWave + t) * kBootWaves + wave) * 32;
+    const int arow = row0 + li < n_rows ? row0 + li : n_rows - 1;
+    const char* ap = xb + (size_t)arow * kRowBytes;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[t][j] = *(const f16x8*)(ap + (2 * j + half) * 16);
+  }
+#pragma unroll
   for (int t = 0; t < kBootTilesPerWave; ++t) {
     const int row0 = ((blockIdx.x * kBootTilesPerWave + t) * kBootWaves + wave) * 32;
     if (row0 >= n_rows) break;   // wave-uniform; no workgroup barrier below: the LDS tile is private to the wave
-    const int arow = row0 + li < n_rows ? row0 + li : n_rows - 1;
-    const char* ap = xb + (size_t)arow * kRowBytes;
-    f16x8 af[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(ap + (2 * j + half) * 16);
     f32x16 acc = {0};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[j], acc, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t][j], qf[j], acc, 0, 0, 0);
     // lane (li, half) holds query li, rows (r&3) + 8*(r>>2) + 4*half; LDS operations of one wave execute in
     // program order, so the transposed reads below see the writes of the other lanes
 #pragma unroll

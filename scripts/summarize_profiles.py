@@ -17,7 +17,7 @@ root = sys.argv[1]
 def short(name):
     if "mips_filter_f16<1" in name:
         return "mips_filter_f16_qw1"      # the HBM-bound small-batch instantiation (bench.py scan_small_batch)
-    for key in ("mips_filter_f16", "topk_merge", "merge_lists", "bootstrap_scores", "bootstrap_select", "prep_queries",
+    for key in ("mips_filter_f16", "topk_merge", "merge_sorted_lists", "merge_lists", "kmeans_assign", "segmented_mean", "bootstrap_scores", "bootstrap_select", "prep_queries",
                 "finalize_topk", "gemm_tn_f16", "attention_fwd", "attention_cls_fwd", "bias_gelu", "bias_residual_layernorm",
                 "embed_layernorm", "pool_project", "cls_dense_mfma", "small_dense_mfma", "gather_rows_kernel", "stream_copy", "stream_read", "mfma_loop", "Cijk_"):
         if key in name:
