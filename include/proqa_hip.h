@@ -321,6 +321,22 @@ int proqa_npy_create(const char* path, int64_t rows, int64_t cols, int dtype);
 int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* src, int64_t cols, int dtype);
 
 /* ------------------------------------------------------------------------------------
+ * WordPiece tokenisation on the host, native and multi-threaded: `tokenizer.encode(sent, max_length=L)` of
+ * retrieval/datasets.py:285-286 (transformers' BertTokenizer) for the texts it reproduces exactly -- pure 7-bit ASCII
+ * without a '[' -- so that get_embed.py's loader does not depend on ~3.5 k passages/s per thread of Python-bound
+ * tokenizer calls.  Other texts are flagged (length -1) and left to the caller's reference tokenizer.
+ * ---------------------------------------------------------------------------------- */
+typedef struct proqa_wordpiece proqa_wordpiece;
+/* vocab: the tokens of vocab.txt joined by '\n' (token i has id i), vocab_bytes long; do_lower_case as the model's */
+int proqa_wordpiece_create(const char* vocab, size_t vocab_bytes, int do_lower_case, proqa_wordpiece** out);
+int proqa_wordpiece_free(proqa_wordpiece* tok);
+/* texts[i] (text_bytes[i] bytes, UTF-8, not NUL-terminated) -> ids_out[i, 0..max_length) = [CLS] pieces [SEP] truncated
+ * to max_length, zero-padded; lens_out[i] = its length, or -1 if text i is not plain ASCII (row i of ids_out is then
+ * unspecified).  n_threads host threads share the batch. */
+int proqa_wordpiece_encode_batch(const proqa_wordpiece* tok, const char* const* texts, const int64_t* text_bytes, int64_t n,
+                                 int max_length, int64_t* ids_out, int32_t* lens_out, int n_threads);
+
+/* ------------------------------------------------------------------------------------
  * Multi-GPU search without PyTorch (BASELINE.json configs[3]).  One process (or thread)
  * per GPU holds rows [lo, hi) of the corpus in its own proqa_index and all queries.  A sharded search is the
  * local exact top-k with global ids, ONE RCCL all-gather of the per-rank [nq, k] (id, score) lists over xGMI,

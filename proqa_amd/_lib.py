@@ -125,6 +125,10 @@ SIGNATURES = {
     "proqa_npy_write": (c_int, [c_char_p, c_void_p, c_int64, c_int64, c_int]),
     "proqa_npy_create": (c_int, [c_char_p, c_int64, c_int64, c_int]),
     "proqa_npy_write_rows": (c_int, [c_char_p, c_int64, c_int64, c_void_p, c_int64, c_int]),
+    "proqa_wordpiece_create": (c_int, [c_char_p, c_size_t, c_int, ctypes.POINTER(c_void_p)]),
+    "proqa_wordpiece_free": (c_int, [c_void_p]),
+    "proqa_wordpiece_encode_batch": (c_int, [c_void_p, ctypes.POINTER(c_char_p), ctypes.POINTER(c_int64), c_int64, c_int,
+                                             c_void_p, c_void_p, c_int]),
     "proqa_comm_get_unique_id": (c_int, [c_void_p]),
     "proqa_comm_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "proqa_comm_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

@@ -18,6 +18,7 @@ ARCH = "gfx950"
 SOURCES = [
     "common.cpp",
     "npy_io.cpp",
+    "wordpiece.cpp",
     "mips_index.cpp",
     "mips_kernels.hip",
     "sharded_search.cpp",
