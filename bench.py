@@ -289,7 +289,7 @@ def cli_text_leg(args, device, sd):
     import shutil
     import tempfile
     from proqa_amd import get_embed as ge
-    from proqa_amd.datasets import EmDataset, EmTextView, TextBatchLoader, TokenizeCollate
+    from proqa_amd.datasets import JsonlTexts, TextBatchLoader, TokenizeCollate
     from proqa_amd.retriever import BERT_BASE
     n_pass = args.cli_passages
     d = tempfile.mkdtemp(prefix="proqa_cli_")
@@ -345,9 +345,10 @@ def cli_text_leg(args, device, sd):
         # the loader alone: the same dataset / collate / worker count, nothing consumed on the GPU
         from transformers import BertTokenizer
         tok = BertTokenizer.from_pretrained(model_dir)
-        ds = EmDataset(tok, os.path.join(d, "paras.txt"), 30, args.seq_len, False)
+        ds = JsonlTexts(os.path.join(d, "paras.txt"), 30, args.seq_len, False)
         n_tok = min(n_pass, 60000)
-        loader = TextBatchLoader(EmTextView(ds), args.encode_batch, TokenizeCollate(tok, ds.max_length, parallel=True), prefetch=8,
+        loader = TextBatchLoader(ds, args.encode_batch,
+                                 TokenizeCollate(tok, ds.max_length, parallel=True, native_threads=max(1, cores - 2)), prefetch=8,
                                  lo=0, hi=n_tok)
         t1 = time.perf_counter()
         tokens = 0
@@ -362,8 +363,8 @@ def cli_text_leg(args, device, sd):
                                 "feed_seconds": st["feed_seconds"], "upload_seconds": st["upload_seconds"],
                                 "gpu_idle_fraction": max(0.0, 1.0 - st["gpu_busy_seconds"] / st["loop_seconds"])},
                 "tokenise_only": {"passages_per_s": n_tok / t_tok, "passages": n_tok,
-                                  "note": "the same loader (TextBatchLoader: one producer thread, the tokenizer's thread "
-                                          "pool of cores - 2) with nothing consumed on the GPU"},
+                                  "note": "the same loader (TextBatchLoader: one producer thread; plain-ASCII sentences on "
+                                          "libproqa_hip.so's WordPiece, cores - 2 threads) with nothing consumed on the GPU"},
                 "workload": f"{n_pass} synthetic passages of 100 words (88 in-vocabulary, 12 split into word pieces) in a "
                             f"JSON-lines file, bert-base-shaped 30 522-entry vocabulary, max_seq_length {args.seq_len}, batch "
                             f"{args.encode_batch}; whole call = JSONL read + tokeniser + model/checkpoint load + encode + np.save"}

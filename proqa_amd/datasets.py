@@ -84,6 +84,30 @@ class EmTextView(Dataset):
         return self.data[index][self.key]
 
 
+class JsonlTexts(Dataset):
+    """The sentences of a JSON-lines file, parsed on demand: item i is what EmTextView(EmDataset(...))[i] is.
+
+    EmDataset parses every line before the first batch can be encoded (datasets.py:271-272; 3.5 us per passage: a minute
+    for an 18M-passage corpus, with the GPU idle).  Here the file is read once as raw lines -- its length is known at once,
+    which the row sharding and the pre-sized output need -- and a line is parsed when the loader's producer thread asks
+    for it, i.e. beside the encoding of the batches before it.  A malformed line raises there, as it does in EmDataset."""
+
+    def __init__(self, data_path, max_query_length, max_length, is_query_embed):
+        self.is_query_embed = is_query_embed
+        self.key = "question" if is_query_embed else "text"
+        print(f"Loading data from {data_path}")
+        with open(data_path) as f:
+            self.lines = f.readlines()
+        self.max_length = max_query_length if is_query_embed else max_length
+        print(f"Max sequence length: {self.max_length}")
+
+    def __len__(self):
+        return len(self.lines)
+
+    def __getitem__(self, index):
+        return json.loads(self.lines[index].strip())[self.key]
+
+
 class TokenizeCollate:
     """collate_fn over strings: tokenizer.encode(sent, max_length=L, truncation=True) for every sentence of the batch
     (datasets.py:285-286) and the right-padding of em_collate (:298-305) in one step.
@@ -94,22 +118,73 @@ class TokenizeCollate:
     copy (own truncation setting, one thread per DataLoader worker: the workers are the parallelism); any other tokenizer
     is called sentence by sentence, as the reference does."""
 
-    def __init__(self, tokenizer, max_length, parallel=False):
+    def __init__(self, tokenizer, max_length, parallel=False, native_threads=0):
         """parallel: let the tokenizer library spread a batch over its own thread pool (TextBatchLoader: one producer
-        thread in the process that feeds the GPU); off inside DataLoader workers, which are the parallelism there."""
+        thread in the process that feeds the GPU); off inside DataLoader workers, which are the parallelism there.
+        native_threads > 0: plain-ASCII sentences go through libproqa_hip.so's own WordPiece (proqa_wordpiece_*, that many
+        threads: ids written straight into the batch array, no Python object per token); every other sentence -- and every
+        sentence if the tokenizer is not a plain BERT WordPiece one -- goes through the tokenizer itself, so the batch is
+        the reference's either way."""
         self.tokenizer = tokenizer
         self.max_length = int(max_length)
         self.parallel = bool(parallel)
+        self.native_threads = int(native_threads)
+        self._native = None
+        self._native_spec = self._native_vocab(tokenizer) if self.native_threads > 0 else None
         self._backend_json = None
         backend = getattr(tokenizer, "backend_tokenizer", None) or getattr(tokenizer, "_tokenizer", None)
         if backend is not None and hasattr(backend, "encode_batch") and hasattr(backend, "to_str"):
             self._backend_json = backend.to_str()
         self._backend = None
 
-    def __getstate__(self):      # the private backend is rebuilt in every worker
+    def __getstate__(self):      # the private backend / native handle is rebuilt in every worker
         state = dict(self.__dict__)
         state["_backend"] = None
+        state["_native"] = None
         return state
+
+    @staticmethod
+    def _native_vocab(tokenizer):
+        """(vocab bytes in id order, do_lower_case) if `tokenizer` is a BERT WordPiece tokenizer the native code restates
+        (contiguous ids, [UNK]/[CLS]/[SEP] present, '##' continuation prefix, default clean-up), else None."""
+        try:
+            vocab = tokenizer.get_vocab()
+            toks = sorted(vocab, key=vocab.get)
+            if [vocab[t] for t in toks] != list(range(len(toks))) or any("\n" in t for t in toks):
+                return None
+            if not {"[UNK]", "[CLS]", "[SEP]"} <= set(vocab):
+                return None
+            if (tokenizer.unk_token, tokenizer.cls_token, tokenizer.sep_token) != ("[UNK]", "[CLS]", "[SEP]"):
+                return None
+            backend = getattr(tokenizer, "backend_tokenizer", None) or getattr(tokenizer, "_tokenizer", None)
+            if backend is not None:
+                import json as _json
+                spec = _json.loads(backend.to_str())
+                norm, model = spec.get("normalizer") or {}, spec.get("model") or {}
+                if norm.get("type") != "BertNormalizer" or not norm.get("clean_text", True):
+                    return None
+                if model.get("type") != "WordPiece" or model.get("continuing_subword_prefix") != "##" or \
+                        model.get("max_input_chars_per_word", 100) != 100 or model.get("unk_token") != "[UNK]":
+                    return None
+                if (spec.get("pre_tokenizer") or {}).get("type") != "BertPreTokenizer":
+                    return None
+                lower = bool(norm.get("lowercase", True))
+            else:
+                lower = bool(getattr(tokenizer, "do_lower_case", True))
+            return ("\n".join(toks).encode("utf-8"), lower)
+        except Exception:
+            return None
+
+    def _native_handle(self):
+        if self._native is None and self._native_spec is not None:
+            import ctypes
+            from . import _lib
+            lib = _lib.load()
+            h = ctypes.c_void_p()
+            blob, lower = self._native_spec
+            _lib.check(lib.proqa_wordpiece_create(blob, len(blob), 1 if lower else 0, ctypes.byref(h)))
+            self._native = (lib, h)
+        return self._native
 
     def _encode(self, texts):
         if self._backend_json is None:
@@ -137,9 +212,35 @@ class TokenizeCollate:
             return out
         return [e.ids for e in self._backend.encode_batch(list(texts), add_special_tokens=True)]
 
+    def _call_native(self, texts):
+        """The batch through proqa_wordpiece_encode_batch; sentences it declines (non-ASCII, a '[') through _encode."""
+        import ctypes
+        lib, h = self._native_handle()
+        n, L = len(texts), self.max_length
+        raw = [t.encode("utf-8") for t in texts]
+        ptrs = (ctypes.c_char_p * n)(*raw)
+        sizes = np.fromiter(map(len, raw), dtype=np.int64, count=n)
+        ids = np.empty((n, L), dtype=np.int64)
+        lens = np.empty(n, dtype=np.int32)
+        from . import _lib
+        _lib.check(lib.proqa_wordpiece_encode_batch(h, ptrs, sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n, L,
+                                                    ids.ctypes.data, lens.ctypes.data, self.native_threads))
+        rest = np.nonzero(lens < 0)[0]
+        if len(rest):
+            for i, x in zip(rest.tolist(), self._encode([texts[i] for i in rest.tolist()])):
+                ids[i, :len(x)] = x
+                ids[i, len(x):] = 0
+                lens[i] = len(x)
+        width = int(lens.max())
+        out = np.ascontiguousarray(ids[:, :width])
+        mask = np.arange(width)[None, :] < lens[:, None]
+        return {"input_ids": torch.from_numpy(out), "input_mask": torch.from_numpy(mask), "seq_lens": lens.tolist()}
+
     def __call__(self, texts):
         if len(texts) == 0:
             return {}
+        if self._native_spec is not None:
+            return self._call_native(texts)
         ids = self._encode(texts)
         lens = [len(x) for x in ids]
         width = max(lens)

@@ -20,7 +20,7 @@ import torch
 
 from . import npy
 from .config import get_args
-from .datasets import EmDataset, EmTextView, TextBatchLoader, TokenizeCollate
+from .datasets import JsonlTexts, TextBatchLoader, TokenizeCollate
 from .retriever import BertForRetriever, config_from_dict
 from .utils import move_to_cuda
 
@@ -221,16 +221,18 @@ def main(argv=None):
     model = BertForRetriever(bert_config, args, device=device)
     tokenizer = BertTokenizer.from_pretrained(args.bert_model_name)
 
-    dataset = EmDataset(tokenizer, args.predict_file, args.max_query_length, args.max_seq_length, is_query_embed)
+    # (the sentences EmDataset would tokenise, parsed line by line in the loader's producer thread: datasets.JsonlTexts)
+    dataset = JsonlTexts(args.predict_file, args.max_query_length, args.max_seq_length, is_query_embed)
     n_total = len(dataset)
     lo, hi = (n_total * rank) // world, (n_total * (rank + 1)) // world
     # The loader hands over whole tokenised batches (datasets.TokenizeCollate: same ids / masks as EmDataset + em_collate)
     # from a background thread of this process (datasets.TextBatchLoader); --eval-workers is the size of the tokenizer's
     # thread pool, capped two below the CPUs this process may use: one for the thread that launches the kernels, one for
     # the producer.  --eval-workers 0 tokenises in the consumer thread, batch by batch.
-    texts = EmTextView(dataset)
+    texts = dataset
     workers = max(0, min(args.eval_workers, usable_cpus() - 2))
-    collate = TokenizeCollate(tokenizer, dataset.max_length, parallel=workers > 1)
+    # (plain-ASCII sentences are tokenised by the library's own WordPiece on `workers` threads, the rest by the tokenizer)
+    collate = TokenizeCollate(tokenizer, dataset.max_length, parallel=workers > 1, native_threads=workers)
     if workers > 0:
         loader = TextBatchLoader(texts, args.predict_batch_size, collate, prefetch=8, lo=lo, hi=hi)
     else:

@@ -112,6 +112,45 @@ int main(int argc, char** argv) {
   for (int s : seen) CHECK(s == 1);
   CHECK(proqa_rand_perm(-1, 1, perm.data()) == PROQA_EINVAL);
   CHECK(proqa_abi_version() == PROQA_ABI_VERSION);
+
+  // native WordPiece: truncation at the row edge, words around the 100-character limit, control bytes, declined texts,
+  // several threads, a vocabulary without the special tokens
+  {
+    const std::string vocab = "[PAD]\n[UNK]\n[CLS]\n[SEP]\nab\n##cd\n##c\n.\nx\n##x";
+    proqa_wordpiece* tok = nullptr;
+    CHECK(proqa_wordpiece_create(vocab.data(), vocab.size(), 1, &tok) == 0);
+    std::vector<std::string> texts = {"", "AB abcd abc. zz", std::string(100, 'x'), std::string(101, 'x'), "ab\x01" "cd \t ab",
+                                      "caf\xc3\xa9", "[CLS]", "ab ab ab ab ab ab ab ab ab ab"};
+    std::vector<const char*> ptrs;
+    std::vector<int64_t> sizes;
+    for (auto& t : texts) {
+      ptrs.push_back(t.data());
+      sizes.push_back((int64_t)t.size());
+    }
+    for (int max_length : {2, 3, 8, 128}) {
+      for (int threads : {1, 3, 16}) {
+        std::vector<int64_t> ids(texts.size() * max_length, -7);
+        std::vector<int32_t> lens(texts.size(), -7);
+        CHECK(proqa_wordpiece_encode_batch(tok, ptrs.data(), sizes.data(), (int64_t)texts.size(), max_length, ids.data(),
+                                           lens.data(), threads) == 0);
+        CHECK(lens[0] == 2 && ids[0] == 2 && ids[1] == 3);                       // "" -> [CLS] [SEP]
+        CHECK(lens[5] == -1 && lens[6] == -1);                                     // non-ASCII / a '[': declined
+        for (size_t i = 0; i < texts.size(); ++i) CHECK(lens[i] == -1 || (lens[i] >= 2 && lens[i] <= max_length));
+        if (max_length == 128) {
+          CHECK(lens[1] == 9);   // [CLS] ab ab ##cd ab ##c . [UNK] [SEP]
+          const int64_t want[9] = {2, 4, 4, 5, 4, 6, 7, 1, 3};
+          for (int j = 0; j < 9; ++j) CHECK(ids[1 * 128 + j] == want[j]);
+          CHECK(lens[2] == 102 && ids[2 * 128 + 1] == 8 && ids[2 * 128 + 100] == 9);   // 100 x: x ##x ... ##x
+          CHECK(lens[3] == 3 && ids[3 * 128 + 1] == 1);                                 // 101 x: [UNK]
+          CHECK(lens[4] == 5 && ids[4 * 128 + 1] == 4 && ids[4 * 128 + 2] == 5);        // the control byte vanishes: "abcd"
+        }
+      }
+    }
+    CHECK(proqa_wordpiece_encode_batch(tok, ptrs.data(), sizes.data(), 1, 1, nullptr, nullptr, 1) == PROQA_EINVAL);
+    CHECK(proqa_wordpiece_free(tok) == 0);
+    const std::string no_special = "a\nb";
+    CHECK(proqa_wordpiece_create(no_special.data(), no_special.size(), 1, &tok) == PROQA_EINVAL);
+  }
   printf("asan driver ok\n");
   return 0;
 }

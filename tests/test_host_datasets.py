@@ -155,3 +155,90 @@ def test_text_batch_loader_yields_the_batches_in_order(tokenizer, tmp_path):
     it = iter(datasets.TextBatchLoader(view, 10, collate, prefetch=1))
     next(it)
     it.close()
+
+
+def _random_ascii(n, seed):
+    import random
+    rng = random.Random(seed)
+    vocab = [w.strip() for w in open(os.path.join(GOLDEN, "vocab_small.txt"))]
+    words = [w for w in vocab if w.isalpha()]
+
+    def one():
+        out = []
+        for _ in range(rng.randrange(0, 50)):
+            r = rng.random()
+            if r < 0.45:
+                out.append(rng.choice(words))
+            elif r < 0.55:
+                out.append(rng.choice(words).upper())
+            elif r < 0.65:
+                out.append(rng.choice(words) + rng.choice(words))                    # splits into word pieces
+            elif r < 0.8:
+                out.append(chr(rng.randrange(0, 128)))                               # every ASCII code, controls included
+            elif r < 0.9:
+                out.append("".join(chr(rng.randrange(33, 127)) for _ in range(rng.randrange(1, 6))))
+            else:
+                out.append("x" * rng.randrange(95, 110))                             # around the 100-character word limit
+        return (" " if rng.random() < 0.7 else "").join(out)
+
+    return [one() for _ in range(n)] + ["", " ", "\t\n", "a\x00b", "a\x0bb c\x1fd", "it's", "U.S.A.", "x" * 100, "x" * 101]
+
+
+@pytest.mark.parametrize("lower", [True, False])
+def test_native_wordpiece_equals_the_reference_tokenizer(tmp_path, lower):
+    """libproqa_hip.so's WordPiece (proqa_wordpiece_*, the loader's fast path for plain-ASCII sentences) against
+    transformers' BertTokenizer: ids, masks and lengths identical on 6000 random ASCII strings (all 128 codes, word-piece
+    splits, words around the 100-character limit, truncation at three limits), on sentences it must decline (non-ASCII,
+    a literal special token: those rows come from the tokenizer itself) and on the reference's golden batches; uncased and
+    cased models."""
+    import shutil
+    from transformers import BertTokenizer
+    d = tmp_path / "model"
+    d.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "vocab_small.txt"), d / "vocab.txt")
+    tok = BertTokenizer.from_pretrained(str(d), do_lower_case=lower)
+    texts = _random_ascii(6000, 23 + lower) + _random_strings(600, 5) + ["[CLS] x [SEP]", "café au lait", "[unused1]"]
+    for limit in (16, 64, 512):
+        ref = datasets.TokenizeCollate(tok, limit)
+        nat = datasets.TokenizeCollate(tok, limit, native_threads=3)
+        assert nat._native_spec is not None and nat._native_spec[1] == lower
+        for b0 in range(0, len(texts), 97):
+            a, b = ref(texts[b0:b0 + 97]), nat(texts[b0:b0 + 97])
+            assert torch.equal(a["input_ids"], b["input_ids"]), (limit, b0)
+            assert torch.equal(a["input_mask"], b["input_mask"]) and a["seq_lens"] == b["seq_lens"]
+    if lower:
+        with open(os.path.join(GOLDEN, "tokenize_golden.json")) as f:
+            gold = json.load(f)
+        for case in gold["cases"]:
+            L = case["max_query_length"] if case["is_query"] else case["max_length"]
+            batch = datasets.TokenizeCollate(tok, L, native_threads=2)(gold["texts"])
+            assert batch["input_ids"].tolist() == case["input_ids"] and batch["seq_lens"] == case["item_lengths"]
+
+
+def test_native_wordpiece_is_declined_for_other_tokenizers(tokenizer):
+    """A tokenizer the native code does not restate (here: a vocabulary with a gap in its ids) keeps the library path."""
+    class Odd:
+        unk_token, cls_token, sep_token = "[UNK]", "[CLS]", "[SEP]"
+
+        def get_vocab(self):
+            return {"[UNK]": 0, "[CLS]": 1, "[SEP]": 3}
+    assert datasets.TokenizeCollate._native_vocab(Odd()) is None
+    assert datasets.TokenizeCollate._native_vocab(tokenizer) is not None
+
+
+def test_jsonl_texts_is_the_lazy_form_of_emdataset(tokenizer, tmp_path):
+    texts = _random_strings(300, 9)
+    path = tmp_path / "in.jsonl"
+    path.write_text("".join(json.dumps({"text": t, "question": t[::-1], "id": i}) + "\n" for i, t in enumerate(texts)))
+    for is_query in (True, False):
+        ds = datasets.EmDataset(tokenizer, str(path), 30, 64, is_query)
+        lazy = datasets.JsonlTexts(str(path), 30, 64, is_query)
+        view = datasets.EmTextView(ds)
+        assert len(lazy) == len(ds) and lazy.max_length == ds.max_length
+        assert all(lazy[i] == view[i] for i in range(len(ds)))
+    bad = tmp_path / "bad.jsonl"
+    bad.write_text('{"text": "a"}\nnot json\n')
+    lazy = datasets.JsonlTexts(str(bad), 30, 64, False)
+    assert len(lazy) == 2 and lazy[0] == "a"
+    with pytest.raises(ValueError):
+        lazy[1]

@@ -10,11 +10,11 @@ CSRC = os.path.join(ROOT, "proqa_amd", "csrc")
 
 
 @pytest.mark.skipif(shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"), reason="needs g++ and ROCm headers")
-def test_npy_io_and_rand_perm_under_asan(tmp_path):
+def test_npy_io_wordpiece_and_rand_perm_under_asan(tmp_path):
     exe = tmp_path / "npy_asan"
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
            "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "native", "npy_asan_driver.cpp"),
-           os.path.join(CSRC, "npy_io.cpp"), os.path.join(CSRC, "common.cpp"), "-L/opt/rocm/lib", "-lamdhip64",
+           os.path.join(CSRC, "npy_io.cpp"), os.path.join(CSRC, "common.cpp"), os.path.join(CSRC, "wordpiece.cpp"), "-lpthread", "-L/opt/rocm/lib", "-lamdhip64",
            "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)]
     build = subprocess.run(cmd, capture_output=True, text=True)
     assert build.returncode == 0, build.stderr[-3000:]
