@@ -163,3 +163,38 @@ def test_a_failing_local_search_still_enters_the_collective(gpu_device):
     np.testing.assert_array_equal(I2.cpu().numpy(), Io)
     np.testing.assert_array_equal(D2.cpu().numpy(), Do)
     index.close()
+
+
+def _nccl_f32_worker(rank, port, transport, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=1)
+    try:
+        from proqa_amd.index import ShardedIndexFlatIP
+        rng = np.random.default_rng(4)
+        xb = rng.standard_normal((30011, 128)).astype(np.float32)       # values fp16 cannot hold: exact-float32 mode
+        xq = rng.standard_normal((70, 128)).astype(np.float32)
+        index = ShardedIndexFlatIP(30011, transport=transport)
+        index.add_local(xb)
+        D, I = index.search(torch.from_numpy(xq).cuda(), 80, force_collective=True)
+        np.save(os.path.join(out_dir, "D.npy"), D.cpu().numpy())
+        np.save(os.path.join(out_dir, "I.npy"), I.cpu().numpy())
+        np.save(os.path.join(out_dir, "exact.npy"), np.array([index.local_index.exact_f32]))
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("transport", ["torch", "cabi"])
+def test_exact_float32_search_through_the_collective(gpu_device, tmp_path, transport):
+    """bench.py's float32 leg on more than one rank: float32 rows / queries (exact-float32 mode: fp16 scan, float64
+    re-scoring) through the enqueued search, the RCCL all-gather and the rank merge -- bit-identical to the oracle."""
+    from oracle import search_oracle
+    mp.spawn(_nccl_f32_worker, args=(_free_port(), transport, str(tmp_path)), nprocs=1, join=True)
+    rng = np.random.default_rng(4)
+    xb = rng.standard_normal((30011, 128)).astype(np.float32)
+    xq = rng.standard_normal((70, 128)).astype(np.float32)
+    Do, Io = search_oracle.topk_ip_exact(xq, xb, 80)
+    assert np.load(tmp_path / "exact.npy")[0]
+    np.testing.assert_array_equal(np.load(tmp_path / "I.npy"), Io)
+    np.testing.assert_array_equal(np.load(tmp_path / "D.npy"), Do)
