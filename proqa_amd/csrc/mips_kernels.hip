@@ -607,6 +607,7 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
   constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 8192 : 1024;
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
+  __shared__ unsigned long long s_dummy;   // target of the stores of lanes that have nothing to append
   static_assert(kBigLaneCap <= 64 && 2 * T <= 1024, "work item packing: (list within the pass << 6) | slot, 16 bits");
   const unsigned lane_cap = a.store.lane_cap;
   const unsigned q = blockIdx.x;
@@ -726,23 +727,45 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
         const unsigned row0 = (unsigned)__shfl((int)v.y, head, 64);
         const int rows_left = __shfl((int)v.z, head, 64);
         const float tau = __uint_as_float((unsigned)__shfl((int)v.w, head, 64));
-        if (!live || piece == 0) return;
         const int g = piece - 1;
         const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        if constexpr (EXACT) {   // exact-float32 mode: the fp16 score only nominates the row
+          if (!live || piece == 0) return;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if ((inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
-            const unsigned row = row0 + (unsigned)(e + 8 * g);
-            if (ex.nom) {  // exact-float32 mode: the fp16 score only nominates the row
+          for (int e = 0; e < 4; ++e) {
+            if ((inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
               const unsigned pos = atomicAdd(ex.n_nom, 1u);  // LDS
-              if (pos < (unsigned)CAP) ex.nom[pos] = row;
-              continue;
+              if (pos < (unsigned)CAP) ex.nom[pos] = row0 + (unsigned)(e + 8 * g);
             }
-            const unsigned long long key = pack_key(sc[e], row);
-            if (key < bound) {  // paged search: ties with the bound score that were already reported
-              const unsigned pos = atomicAdd(&s_n_keys, 1u);  // LDS
-              if (pos < (unsigned)CAP) keys[pos] = key;
-            }
+          }
+        } else {
+          // Branch-free per lane: the four scores of a piece are tested, the survivors of the WAVE are counted by ballot
+          // and get their slots from ONE LDS atomic; a lane without a survivor stores into a dummy word.  (One atomicAdd
+          // per score made hipcc wrap each in its own exec-mask / ballot / readfirstlane sequence: the launch is bound by
+          // scalar-unit issue, profiles/ABLATIONS.md R3.1.)
+          bool p[4];
+          unsigned long long key[4];
+          unsigned long long m[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            key[e] = pack_key(sc[e], row0 + (unsigned)(e + 8 * g));
+            // (key < bound: paged search, ties with the bound score that were already reported)
+            p[e] = live && piece != 0 && (inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left && key[e] < bound;
+            m[e] = __ballot(p[e]);
+          }
+          const unsigned n0 = (unsigned)__builtin_popcountll(m[0]), n1 = (unsigned)__builtin_popcountll(m[1]),
+                         n2 = (unsigned)__builtin_popcountll(m[2]), n3 = (unsigned)__builtin_popcountll(m[3]);
+          const unsigned total = n0 + n1 + n2 + n3;
+          if (total == 0) return;   // wave-uniform
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&s_n_keys, total);   // LDS
+          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+          const unsigned off[4] = {base, base + n0, base + n0 + n1, base + n0 + n1 + n2};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned pos = off[e] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[e], 0u));
+            unsigned long long* dst = (p[e] && pos < (unsigned)CAP) ? keys + pos : &s_dummy;
+            *dst = key[e];
           }
         }
       };
