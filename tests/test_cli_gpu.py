@@ -101,3 +101,29 @@ def test_get_embed_error_behaviour(workdir):
                         "--bert_model_name", str(d / "small-bert"), "--eval-workers", "0"])   # no checkpoint
     with pytest.raises(SystemExit):
         get_embed.main(["--no_such_flag"])
+
+
+def test_get_embed_loader_variants_write_the_same_file(gpu_device, workdir):
+    """The command line with the producer-thread loader (--eval-workers > 0: native WordPiece for ASCII sentences, the
+    tokenizer for the rest) and with --eval-workers 0 (tokenised in the consumer thread) writes the same embeddings; an
+    empty input file gives an empty [0, 128] index; a malformed line surfaces as an error, not a hang."""
+    from proqa_amd import get_embed
+    d, sd, cfg, gold = workdir
+    mixed = d / "mixed.txt"
+    texts = [t for _, t in gold["docs"]] + ["plain ascii sentence with punctuation, numbers 123 and a verylongwordthatissplit",
+                                             "café naïve 中文 text", "[SEP] literal special token", "", "x" * 300]
+    mixed.write_text("".join(json.dumps({"id": i, "text": t}) + "\n" for i, t in enumerate(texts)))
+    common = ["--do_predict", "--bert_model_name", str(d / "small-bert"), "--fp16", "--init_checkpoint",
+              str(d / "checkpoint_best.pt"), "--predict_batch_size", "5", "--predict_file", str(mixed)]
+    a = np.load(get_embed.main(common + ["--eval-workers", "6", "--embed_save_path", str(d / "mixed_a.npy")]))
+    b = np.load(get_embed.main(common + ["--eval-workers", "0", "--embed_save_path", str(d / "mixed_b.npy")]))
+    assert a.shape == (len(texts), 128) and a.dtype == np.float16
+    np.testing.assert_array_equal(a, b)
+    empty = d / "empty.txt"
+    empty.write_text("")
+    e = np.load(get_embed.main(common[:-1] + [str(empty), "--eval-workers", "4", "--embed_save_path", str(d / "empty.npy")]))
+    assert e.shape == (0, 128)
+    bad = d / "bad.txt"
+    bad.write_text(json.dumps({"text": "fine"}) + "\nnot json at all\n")
+    with pytest.raises(ValueError):
+        get_embed.main(common[:-1] + [str(bad), "--eval-workers", "4", "--embed_save_path", str(d / "bad.npy")])
