@@ -61,6 +61,8 @@ int proqa_device_info(int* n_devices, char* arch_name, size_t arch_name_len);
  * at retrieval/eval_retrieval.py:102-104 (also retrieval/trec_process.py:74-76).
  * Results: scores descending; exact ties ordered by ascending row index (FAISS leaves the
  * tie order unspecified); if fewer than k rows exist the tail is I = -1, D = -FLT_MAX.
+ * Scores that are not finite follow faiss's result heap: +inf ranks first; NaN and -inf never compare greater than what
+ * the heap holds and are never returned (their slots count as missing rows: I = -1, D = -FLT_MAX at the tail).
  * Rows are stored in HBM as fp16 (the --fp16 index format); scores accumulate in fp32.  float32 data
  * that fp16 cannot hold is searched exactly (see proqa_index_add).
  * ---------------------------------------------------------------------------------- */

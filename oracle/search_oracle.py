@@ -167,3 +167,23 @@ def topk_ip_argsort(xq, xb, k):
         D = np.concatenate([D, np.full((S.shape[0], pad), NEG_FILL, np.float32)], axis=1)
         I = np.concatenate([I, np.full((S.shape[0], pad), -1, np.int64)], axis=1)
     return D, I
+
+
+def topk_ip_heap(xq, xb, k):
+    """The rule for scores that are not finite, as faiss's result heap applies it (library knowledge, like the rest of the
+    faiss semantics above: faiss-cpu 1.6.3 knn_inner_product pushes a score only `if (C::cmp(simi[0], ip))` with
+    C = CMin<float, int64_t>, whose heap starts at neutral() = -FLT_MAX): a score enters only if it compares strictly
+    greater than what the heap holds, so NaN (every comparison false), -inf and -FLT_MAX itself are never returned --
+    their slots stay I = -1, D = -FLT_MAX -- and +inf ranks first.  For finite scores this is topk_ip_argsort."""
+    with np.errstate(invalid="ignore", over="ignore"):
+        S = scores_f32(xq, xb)
+    nq, n = S.shape
+    outD = np.full((nq, k), NEG_FILL, dtype=np.float32)
+    outI = np.full((nq, k), -1, dtype=np.int64)
+    for q in range(nq):
+        ok = np.nonzero(S[q] > NEG_FILL)[0]            # False for NaN
+        order = np.lexsort((ok, -S[q, ok].astype(np.float64)))[:k]
+        outI[q, :order.size] = ok[order]
+        outD[q, :order.size] = S[q, ok[order]]
+    return outD, outI
+

@@ -88,3 +88,28 @@ def test_against_torch_topk_and_threaded_variant():
     D2, I2 = search_oracle.topk_ip_threaded(xq, xb, 80, workers=3, query_block=16, block_rows=3000)
     np.testing.assert_array_equal(I2, I)
     np.testing.assert_array_equal(D2, D)
+
+
+def test_heap_rule_for_non_finite_scores():
+    rng = np.random.default_rng(11)
+    xb = rng.standard_normal((300, 16)).astype(np.float16)
+    xq = rng.standard_normal((5, 16)).astype(np.float16)
+    D0, I0 = search_oracle.topk_ip_argsort(xq, xb, 7)
+    D1, I1 = search_oracle.topk_ip_heap(xq, xb, 7)
+    np.testing.assert_array_equal(I0, I1)
+    np.testing.assert_array_equal(D0, D1)
+    xq[:, 0] = 1.0
+    xq[:, 1] = -1.0
+    xb[3, 0] = np.inf        # +inf for every query
+    xb[9, 0] = np.inf
+    xb[4, 0] = -np.inf       # -inf
+    xb[5, 0] = np.nan
+    xb[6, 0] = np.inf
+    xb[6, 1] = np.inf        # inf - inf = NaN
+    D, I = search_oracle.topk_ip_heap(xq, xb, 300)
+    for q in range(5):
+        assert list(I[q, :2]) == [3, 9] and np.isposinf(D[q, :2]).all()
+        assert not set(I[q].tolist()) & {4, 5, 6}
+        assert (I[q, 297:] == -1).all() and (D[q, 297:] == search_oracle.NEG_FILL).all() and (I[q, :297] >= 0).all()
+        assert (np.diff(D[q, 2:297]) <= 0).all()
+

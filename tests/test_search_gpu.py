@@ -843,3 +843,36 @@ def test_candidate_store_follows_the_batch_not_the_largest_batch_seen(gpu_device
     # 256 padded queries x ~330 chunks x 2 lists x 24 records x 80 B ~ 0.33 GB; sized by the 3072-query workspace it was ~4 GB
     assert used < 1.5 * (1 << 30), used
     index.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,k", [(30000, 64, 80), (30000, 600, 80), (100, 9, 80), (70000, 40, 2000)])
+def test_non_finite_scores_follow_the_heap_rule(gpu_device, n, nq, k):
+    """+inf ranks first (lowest row first among several); NaN and -inf scores are never returned, as in faiss's heap --
+    with fewer than k comparable rows the tail is I = -1, D = -FLT_MAX."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(n + nq)
+    xb = _int_corpus(rng, n)           # integer-valued: finite scores are exact, ids must match bit for bit
+    xq = _int_corpus(rng, nq)
+    xq[:, 0] = np.where(np.arange(nq) % 2 == 0, 1.0, -1.0).astype(np.float16)   # sign decides +inf / -inf per query
+    xq[:, 1] = 1.0
+    plant = rng.choice(n, size=min(40, n // 2), replace=False)
+    for i, r in enumerate(plant):
+        kind = i % 4
+        if kind == 0:
+            xb[r, 0] = np.inf
+        elif kind == 1:
+            xb[r, 0] = -np.inf
+        elif kind == 2:
+            xb[r, 1] = np.nan
+        else:
+            xb[r, 0] = np.inf
+            xb[r, 1] = -np.inf                      # NaN for the even queries, -inf for the odd ones
+    index = IndexFlatIP(128)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    Do, Io = search_oracle.topk_ip_heap(xq, xb, k)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert not np.isnan(D).any() and np.isposinf(D[:, 0]).all()
+
