@@ -483,7 +483,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
 // Exact top-k of rows [0, rows) for every query in two launches (see bootstrap_scores / bootstrap_select): the state the
 // rounds would have after those rows.  Its overflow word is the last-but-one (the last belongs to the overflow-safe
 // re-scans).
-int run_bootstrap(proqa_index* idx, long long rows, unsigned nq_pad, int k, hipStream_t st) {
+int run_bootstrap(proqa_index* idx, long long rows, unsigned nq_pad, int k, hipStream_t st, int run_stride = 0) {
   const size_t need = (size_t)idx->ws_nq_pad * round_up<long long>(rows, 32);
   if (need > idx->boot_floats) {
     PROQA_HIP(hipStreamSynchronize(st));
@@ -494,7 +494,7 @@ int run_bootstrap(proqa_index* idx, long long rows, unsigned nq_pad, int k, hipS
     idx->boot_floats = need;
   }
   PROQA_HIP(launch_bootstrap(idx->xb, idx->xq_pad, (int)rows, nq_pad, k, idx->boot_scores, idx->run_keys, idx->run_n, idx->tau,
-                             idx->stat_dev, idx->overflow + kMaxRounds - 2, st));
+                             idx->stat_dev, idx->overflow + kMaxRounds - 2, st, run_stride));
   return PROQA_OK;
 }
 
@@ -676,6 +676,7 @@ struct OnePassPlan {
 };
 
 const bool kOnePass = !(getenv("PROQA_ONE_PASS") && atoi(getenv("PROQA_ONE_PASS")) == 0);   // developer A/B switch
+const bool kOnePassTwoStep = !(getenv("PROQA_ONE_PASS_TWO_STEP") && atoi(getenv("PROQA_ONE_PASS_TWO_STEP")) == 0);   // the same, for its sample
 constexpr size_t kOnePassMaxStoreBytes = 24ull << 30;   // a batch whose store would be larger is searched in groups
 
 OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool latency_bound) {
@@ -719,6 +720,26 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool la
   return p;
 }
 
+// steps (2) and (3) of search_one_pass: the thresholds stand, the sample's lists are forgotten; one launch over the shard,
+// one merge, the result written optimistically before the one host sync
+int one_pass_big_launch(proqa_index* idx, const OnePassPlan& pl, const RoundShape& shape, int qw, unsigned n_qtiles, int64_t nq,
+                        int64_t nq_pad, int k, const PageOut& out, hipStream_t st, int sample_rounds, bool* done) {
+  (void)pl;
+  PROQA_HIP(hipMemsetAsync(idx->run_n, 0, (size_t)idx->ws_nq_pad * sizeof(unsigned), st));
+  unsigned* word = idx->overflow + 1;   // [1]: the pass overflowed, [2]: a query came back short
+  if (int rc = run_round(idx, Slab{0, idx->n}, qw, n_qtiles, (unsigned)nq_pad, k, false, false, false, word, st, nullptr, nullptr,
+                         shape))
+    return rc;
+  PROQA_HIP(launch_flag_short_lists(idx->run_n, nq, (unsigned)k, word + 1, st));
+  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, out.idx_offset, out.D, out.I, out.out_stride, 0, idx->overflow, nullptr,
+                            idx->mirror, idx->stat_dev, st));
+  PROQA_HIP(hipEventRecord(idx->ev[1], st));
+  PROQA_HIP(hipStreamSynchronize(st));
+  idx->stats.rounds += sample_rounds + 1;
+  *done = !idx->mirror->overflow[1] && !idx->mirror->overflow[2];
+  return PROQA_OK;
+}
+
 // returns PROQA_OK with *done = false when the estimate failed (the caller searches page by page)
 int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int k,
                     const PageOut& out, hipStream_t st, bool* done) {
@@ -732,6 +753,66 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   }
   // (1) thresholds from the sample (the round words were zeroed by prep_queries).  Overflow in here is harmless: it loosens the estimate.
   const int r = pl.r;
+  // A rank beyond the bootstrap's (r = 512, 1024: thousands of queries with k in the thousands) would need ~7 rounds of
+  // r (g - 1) candidates each to reach the r-th best of the sample (6.8 k candidates per query for k = 10000: 4.5 of the
+  // 29 ms of 6980 queries over 8.8M rows).  Two steps instead: the bootstrap's rank-r' score t' (r' ~ 64 of 8192 rows)
+  // is a coarse estimate of the same quantile; ONE round over the rest of the sample against t' logs c = r' m / 8192
+  // rows per query (~2 k), with a spread of 1 / sqrt(r'), and its merge keeps the best r of them: the r-th best of the
+  // sample, exactly, unless fewer than r - r' rows beat t' (below; the big launch then overflows and the search goes
+  // page by page) or more than the merge holds (the estimate loosens).
+  if (r > kBootstrapMaxK && kOnePassTwoStep && idx->bootstrap_rows > 0 && pl.n_sample >= 8ll * kBootstrapMaxRows) {
+    const long long boot_rows = kBootstrapMaxRows;
+    const long long m = pl.n_sample - boot_rows;
+    // Fewer than r - r' of the m sample rows beat the r'-th best of the bootstrap's 8192 iff the (r - r')-th best of those
+    // m rows is among the best r' of all m + 8192: with lambda = (r - r') 8192 / m head rows expected above that score,
+    // a Poisson upper tail P(X >= r').  The smallest r' that puts it below 1e-12 per query.
+    auto poisson_tail = [](double lambda, int at_least) {
+      double term = std::exp(-lambda), below = 0.0;   // P(X = 0)
+      for (int i = 0; i < at_least; ++i) {
+        below += term;
+        term *= lambda / (double)(i + 1);
+      }
+      double tail = 0.0;                                // sum the tail itself: 1 - below loses it to rounding
+      for (int i = at_least; i < at_least + 200; ++i) {
+        tail += term;
+        term *= lambda / (double)(i + 1);
+      }
+      (void)below;
+      return tail;
+    };
+    int r1 = 0;
+    double c = 0.0;
+    for (int cand = 32; cand <= kBootstrapMaxK; cand += 16) {
+      c = (double)cand * (double)m / (double)boot_rows;
+      if (poisson_tail((double)(r - cand) * (double)boot_rows / (double)m, cand) < 1e-12) {
+        r1 = cand;
+        break;
+      }
+    }
+    if (r1 && c * (1.0 + 5.0 / std::sqrt((double)r1)) + r1 <= (double)kBigSortKeys) {
+      if (int rc = run_bootstrap(idx, boot_rows, (unsigned)nq_pad, r1, st, r)) return rc;
+      // the sample slab: the middle of the shard (the bootstrap looked at its head)
+      long long r0 = std::max<long long>(boot_rows, ((idx->n - m) / 2) / kStageRows * kStageRows);
+      if (r0 + m > idx->n) r0 = idx->n - m;
+      RoundShape sample_shape;
+      sample_shape.want_chunks = round_up<unsigned>((unsigned)std::ceil(c / 8.0), 8);   // ~4 records per lane list
+      sample_shape.lane_cap = (unsigned)kOnePassLaneCap;
+      sample_shape.sort_cap = kBigSortKeys;
+      if (int rc = run_round(idx, Slab{r0, r0 + m}, qw, n_qtiles, (unsigned)nq_pad, r, false, false, false, idx->overflow, st,
+                             nullptr, nullptr, sample_shape))
+        return rc;
+      if (kDebugCand) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> per_query((size_t)nq);
+        (void)hipMemcpy(per_query.data(), idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0;
+        for (int64_t q = 0; q < nq; ++q) tot += per_query[q];
+        fprintf(stderr, "two-step sample: bootstrap rank %d of %lld rows, then rows [%lld, %lld) for rank %d: %.0f candidates per query "
+                "(expected %.0f)\n", r1, boot_rows, r0, r0 + m, r, (double)tot / (double)nq, c);
+      }
+      return one_pass_big_launch(idx, pl, shape, qw, n_qtiles, nq, nq_pad, k, out, st, 2, done);
+    }
+  }
   long long boot = 0;
   if (idx->bootstrap_rows > 0 && r <= kBootstrapMaxK && r <= idx->bootstrap_rows / 4 && pl.n_sample >= 4ll * idx->bootstrap_rows)
     boot = std::min<long long>(idx->bootstrap_rows, kBootstrapMaxRows);
@@ -767,22 +848,19 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
                            nullptr))
       return rc;
     seen += slabs[i].r1 - slabs[i].r0;
+    if (kDebugCand) {
+      (void)hipStreamSynchronize(st);
+      std::vector<unsigned long long> per_query((size_t)nq);
+      (void)hipMemcpy(per_query.data(), idx->stat_dev, (size_t)nq * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      unsigned long long c = 0;
+      for (int64_t q = 0; q < nq; ++q) c += per_query[q];
+      unsigned ov = 0;
+      (void)hipMemcpy(&ov, idx->overflow, sizeof ov, hipMemcpyDeviceToHost);
+      fprintf(stderr, "sample round %zu: rows [%lld, %lld), rank %d, cumulative candidates %llu (%.0f per query), overflow word %u\n", i,
+              slabs[i].r0, slabs[i].r1, r, c, (double)c / (double)nq, ov);
+    }
   }
-  // (2) keep the thresholds, forget the sample's lists; one launch over the shard, one merge
-  PROQA_HIP(hipMemsetAsync(idx->run_n, 0, (size_t)idx->ws_nq_pad * sizeof(unsigned), st));
-  unsigned* word = idx->overflow + 1;   // [1]: the pass overflowed, [2]: a query came back short
-  if (int rc = run_round(idx, Slab{0, idx->n}, qw, n_qtiles, (unsigned)nq_pad, k, false, false, false, word, st, nullptr, nullptr,
-                         shape))
-    return rc;
-  PROQA_HIP(launch_flag_short_lists(idx->run_n, nq, (unsigned)k, word + 1, st));
-  // (3) results, optimistically, before the one host sync
-  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, out.idx_offset, out.D, out.I, out.out_stride, 0, idx->overflow, nullptr,
-                            idx->mirror, idx->stat_dev, st));
-  PROQA_HIP(hipEventRecord(idx->ev[1], st));
-  PROQA_HIP(hipStreamSynchronize(st));
-  idx->stats.rounds += (int)slabs.size() + 1;
-  *done = !idx->mirror->overflow[1] && !idx->mirror->overflow[2];
-  return PROQA_OK;
+  return one_pass_big_launch(idx, pl, shape, qw, n_qtiles, nq, nq_pad, k, out, st, (int)slabs.size(), done);
 }
 
 int finish_pending(proqa_index* idx, int* rewritten);

@@ -115,10 +115,11 @@ hipError_t launch_gather_index_rows(const void* xb16, const float* xb32, long lo
 // *flag = 1 if any of the nq lists holds fewer than `want` keys
 hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag, hipStream_t st);
 // exact top-k of rows [0, n_rows) (n_rows <= kBootstrapMaxRows, k <= kBootstrapMaxK) for every query: run_keys / run_n /
-// tau as the geometric rounds would leave them after those rows.  scores: [nq_pad, round_up(n_rows, 32)] floats
+// tau as the geometric rounds would leave them after those rows.  scores: [nq_pad, round_up(n_rows, 32)] floats.
+// run_stride (0 = k): keys per query in run_keys when the list that follows is longer than this k (search_one_pass)
 hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,
                             unsigned long long* run_keys, unsigned* run_n, float* tau, unsigned long long* stat,
-                            unsigned* overflow, hipStream_t st);
+                            unsigned* overflow, hipStream_t st, int run_stride = 0);
 // overflow (optional): the kOverflowWords round words of the page that follows are zeroed
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,

@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(kBootWaves * 64) void bootstrap_scores(const char* 
 // overflow flag; the host then repeats the page without the bootstrap.
 template <int E>   // keys per thread: n_rows <= 256 E
 __global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* __restrict__ S, int n_rows, int s_stride,
-                                                                  int k, unsigned long long* __restrict__ run_keys,
+                                                                  int k, int run_stride, unsigned long long* __restrict__ run_keys,
                                                                   unsigned* __restrict__ run_n, float* __restrict__ tau,
                                                                   unsigned long long* __restrict__ stat_candidates,
                                                                   unsigned* __restrict__ overflow) {
@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* _
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
       const unsigned i = (unsigned)tid * NK + j;
-      if (i < keep) run_keys[(size_t)q * k + i] = v[j];
+      if (i < keep) run_keys[(size_t)q * run_stride + i] = v[j];
       if (i + 1 == (unsigned)k && keep == (unsigned)k) tau[q] = float_from_ord((unsigned)(v[j] >> 32));
     }
     if (tid == 0) {
@@ -1596,15 +1596,16 @@ hipError_t launch_query_margins(const void* xq, int dtype, long long nq, long lo
 
 hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,
                             unsigned long long* run_keys, unsigned* run_n, float* tau, unsigned long long* stat,
-                            unsigned* overflow, hipStream_t st) {
+                            unsigned* overflow, hipStream_t st, int run_stride) {
+  if (run_stride <= 0) run_stride = k;
   const int s_stride = (n_rows + 31) / 32 * 32;
   const unsigned row_tiles = (unsigned)(s_stride / 32);
   const unsigned per_wg = kBootWaves * kBootTilesPerWave;
   hipLaunchKernelGGL(bootstrap_scores, dim3((row_tiles + per_wg - 1) / per_wg, nq_pad / 32), dim3(kBootWaves * 64), 0, st,
                      xb, xq_pad, n_rows, s_stride, scores);
 #define PROQA_SELECT_CASE(E)                                                                                            \
-  hipLaunchKernelGGL(bootstrap_select<E>, dim3(nq_pad), dim3(kMergeThreads), 0, st, scores, n_rows, s_stride, k, run_keys, \
-                     run_n, tau, stat, overflow)
+  hipLaunchKernelGGL(bootstrap_select<E>, dim3(nq_pad), dim3(kMergeThreads), 0, st, scores, n_rows, s_stride, k, run_stride, \
+                     run_keys, run_n, tau, stat, overflow)
   if (n_rows <= 4 * kMergeThreads)
     PROQA_SELECT_CASE(4);
   else if (n_rows <= 8 * kMergeThreads)
