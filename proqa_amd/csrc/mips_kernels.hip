@@ -603,10 +603,11 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
-  // (the one-pass merge of a large k gathers ~8 records from each of 1024 lists per pass: a longer queue; big pages and
+  // (the one-pass merge of a large k gathers ~8 records from each of 1024 lists per pass, ~8.1 k +- 0.1 k: a queue of
+  // 12288 -- with 8192 four queries in ten overflowed it by a hundred records or two, 5.5 vs 5.2 ms; big pages and
   // the one-pass search's sample round put ~2 k records of a query into one pass: 4096 -- with 1024, half of them took the
   // one-at-a-time path and the sample merge of 6980 queries 1.4-1.5 ms instead of 1.1)
-  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 8192 : (CAP > kMaxSortKeys ? 4096 : 1024);
+  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 12288 : (CAP > kMaxSortKeys ? 4096 : 1024);
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
   __shared__ unsigned long long s_dummy;   // target of the stores of lanes that have nothing to append
