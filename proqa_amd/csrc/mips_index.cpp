@@ -797,7 +797,7 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
       RoundShape sample_shape;
       sample_shape.want_chunks = round_up<unsigned>((unsigned)std::ceil(c / 8.0), 8);   // ~4 records per lane list
       sample_shape.lane_cap = (unsigned)kOnePassLaneCap;
-      sample_shape.sort_cap = kBigSortKeys;
+      sample_shape.sort_cap = c * (1.0 + 5.0 / std::sqrt((double)r1)) + r1 <= (double)kMidSortKeys ? kMidSortKeys : kBigSortKeys;
       if (int rc = run_round(idx, Slab{r0, r0 + m}, qw, n_qtiles, (unsigned)nq_pad, r, false, false, false, idx->overflow, st,
                              nullptr, nullptr, sample_shape))
         return rc;

@@ -22,6 +22,7 @@ constexpr int kPageK = kMaxSortKeys / 2;  // k up to here is one page at the sma
 // k > kPageK (retrieval/trec_process.py:76 asks for 10000, qa/online_sampler.py:113 for 5000): pages of kBigPageK
 // results on a merge that holds kBigSortKeys keys (64 KiB of LDS), with deeper lane lists and more corpus chunks
 constexpr int kBigSortKeys = 8192;
+constexpr int kMidSortKeys = 4096;  // the sample round of the one-pass search (~2 k candidates per query): four workgroups per CU
 constexpr int kBigPageK = kBigSortKeys / 2;
 // One-pass search of a large k (see search_one_pass in mips_index.cpp): ONE filter launch over the whole shard against
 // thresholds estimated from a sample, and ONE merge per query that holds up to kOnePassSortKeys keys (128 KiB of LDS)

@@ -599,7 +599,7 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
 // T = threads: 256, or 512 for the largest CAP (one workgroup per CU there: the second wave per SIMD hides the latencies)
 template <bool EXACT, int CAP, int T = kMergeThreads>
-__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2 : (EXACT ? 4 : 8))) void topk_merge(MergeArgs a) {
+__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? 2 : (CAP > kMaxSortKeys || EXACT ? 4 : 8))) void topk_merge(MergeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
   // 12288 -- with 8192 four queries in ten overflowed it by a hundred records or two, 5.5 vs 5.2 ms; big pages and
   // the one-pass search's sample round put ~2 k records of a query into one pass: 4096 -- with 1024, half of them took the
   // one-at-a-time path and the sample merge of 6980 queries 1.4-1.5 ms instead of 1.1)
-  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 12288 : (CAP > kMaxSortKeys ? 4096 : 1024);
+  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 12288 : (CAP > kMidSortKeys ? 4096 : (CAP > kMaxSortKeys ? 3072 : 1024));
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
   __shared__ unsigned long long s_dummy;   // target of the stores of lanes that have nothing to append
@@ -953,16 +953,18 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMaxSortKeys ? 2
     unsigned long long v[8];
     finish(v);
   } else if constexpr (CAP > 8 * T) {
-    static_assert(CAP == 8 * T || CAP == 32 * T || CAP == 64 * T, "largest sort");
+    static_assert(CAP == 16 * T || CAP == 32 * T || CAP == 64 * T, "largest sort");
     if (total <= 16u * T) {
       unsigned long long v[16];
       finish(v);
-    } else if (total <= 32u * T) {
-      unsigned long long v[32];
-      finish(v);
-    } else if constexpr (CAP > 32 * T) {
-      unsigned long long v[64];
-      finish(v);
+    } else if constexpr (CAP > 16 * T) {
+      if (total <= 32u * T) {
+        unsigned long long v[32];
+        finish(v);
+      } else if constexpr (CAP > 32 * T) {
+        unsigned long long v[64];
+        finish(v);
+      }
     }
   }
   PROQA_STAMP(6);
@@ -1646,8 +1648,10 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   } else {
     if (a.sort_cap > kBigSortKeys)
       hipLaunchKernelGGL((topk_merge<false, kOnePassSortKeys, kOnePassMergeThreads>), dim3(nq_pad), dim3(kOnePassMergeThreads), 0, st, a);
-    else if (big)
+    else if (a.sort_cap > kMidSortKeys)
       hipLaunchKernelGGL((topk_merge<false, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    else if (big)
+      hipLaunchKernelGGL((topk_merge<false, kMidSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
     else
       hipLaunchKernelGGL((topk_merge<false, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   }
