@@ -876,3 +876,36 @@ def test_non_finite_scores_follow_the_heap_rule(gpu_device, n, nq, k):
     np.testing.assert_array_equal(D, Do)
     assert not np.isnan(D).any() and np.isposinf(D[:, 0]).all()
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bounds,k", [([(0, 60), (60, 5000), (5000, 9000)], 80), ([(0, 3000), (3000, 9000)], 300)])
+def test_shards_with_non_finite_scores_merge_like_the_unsharded_search(gpu_device, bounds, k):
+    """The rank merge of per-shard lists with +inf scores, excluded NaN / -inf rows and a shard shorter than k (its list ends
+    in I = -1 slots) equals the heap rule applied to the whole corpus."""
+    import torch
+    from proqa_amd.index import IndexFlatIP, merge_topk_device
+    rng = np.random.default_rng(len(bounds) * 100 + k)
+    xb = _int_corpus(rng, 9000)
+    xq = _int_corpus(rng, 70)
+    xq[:, 0] = np.where(np.arange(70) % 2 == 0, 1.0, -1.0).astype(np.float16)
+    xq[:, 1] = 1.0
+    for i, r in enumerate(rng.choice(9000, size=60, replace=False)):
+        if i % 3 == 0:
+            xb[r, 0] = np.inf
+        elif i % 3 == 1:
+            xb[r, 1] = np.nan
+        else:
+            xb[r, 0] = -np.inf
+    xb[5, 0] = np.inf       # the short first shard holds one of each kind
+    xb[6, 1] = np.nan
+    tq = torch.from_numpy(xq).to(gpu_device)
+    parts = []
+    for lo, hi in bounds:
+        ix = IndexFlatIP(128)
+        ix.add_device(torch.from_numpy(xb[lo:hi]).to(gpu_device))
+        parts.append(ix.search_device(tq, k, idx_offset=lo))
+    D, I = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    Do, Io = search_oracle.topk_ip_heap(xq, xb, k)
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do)
+
