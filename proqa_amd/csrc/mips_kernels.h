@@ -27,7 +27,7 @@ constexpr int kBigPageK = kBigSortKeys / 2;
 // One-pass search of a large k (see search_one_pass in mips_index.cpp): ONE filter launch over the whole shard against
 // thresholds estimated from a sample, and ONE merge per query that holds up to kOnePassSortKeys keys (128 KiB of LDS)
 constexpr int kOnePassSortKeys = 16384;
-constexpr int kOnePassMergeThreads = 512;  // of that merge (the others run kMergeThreads)
+constexpr int kOnePassMergeThreads = 1024;  // of that merge (the others run kMergeThreads)
 constexpr int kOnePassLaneCap = 24;  // records per lane list of that launch (the chunk count aims at ~8 per list)
 constexpr int kLaneCap = 8;         // records a lane can log per (chunk, query) before spilling
 constexpr int kBigLaneCap = 32;     // the same for big pages (thousands of candidates per query and round)

@@ -611,7 +611,10 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? 2
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
   __shared__ unsigned long long s_dummy;   // target of the stores of lanes that have nothing to append
-  static_assert(kBigLaneCap <= 64 && 2 * T <= 1024, "work item packing: (list within the pass << 6) | slot, 16 bits");
+  // work item = (list within the pass << kSlotBits) | slot in 16 bits: 1024 lists x 64 slots, or (T = 1024) 2048 x 32
+  constexpr int kSlotBits = 2 * T > 1024 ? 5 : 6;
+  constexpr unsigned kSlotMask = (1u << kSlotBits) - 1u;
+  static_assert(kBigLaneCap <= (1 << kSlotBits) && kOnePassLaneCap <= (1 << kSlotBits) && 2 * T <= (65536 >> kSlotBits), "work item packing");
   const unsigned lane_cap = a.store.lane_cap;
   const unsigned q = blockIdx.x;
   const int tid = threadIdx.x;
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? 2
         const unsigned pos = atomicAdd(&s_n_work, cnt[e]);   // LDS
         for (unsigned s = 0; s < cnt[e]; ++s) {
           if (pos + s < kWorkCap)
-            s_work[pos + s] = (unsigned short)((t << 6) | s);
+            s_work[pos + s] = (unsigned short)((t << kSlotBits) | s);
           else
             keep_scores(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
         }
@@ -717,9 +720,9 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? 2
         const unsigned w1 = w0 + T;
         const bool two = w1 < n_work;
         const unsigned i0 = s_work[w0], i1 = two ? s_work[w1] : i0;
-        const unsigned l0 = base + (i0 >> 6), l1 = base + (i1 >> 6);
-        const uint4* r0 = (const uint4*)(st.lane_log + lane_list_index(st, l0 >> 1, q, (int)(l0 & 1)) * lane_cap + (i0 & 63u));
-        const uint4* r1 = (const uint4*)(st.lane_log + lane_list_index(st, l1 >> 1, q, (int)(l1 & 1)) * lane_cap + (i1 & 63u));
+        const unsigned l0 = base + (i0 >> kSlotBits), l1 = base + (i1 >> kSlotBits);
+        const uint4* r0 = (const uint4*)(st.lane_log + lane_list_index(st, l0 >> 1, q, (int)(l0 & 1)) * lane_cap + (i0 & kSlotMask));
+        const uint4* r1 = (const uint4*)(st.lane_log + lane_list_index(st, l1 >> 1, q, (int)(l1 & 1)) * lane_cap + (i1 & kSlotMask));
         uint4 b0[5], b1[5];
 #pragma unroll
         for (int g = 0; g < 5; ++g) b0[g] = r0[g];
@@ -742,8 +745,8 @@ __global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? 2
         live = lane_on && w < n_work;
         if (!live) return make_uint4(0u, 0u, 0u, 0u);
         const unsigned item = s_work[w];
-        const unsigned l = base + (item >> 6);
-        const uint4* r = (const uint4*)(st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * lane_cap + (item & 63u));
+        const unsigned l = base + (item >> kSlotBits);
+        const uint4* r = (const uint4*)(st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * lane_cap + (item & kSlotMask));
         return r[piece];
       };
       auto keep = [&](const uint4& v, bool live) {
