@@ -147,7 +147,7 @@ __device__ __forceinline__ void log_columns(const f32x16& acc, bool hit, float t
 //     stages earlier (counted vmcnt: DMA(s+2) stays in flight), so stage s+1 is readable from unit 3 on.
 template <int QW, int NW, bool INCLUSIVE, bool BOUNDED>
 __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
-  static_assert((QW == 1 || QW == 2) && NW == 8 || QW == 4 && NW == 4, "8 waves x 32/64 queries or 4 waves x 128 queries");
+  static_assert(((QW == 1 || QW == 2) && NW == 8) || (QW == 4 && NW == 4), "8 waves x 32/64 queries or 4 waves x 128 queries");
   // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads)
   __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytes];
 
@@ -599,7 +599,8 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
 // T = threads: 256, or 512 for the largest CAP (one workgroup per CU there: the second wave per SIMD hides the latencies)
 template <bool EXACT, int CAP, int T = kMergeThreads>
-__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? 2 : (CAP > kMaxSortKeys || EXACT ? 4 : 8))) void topk_merge(MergeArgs a) {
+__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (EXACT ? 1 : 2) : (CAP > kMaxSortKeys || EXACT ? 4 : 8)))
+void topk_merge(MergeArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
