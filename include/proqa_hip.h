@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROQA_ABI_VERSION 3
+#define PROQA_ABI_VERSION 4
 
 /* element types of embedding matrices (the .npy index is '<f2' under --fp16, else '<f4':
  * retrieval/get_embed.py:139) */
@@ -83,6 +83,13 @@ int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out);
  * same, the merge more.  Values beyond the fp16 range (|x| > 65504) are refused.
  * proqa_index_allow_rounding(idx, 1) opts out: float32 inputs are rounded to fp16 instead. */
 int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype);
+/* np.load(path) + index.add(xb[row0:row0+n]) (retrieval/eval_retrieval.py:99-102) in one call: appends rows
+ * [row0, row0 + n) of a 2-D .npy file ('<f2' or '<f4', 128 columns; n < 0 = up to the last row).  n_readers host
+ * threads (<= 0: 4) pread() the rows into a ring of pinned 32 MiB pieces while the pieces read before them travel to
+ * HBM, so that the file read, the PCIe transfer and (float32 files) the conversion overlap and no pageable copy of the
+ * corpus is made.  A rank of a row-sharded index loads only its own row range this way.  Same precision rules as
+ * proqa_index_add.  All or nothing: on failure the index still holds the rows it had. */
+int proqa_index_add_npy(proqa_index* idx, const char* path, int64_t row0, int64_t n, int n_readers);
 /* same, source already in HBM (used by the synthetic benchmark and the sharded path) */
 int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int dtype, void* stream);
 /* adopt caller-owned fp16 rows already in HBM without copying; the caller keeps them alive

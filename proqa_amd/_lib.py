@@ -69,6 +69,7 @@ SIGNATURES = {
     "proqa_device_info": (c_int, [ctypes.POINTER(c_int), c_char_p, c_size_t]),
     "proqa_index_create": (c_int, [c_int, c_int64, ctypes.POINTER(c_void_p)]),
     "proqa_index_add": (c_int, [c_void_p, c_void_p, c_int64, c_int]),
+    "proqa_index_add_npy": (c_int, [c_void_p, c_char_p, c_int64, c_int64, c_int]),
     "proqa_index_add_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "proqa_index_adopt_device": (c_int, [c_void_p, c_void_p, c_int64]),
     "proqa_index_allow_rounding": (c_int, [c_void_p, c_int]),
@@ -196,7 +197,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.proqa_abi_version() != 3:
+        if lib.proqa_abi_version() != 4:
             raise RuntimeError("libproqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
         return lib

@@ -13,8 +13,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <fcntl.h>
+#include <unistd.h>
+#include <cerrno>
 
 #include "common.h"
 #include "mips_kernels.h"
@@ -203,6 +210,69 @@ int ensure_stage(proqa_index* idx, size_t bytes) {
   }
   return PROQA_OK;
 }
+
+constexpr int64_t kAddPieceRows = 1 << 20;   // rows per upload piece of proqa_index_add (256 MiB of fp16 rows)
+constexpr int kLoaderSlots = 4;               // pinned pieces of proqa_index_add_npy: two being read, two on their way up
+constexpr int64_t kLoaderPieceBytes = 32 << 20;
+
+// One piece of float32 rows from host memory -> fp16 rows [row, row+m) of the index, with the exact-float32 bookkeeping.
+// Rows [idx->n, row) are the earlier pieces of the same call (idx->n counts the rows of completed calls only).
+int ingest_f32_piece(proqa_index* idx, int64_t row, int64_t m, const void* src_host, bool pinned, hipStream_t st) {
+  if (int rc = ensure_stage(idx, (size_t)kAddPieceRows * kDim * 4)) return rc;
+  char* dst = idx->xb + (size_t)row * kDim * 2;
+  if (pinned)
+    PROQA_HIP(hipMemcpyAsync(idx->stage_dev, src_host, (size_t)m * kDim * 4, hipMemcpyHostToDevice, st));
+  else
+    PROQA_HIP(hipMemcpy(idx->stage_dev, src_host, (size_t)m * kDim * 4, hipMemcpyHostToDevice));
+  PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), st));
+  PROQA_HIP(launch_convert_f32_to_f16((const float*)idx->stage_dev, dst, m * kDim, idx->inexact, st));
+  unsigned bad = 0;
+  if (int rc = read_inexact(idx, "index_add", st, &bad)) return rc;
+  if (bad && !idx->allow_rounding && !idx->exact) {
+    // first values fp16 cannot hold: from here on the index keeps float32 copies.  enable_exact covers the
+    // rows counted in idx->n; the pieces of THIS call that were already uploaded are caught up here
+    if (int rc = enable_exact(idx, st)) return rc;
+    if (int rc = finish_rows_exact(idx, idx->n, row - idx->n, nullptr, st)) return rc;   // earlier pieces were exact
+  }
+  if (int rc = finish_rows_exact(idx, row, m, (const float*)idx->stage_dev, st)) return rc;
+  if (idx->exact) PROQA_HIP(hipStreamSynchronize(st));   // stage_dev is reused by the next piece
+  return PROQA_OK;
+}
+
+// state shared by the reader threads of proqa_index_add_npy and the uploading thread; the destructor stops and joins
+// the readers before anything they touch goes away
+struct NpyRing {
+  int fd = -1;
+  char* pinned = nullptr;
+  hipStream_t stream = nullptr;                        // uploads that read the ring
+  hipEvent_t uploaded[kLoaderSlots] = {};
+  int n_slots = 0;
+  int64_t n_pieces = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int64_t next_piece = 0;                              // next piece a reader takes
+  int64_t retired = 0;                                 // pieces (in order) whose upload has completed
+  int64_t filled[kLoaderSlots] = {-1, -1, -1, -1};     // piece that sits in the slot, read completely
+  bool failed = false;
+  char why[256] = {0};
+  std::vector<std::thread> threads;
+  void set_error(const char* msg) {
+    std::lock_guard<std::mutex> lk(m);
+    if (!failed && msg) snprintf(why, sizeof why, "%s", msg);
+    failed = true;
+    cv.notify_all();
+  }
+  ~NpyRing() {
+    set_error(nullptr);
+    for (auto& t : threads)
+      if (t.joinable()) t.join();
+    if (fd >= 0) close(fd);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& e : uploaded)
+      if (e) (void)hipEventDestroy(e);
+    if (pinned) (void)hipHostFree(pinned);
+  }
+};
 
 void free_store(proqa_index* idx) {
   void* ptrs[] = {idx->lane_log, idx->lane_cnt, idx->spill_log, idx->spill_cnt};
@@ -1218,32 +1288,142 @@ int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype) {
   if (int rc = reserve_rows(idx, idx->n + n)) return rc;
   const size_t esz = dtype == PROQA_F16 ? 2 : 4;
   // upload in bounded pieces (the source may be an mmap of a multi-GB .npy)
-  const int64_t piece = 1 << 20;  // rows
-  for (int64_t r0 = 0; r0 < n; r0 += piece) {
-    const int64_t m = std::min(piece, n - r0);
+  for (int64_t r0 = 0; r0 < n; r0 += kAddPieceRows) {
+    const int64_t m = std::min<int64_t>(kAddPieceRows, n - r0);
     const char* src = (const char*)xb + (size_t)r0 * kDim * esz;
-    char* dst = idx->xb + (size_t)(idx->n + r0) * kDim * 2;
     if (dtype == PROQA_F16) {
-      PROQA_HIP(hipMemcpy(dst, src, (size_t)m * kDim * 2, hipMemcpyHostToDevice));
-    } else {
-      if (int rc = ensure_stage(idx, (size_t)piece * kDim * 4)) return rc;
-      PROQA_HIP(hipMemcpy(idx->stage_dev, src, (size_t)m * kDim * 4, hipMemcpyHostToDevice));
-      PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), nullptr));
-      PROQA_HIP(launch_convert_f32_to_f16((const float*)idx->stage_dev, dst, m * kDim, idx->inexact, nullptr));
-      unsigned bad = 0;
-      if (int rc = read_inexact(idx, "index_add", nullptr, &bad)) return rc;
-      if (bad && !idx->allow_rounding && !idx->exact) {
-        // first values fp16 cannot hold: from here on the index keeps float32 copies.  enable_exact covers the
-        // rows counted in idx->n; the pieces of THIS call that were already uploaded are caught up below
-        if (int rc = enable_exact(idx, nullptr)) return rc;
-        if (int rc = finish_rows_exact(idx, idx->n, r0, nullptr, nullptr)) return rc;   // earlier pieces were exact
-      }
-    }
-    if (int rc = finish_rows_exact(idx, idx->n + r0, m, dtype == PROQA_F32 ? (const float*)idx->stage_dev : nullptr,
-                                   nullptr))
+      PROQA_HIP(hipMemcpy(idx->xb + (size_t)(idx->n + r0) * kDim * 2, src, (size_t)m * kDim * 2, hipMemcpyHostToDevice));
+      if (int rc = finish_rows_exact(idx, idx->n + r0, m, nullptr, nullptr)) return rc;
+    } else if (int rc = ingest_f32_piece(idx, idx->n + r0, m, src, /*pinned=*/false, nullptr)) {
       return rc;
-    if (idx->exact) PROQA_HIP(hipDeviceSynchronize());   // stage_dev is reused by the next piece
+    }
   }
+  idx->n += n;
+  return PROQA_OK;
+}
+
+// np.load + index.add of the reference in one call, without the host copy in between: reader threads pread() the rows
+// into a ring of pinned buffers while the pieces read before are on their way over PCIe (see proqa_hip.h).
+int proqa_index_add_npy(proqa_index* idx, const char* path, int64_t row0, int64_t n, int n_readers) {
+  if (!idx || !path) return fail(PROQA_EINVAL, "index_add_npy: NULL argument");
+  proqa_npy_info info;
+  if (int rc = proqa_npy_stat(path, &info)) return rc;
+  if (info.cols != kDim) return fail(PROQA_EINVAL, "index_add_npy: %s holds %lld-d rows, the index %d-d", path, (long long)info.cols, kDim);
+  if (n < 0) n = info.rows - row0;
+  if (row0 < 0 || n < 0 || row0 + n > info.rows)
+    return fail(PROQA_EINVAL, "index_add_npy: rows [%lld, %lld) of a file of %lld rows", (long long)row0, (long long)(row0 + n),
+                (long long)info.rows);
+  if (n == 0) return PROQA_OK;
+  PROQA_ON_DEVICE(idx->device);
+  if (int rc = reserve_rows(idx, idx->n + n)) return rc;
+  if (!idx->io_stream) PROQA_HIP(hipStreamCreateWithFlags(&idx->io_stream, hipStreamNonBlocking));
+  const bool f32 = info.dtype == PROQA_F32;
+  const size_t row_bytes = (size_t)kDim * (f32 ? 4 : 2);
+  const int64_t piece_rows = std::min<int64_t>(kLoaderPieceBytes / (int64_t)row_bytes, n);
+  const size_t piece_bytes = (size_t)piece_rows * row_bytes;
+  const int64_t n_pieces = ceil_div<int64_t>(n, piece_rows);
+  const int n_slots = (int)std::min<int64_t>(kLoaderSlots, n_pieces);
+  NpyRing ring;
+  ring.fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (ring.fd < 0) return fail(PROQA_EIO, "index_add_npy: cannot open %s: %s", path, strerror(errno));
+  const off_t base = (off_t)info.data_offset + (off_t)row0 * (off_t)row_bytes;
+  (void)posix_fadvise(ring.fd, base, (off_t)n * (off_t)row_bytes, POSIX_FADV_SEQUENTIAL);
+  PROQA_HIP(hipHostMalloc((void**)&ring.pinned, piece_bytes * n_slots, hipHostMallocDefault));
+  for (int s = 0; s < n_slots; ++s) PROQA_HIP(hipEventCreateWithFlags(&ring.uploaded[s], hipEventDisableTiming));
+  ring.n_slots = n_slots;
+  ring.n_pieces = n_pieces;
+  // piece p -> slot p % n_slots; a reader may fill it once piece p - n_slots has left the slot (ring.retired counts the
+  // pieces, in order, whose upload has completed)
+  auto read_piece = [&](int64_t p) -> bool {
+    const int64_t m = std::min<int64_t>(piece_rows, n - p * piece_rows);
+    char* dst = ring.pinned + (size_t)(p % n_slots) * piece_bytes;
+    size_t want = (size_t)m * row_bytes, got = 0;
+    const off_t off = base + (off_t)p * (off_t)piece_bytes;
+    while (got < want) {
+      const ssize_t r = pread(ring.fd, dst + got, want - got, off + (off_t)got);
+      if (r < 0 && errno == EINTR) continue;
+      if (r <= 0) {
+        ring.set_error(r < 0 ? strerror(errno) : "file is shorter than its header says");
+        return false;
+      }
+      got += (size_t)r;
+    }
+    return true;
+  };
+  auto reader = [&]() {
+    for (;;) {
+      int64_t p;
+      {
+        std::unique_lock<std::mutex> lk(ring.m);
+        p = ring.next_piece;
+        if (p >= n_pieces || ring.failed) return;
+        ++ring.next_piece;
+        ring.cv.wait(lk, [&] { return ring.failed || p < ring.retired + n_slots; });
+        if (ring.failed) return;
+      }
+      const bool ok = read_piece(p);
+      std::lock_guard<std::mutex> lk(ring.m);
+      if (ok) ring.filled[p % n_slots] = p;
+      ring.cv.notify_all();
+      if (!ok) return;
+    }
+  };
+  if (n_readers <= 0) n_readers = 4;
+  n_readers = (int)std::min<int64_t>(n_readers, std::min<int64_t>(n_pieces, kLoaderSlots));
+  try {
+    for (int t = 0; t < n_readers; ++t) ring.threads.emplace_back(reader);
+  } catch (...) {
+    // (thread limit of a cgroup: the threads that did start keep reading; with none, this thread reads in line)
+  }
+  const bool inline_reads = ring.threads.empty();
+  hipStream_t st = idx->io_stream;
+  ring.stream = st;
+  const int in_flight = std::max(1, n_slots / 2);   // uploads on the stream before the host waits for the oldest
+  for (int64_t p = 0; p < n_pieces; ++p) {
+    const int slot = (int)(p % n_slots);
+    if (inline_reads) {
+      if (!read_piece(p)) break;
+    } else {
+      std::unique_lock<std::mutex> lk(ring.m);
+      ring.cv.wait(lk, [&] { return ring.failed || ring.filled[slot] == p; });
+      if (ring.failed) break;
+    }
+    const int64_t m = std::min<int64_t>(piece_rows, n - p * piece_rows);
+    const int64_t row = idx->n + p * piece_rows;
+    const char* src = ring.pinned + (size_t)slot * piece_bytes;
+    int rc = PROQA_OK;
+    if (!f32) {
+      if (hipError_t e = hipMemcpyAsync(idx->xb + (size_t)row * kDim * 2, src, (size_t)m * row_bytes, hipMemcpyHostToDevice, st))
+        rc = hip_fail(e, "hipMemcpyAsync", __FILE__, __LINE__);
+      else
+        rc = finish_rows_exact(idx, row, m, nullptr, st);
+    } else {
+      rc = ingest_f32_piece(idx, row, m, src, /*pinned=*/true, st);
+    }
+    if (rc == PROQA_OK)
+      if (hipError_t e = hipEventRecord(ring.uploaded[slot], st)) rc = hip_fail(e, "hipEventRecord", __FILE__, __LINE__);
+    if (rc == PROQA_OK && p + 1 >= in_flight) {
+      const int64_t done = p + 1 - in_flight;      // the oldest upload in flight: its slot goes back to the readers
+      if (hipError_t e = hipEventSynchronize(ring.uploaded[done % n_slots])) rc = hip_fail(e, "hipEventSynchronize", __FILE__, __LINE__);
+      std::lock_guard<std::mutex> lk(ring.m);
+      ring.retired = done + 1;
+      ring.cv.notify_all();
+    }
+    if (rc != PROQA_OK) {
+      ring.set_error(nullptr);
+      return rc;               // (~NpyRing joins the readers and releases the ring)
+    }
+  }
+  bool read_failed;
+  {
+    std::lock_guard<std::mutex> lk(ring.m);
+    read_failed = ring.failed;
+  }
+  if (read_failed) {
+    (void)hipStreamSynchronize(st);
+    return fail(PROQA_EIO, "index_add_npy: reading %s failed: %s", path, ring.why);
+  }
+  PROQA_HIP(hipStreamSynchronize(st));
   idx->n += n;
   return PROQA_OK;
 }
@@ -1311,8 +1491,9 @@ int proqa_topk_merge_strided_device(const float* D_parts_dev, const int64_t* I_p
   if (stride_d < nq * k || stride_i < nq * k)
     return fail(PROQA_EINVAL, "topk_merge_device: part strides %lld / %lld are shorter than a part (%lld)", (long long)stride_d,
                 (long long)stride_i, (long long)(nq * k));
+  // (lists of unknown provenance: always the sorting kernels, never the rank merge that trusts the order of its parts)
   PROQA_HIP(launch_merge_lists(D_parts_dev, (const long long*)I_parts_dev, n_parts, nq, k, (long long)stride_d, (long long)stride_i,
-                               D_dev, (long long*)I_dev, as_stream(stream)));
+                               D_dev, (long long*)I_dev, as_stream(stream), nullptr, 0, nullptr, /*parts_sorted=*/false));
   return PROQA_OK;
 }
 

@@ -141,9 +141,13 @@ hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* r
                            hipStream_t st);
 // part p's [nq, k] scores / ids start stride_d / stride_i ELEMENTS after part p-1's (nq*k for dense [n_parts, nq, k] arrays);
 // status_host (optional, pinned host memory, n_parts words) receives status_src[p * status_stride] of every part
+// (also when nq == 0).  parts_sorted: every part is a list as a search reports it (scores descending, ties by ascending id,
+// no NaN, the I = -1 slots at its tail) -- small merges then rank by binary search instead of sorting; lists of unknown
+// order (the public merge entry points) must pass false.
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
                               int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st,
-                              const unsigned* status_src = nullptr, long long status_stride = 0, unsigned* status_host = nullptr);
+                              const unsigned* status_src = nullptr, long long status_stride = 0, unsigned* status_host = nullptr,
+                              bool parts_sorted = true);
 hipError_t launch_convert_f32_to_f16(const float* src, void* dst, long long n, unsigned* inexact, hipStream_t st);
 // exact-float32 mode helpers
 hipError_t launch_upconvert_f16_to_f32(const void* src, float* dst, long long n, hipStream_t st);

@@ -1689,10 +1689,14 @@ hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* r
 
 hipError_t launch_merge_lists(const float* D_parts, const long long* I_parts, int n_parts, long long nq,
                               int k, long long stride_d, long long stride_i, float* D, long long* I, hipStream_t st,
-                              const unsigned* status_src, long long status_stride, unsigned* status_host) {
-  if (nq == 0) return hipSuccess;
+                              const unsigned* status_src, long long status_stride, unsigned* status_host, bool parts_sorted) {
+  if (nq == 0) {   // nothing to merge, but the caller still reads every part's status word
+    if (status_host && status_src)
+      hipLaunchKernelGGL(copy_status_words, dim3(1), dim3(256), 0, st, status_src, status_stride, n_parts, status_host);
+    return hipGetLastError();
+  }
   const long long per_q = (long long)n_parts * k;
-  if (per_q <= kRankMergeKeys && n_parts <= kRankMergeParts) {
+  if (parts_sorted && per_q <= kRankMergeKeys && n_parts <= kRankMergeParts) {
     hipLaunchKernelGGL(merge_sorted_lists, dim3((unsigned)nq), dim3(kMergeThreads), (size_t)per_q * 8, st, D_parts, I_parts,
                        n_parts, nq, k, stride_d, stride_i, D, I, status_src, status_stride, status_host);
     return hipGetLastError();

@@ -233,7 +233,12 @@ int proqa_sharded_search_device(proqa_index* idx, proqa_comm* c, const void* xq_
       }
       redo = redo || c->status_host[r] != 0;
     }
-    if (!redo) return PROQA_OK;
+    if (!redo) {
+      // (a finish that failed behind an all-zero exchange: the lists were exchanged, nobody waits, but this rank's
+      // D / I may be incomplete -- report it instead of success)
+      if (rc_local != PROQA_OK) return fail(rc_local, "%s", local_error);
+      return PROQA_OK;
+    }
     // some rank rewrote its list (here: `rewritten`): exchange and merge once more, with final lists
     if (rc_local == PROQA_OK) PROQA_HIP(hipMemsetAsync(status_dev, 0, sizeof(uint32_t), st));
     (void)rewritten;

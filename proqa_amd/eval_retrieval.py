@@ -3,6 +3,7 @@
 Drop-in for /root/reference/retrieval/eval_retrieval.py:
 
     python eval_retrieval.py RAW_DATA INDEXPATH QUERY_EMBED DB [--topk 80] [--num-workers 10]
+    torchrun --nproc-per-node 8 eval_retrieval.py ...     # the corpus row-sharded over 8 MI355X (see search())
 
 Same inputs (QA JSON-lines, para_embed.npy, query .npy, sqlite DB, idx_id.json), same stdout
 lines `Top {k} Recall for {n} QA pairs: {mean} ...`.  The faiss.IndexFlatIP search (:102-104)
@@ -12,6 +13,7 @@ reference (:92-96).
 """
 import argparse
 import json
+import os
 from collections import defaultdict
 from functools import partial
 from multiprocessing import Pool as ProcessPool
@@ -79,25 +81,80 @@ def convert_idx2id(idxs, mapping_path=DEFAULT_IDX_ID):
     return [[idx_id[str(int(i))] for i in row] for row in idxs]
 
 
-def search(indexpath, query_embed, topk, chunk_rows=1 << 21, allow_rounding=False):
-    """np.load + IndexFlatIP.add + search of the reference, on the GPU (index streamed from an mmap).
+def dist_env():
+    """(world_size, rank, local_rank) of a torchrun launch; (1, 0, 0) for a plain `python eval_retrieval.py`."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 1, 0, 0
+    return world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
-    fp16 .npy files (get_embed.py --fp16) are scanned as they are.  float32 files whose values fp16
-    cannot hold are searched in exact-float32 mode (float32 copies of the rows in HBM, fp16 scan +
-    exact re-scoring) unless allow_rounding asks for the rounded, faster variant."""
+
+LAST_RUN_STATS = {}     # filled by search() / main(): seconds per stage of the last run (bench.py's search.cli_eval reads it)
+
+
+def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
+    """np.load + IndexFlatIP.add + search of the reference (:98-104), on the GPU.
+
+    The index file goes from disk to HBM inside the library (proqa_index_add_npy: reader threads -> pinned ring -> PCIe,
+    no host copy of the corpus).  fp16 .npy files (get_embed.py --fp16) are scanned as they are.  float32 files whose
+    values fp16 cannot hold are searched in exact-float32 mode (float32 copies of the rows in HBM, fp16 scan + exact
+    re-scoring) unless allow_rounding asks for the rounded, faster variant.
+
+    Under torchrun (WORLD_SIZE > 1) the corpus is row-sharded: every rank loads ONLY rows [r*N/G, (r+1)*N/G) of the file
+    into its GPU, all ranks search all queries, one all-gather of the per-shard lists (RCCL over xGMI) and a merge give
+    every rank the result of the single-GPU search, bit for bit (ShardedIndexFlatIP)."""
+    import time
     from . import npy
-    from .index import IndexFlatIP
     xq = npy.load(query_embed)
     info = npy.stat(indexpath)
     if info["cols"] != 128 or xq.shape[1] != 128:
         raise ValueError("embeddings must be 128-d")
-    xb = npy.memmap(indexpath)
-    index = IndexFlatIP(128, capacity=info["rows"])
-    if allow_rounding:
-        index.allow_rounding(True)
-    for r0 in range(0, info["rows"], chunk_rows):
-        index.add(np.ascontiguousarray(xb[r0:r0 + chunk_rows]))
-    return index.search(xq, topk)
+    world, rank, local_rank = dist_env()
+    t0 = time.perf_counter()
+    if world == 1:
+        from .index import IndexFlatIP
+        index = IndexFlatIP(128, capacity=info["rows"])
+        if allow_rounding:
+            index.allow_rounding(True)
+        index.add_npy(indexpath, 0, info["rows"], readers)
+        t1 = time.perf_counter()
+        D, I = index.search(xq, topk)
+        rows_here = info["rows"]
+    else:
+        import torch
+        import torch.distributed as dist
+        from .index import ShardedIndexFlatIP
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        if not dist.is_initialized():
+            # RCCL ("nccl") on ROCm.  PROQA_DIST_BACKEND=gloo lets two ranks share one GPU (RCCL refuses that), which is
+            # how the GPU test exercises this path.
+            dist.init_process_group(backend=os.environ.get("PROQA_DIST_BACKEND", "nccl"))
+        index = ShardedIndexFlatIP(info["rows"])
+        if allow_rounding:
+            index.local_index.allow_rounding(True)
+        index.add_local_npy(indexpath, readers)
+        t1 = time.perf_counter()
+        D, I = index.search(torch.from_numpy(np.ascontiguousarray(xq)).cuda(), topk)
+        D, I = D.cpu().numpy(), I.cpu().numpy()
+        rows_here = index.hi - index.lo
+    t2 = time.perf_counter()
+    row_bytes = 128 * (2 if info["dtype"] == np.float16 else 4)
+    LAST_RUN_STATS.update(world=world, rows=int(info["rows"]), rows_this_rank=int(rows_here), queries=int(xq.shape[0]),
+                          load_seconds=t1 - t0, load_gbs=rows_here * row_bytes / max(t1 - t0, 1e-9) / 1e9,
+                          search_seconds=t2 - t1)
+    index.close()
+    return D, I
+
+
+def finish_distributed():
+    """After the sharded search: ranks leave the process group together (rank 0 goes on to score alone)."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def build_parser():
@@ -112,26 +169,46 @@ def build_parser():
                         help="idx_id.json (the reference reads ../pretrained_models/idx_id.json)")
     parser.add_argument("--allow-fp16-rounding", action="store_true",
                         help="round float32 embeddings to fp16 instead of searching them in exact-float32 mode")
+    parser.add_argument("--dump-results", type=str, default=None,
+                        help="also write the search result (D float32 [Q,k], I int64 [Q,k]) to this .npz (not in the reference)")
     return parser
 
 
 def main(argv=None):
+    import time
     args = build_parser().parse_args(argv)
+    world, rank, _local_rank = dist_env()
+    LAST_RUN_STATS.clear()
+    t_start = time.perf_counter()
+    if rank != 0:
+        # a shard of the corpus and the collective; rank 0 maps ids, scores and prints
+        search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding)
+        finish_distributed()
+        return []
     with open(args.raw_data) as f:
         qas = [json.loads(line) for line in f.readlines()]
     questions = [item["question"] for item in qas]
     answers = [item["answer"] for item in qas]
 
-    # fork the scorer pool before any HIP call
+    # fork the scorer pool before any HIP call (and before the process group's threads exist)
     processes = ProcessPool(processes=args.num_workers, initializer=init, initargs=[args.db])
     try:
+        t0 = time.perf_counter()
         D, I = search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding)
+        finish_distributed()
+        if args.dump_results:
+            np.savez(args.dump_results, D=D, I=I)
+        t1 = time.perf_counter()
         retrieval_results = convert_idx2id(I, args.idx_id_map)
+        t2 = time.perf_counter()
         assert len(retrieval_results) == len(questions) == len(answers)
         results = processes.map(partial(get_score, topk=args.topk), zip(questions, answers, retrieval_results))
+        t3 = time.perf_counter()
     finally:
         processes.close()
         processes.join()
+    LAST_RUN_STATS.update(startup_seconds=t0 - t_start, search_total_seconds=t1 - t0, idx2id_seconds=t2 - t1,
+                          scoring_seconds=t3 - t2, scorer_processes=args.num_workers)
 
     aggregate = defaultdict(list)
     for r in results:
@@ -142,6 +219,7 @@ def main(argv=None):
         line = "Top {} Recall for {} QA pairs: {} ...".format(key, len(values), np.mean(values))
         print(line)
         lines.append(line)
+    LAST_RUN_STATS["total_seconds"] = time.perf_counter() - t_start
     return lines
 
 

@@ -71,6 +71,11 @@ class IndexFlatIP:
         xb = _as_matrix(xb, self.d, "xb")
         _lib.check(self._lib.proqa_index_add(self._h, xb.ctypes.data, xb.shape[0], _np_dtype_code(xb)))
 
+    def add_npy(self, path, row0=0, n=-1, readers=0):
+        """np.load(path)[row0:row0+n] + add, streamed by the library (reader threads -> pinned ring -> HBM; n < 0: to the
+        last row).  The file's dtype ('<f2' / '<f4') follows the precision rules of add()."""
+        _lib.check(self._lib.proqa_index_add_npy(self._h, str(path).encode(), int(row0), int(n), int(readers)))
+
     def search(self, xq, k):
         """(D float32 [nq,k], I int64 [nq,k]); scores descending, ties by ascending row."""
         if _is_torch(xq):
@@ -285,6 +290,14 @@ class ShardedIndexFlatIP:
         if self._index.ntotal > self.hi - self.lo:
             raise ValueError("more rows added than this rank's shard holds")
 
+    def add_local_npy(self, path, readers=0):
+        """Load this rank's rows [lo, hi) of the .npy index file straight into HBM (every rank reads only its range)."""
+        if self._index is None:
+            raise RuntimeError("add_local_npy is only available with the built-in HIP searcher")
+        if self._index.ntotal:
+            raise ValueError("this rank's shard already holds rows")
+        self._index.add_npy(path, self.lo, self.hi - self.lo, readers)
+
     def adopt_local(self, xb_local):
         """Search this rank's rows [lo, hi) in place: a contiguous CUDA fp16 tensor, not copied."""
         if self._index is None:
@@ -339,27 +352,47 @@ class ShardedIndexFlatIP:
         the exchange once more; a rank whose local search failed (status 0xFFFFFFFF) still enters the collective, and
         every rank raises instead of waiting for it."""
         import torch
-        lib = _lib.load()
+        if not xq.is_cuda:
+            raise ValueError("sharded search expects a CUDA tensor")
         xq = xq.contiguous()
+        if xq.dim() != 2 or xq.shape[1] != self.d:
+            raise ValueError(f"xq must have shape [nq, {self.d}], got {tuple(xq.shape)}")
+        k = int(k)
+        if k <= 0:
+            raise ValueError(f"k={k}")
         nq = xq.shape[0]
-        sizes = [ctypes.c_size_t() for _ in range(3)]
-        _lib.check(lib.proqa_sharded_block_layout(nq, int(k), *[ctypes.byref(v) for v in sizes]))
-        n_i, n_d, block = (v.value for v in sizes)
-        # the send / receive buffers are kept from call to call
-        key = (nq, int(k), xq.device)
-        if getattr(self, "_xchg_key", None) != key:
-            self._xchg_key = key
-            self._xchg_mine = torch.empty(block, dtype=torch.uint8, device=xq.device)
-            self._xchg_gathered = torch.empty((self.world_size, block), dtype=torch.uint8, device=xq.device)
-            self._xchg_status = torch.empty(self.world_size, dtype=torch.int32).pin_memory()
-        mine, gathered, status_host = self._xchg_mine, self._xchg_gathered, self._xchg_status
-        status_dev = mine.data_ptr() + n_i + n_d
         D_out = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
         I_out = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+        # (every rank sees the same nq: with no query nobody enters the collective; above QUERY_BATCH queries the search
+        # runs slice by slice like IndexFlatIP.search_device -- the candidate store of the library grows with nq)
+        for q0 in range(0, nq, QUERY_BATCH):
+            self._exchange_slice(xq[q0:q0 + QUERY_BATCH], k, D_out[q0:q0 + QUERY_BATCH], I_out[q0:q0 + QUERY_BATCH])
+        return D_out, I_out
+
+    def _exchange_slice(self, xq, k, D_out, I_out):
+        """begin -> all-gather -> strided merge -> finish for one slice of at most QUERY_BATCH queries; D_out / I_out are
+        contiguous [nq, k] views that receive the merged result."""
+        import torch
+        lib = _lib.load()
+        nq = xq.shape[0]
+        sizes = [ctypes.c_size_t() for _ in range(3)]
+        _lib.check(lib.proqa_sharded_block_layout(nq, k, *[ctypes.byref(v) for v in sizes]))
+        n_i, n_d, block = (v.value for v in sizes)
+        # the send / receive buffers are kept from call to call (one set per slice size: the full slice and the tail)
+        key = (nq, k, xq.device)
+        cache = self.__dict__.setdefault("_xchg", {})
+        if key not in cache:
+            if len(cache) >= 2:
+                cache.clear()
+            cache[key] = (torch.empty(block, dtype=torch.uint8, device=xq.device),
+                          torch.empty((self.world_size, block), dtype=torch.uint8, device=xq.device),
+                          torch.zeros(self.world_size, dtype=torch.int32).pin_memory())
+        mine, gathered, status_host = cache[key]
+        status_dev = mine.data_ptr() + n_i + n_d
         failure = None
         with torch.cuda.device(xq.device):
             try:
-                _lib.check(lib.proqa_index_search_begin_device(self._index._h, xq.data_ptr(), nq, _torch_dtype_code(xq), int(k),
+                _lib.check(lib.proqa_index_search_begin_device(self._index._h, xq.data_ptr(), nq, _torch_dtype_code(xq), k,
                                                                int(self.lo), mine.data_ptr() + n_i, mine.data_ptr(), status_dev,
                                                                _lib.current_stream_ptr()))
             except Exception as e:       # still enter the collective: the other ranks are already on their way into it
@@ -369,7 +402,7 @@ class ShardedIndexFlatIP:
                     mine[n_i + n_d:n_i + n_d + 4] = 0xFF
                 self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
                 # (the merge kernel drops every rank's status word into the pinned host buffer: no copy on the stream)
-                _lib.check(lib.proqa_topk_merge_gathered_device(gathered.data_ptr(), self.world_size, nq, int(k),
+                _lib.check(lib.proqa_topk_merge_gathered_device(gathered.data_ptr(), self.world_size, nq, k,
                                                                 status_host.data_ptr(), D_out.data_ptr(), I_out.data_ptr(),
                                                                 _lib.current_stream_ptr()))
                 if failure is None:
@@ -383,7 +416,9 @@ class ShardedIndexFlatIP:
                     raise failure if failure is not None else RuntimeError(
                         f"sharded search: rank {status.index(-1)} failed in its local search")
                 if not any(status):
-                    return D_out, I_out
+                    if failure is not None:     # the lists were exchanged (nobody waits), but this rank's result may be incomplete
+                        raise failure
+                    return
                 if failure is None:
                     mine[n_i + n_d:n_i + n_d + 4] = 0
         raise RuntimeError("sharded search: the ranks did not agree on a final result")

@@ -65,10 +65,13 @@ def retrieve_topk(index_path="../data/trec-2019/embeds/msmarco_paras_embed.npy",
     """Top-`topk` passages of every query, written as the query's JSON line + "para_embed_idx" (the rows, best first)
     and "para_labels" (0/1 per row); prints `Avg recall: {fraction of queries with a label among their rows}`.
     Returns that fraction (the reference returns None)."""
-    from .eval_retrieval import search
+    from .eval_retrieval import dist_env, finish_distributed, search
+    _D, I = search(index_path, query_embeds, topk, allow_rounding=allow_rounding)
+    finish_distributed()
+    if dist_env()[1] != 0:      # under torchrun the corpus is row-sharded over the ranks; rank 0 labels and writes
+        return None
     with open(query_input) as f:
         raw_data = [json.loads(line) for line in f]
-    _D, I = search(index_path, query_embeds, topk, allow_rounding=allow_rounding)
     if len(raw_data) < I.shape[0]:
         raise IndexError(f"{I.shape[0]} query embeddings but {len(raw_data)} lines in {query_input}")   # reference: raw_data[idx]
 

@@ -198,3 +198,43 @@ def test_exact_float32_search_through_the_collective(gpu_device, tmp_path, trans
     assert np.load(tmp_path / "exact.npy")[0]
     np.testing.assert_array_equal(np.load(tmp_path / "I.npy"), Io)
     np.testing.assert_array_equal(np.load(tmp_path / "D.npy"), Do)
+
+
+def _nccl_many_queries_worker(rank, port, n, nq, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=1)
+    try:
+        from proqa_amd import index as index_mod
+        index_mod.QUERY_BATCH = 1000                      # the slicing of the in-place exchange at a test-sized batch
+        xb, xq = _data(n, nq)
+        index = index_mod.ShardedIndexFlatIP(n)
+        index.add_local(xb)
+        xq_dev = torch.from_numpy(xq).cuda()
+        D, I = index.search(xq_dev, k, force_collective=True)
+        D0, I0 = index.search(xq_dev[:0], k, force_collective=True)          # no query: nobody enters the collective
+        assert tuple(D0.shape) == (0, k) and tuple(I0.shape) == (0, k)
+        for bad in (xq_dev[:, :64], xq_dev.cpu()):
+            try:
+                index.search(bad, k, force_collective=True)
+            except ValueError:
+                pass
+            else:
+                raise AssertionError("a malformed query matrix was accepted")
+        np.save(os.path.join(out_dir, "D.npy"), D.cpu().numpy())
+        np.save(os.path.join(out_dir, "I.npy"), I.cpu().numpy())
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_in_place_exchange_runs_in_query_slices(gpu_device, tmp_path):
+    """More queries than QUERY_BATCH on the torch + nccl transport: begin / all-gather / merge / finish per slice (full
+    slices and a tail), one result; empty and malformed query matrices are handled before the collective."""
+    from oracle import search_oracle
+    n, nq, k = 20011, 2345, 20
+    mp.spawn(_nccl_many_queries_worker, args=(_free_port(), n, nq, k, str(tmp_path)), nprocs=1, join=True)
+    xb, xq = _data(n, nq)
+    D, I = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(np.load(tmp_path / "I.npy"), I)
+    np.testing.assert_array_equal(np.load(tmp_path / "D.npy"), D)

@@ -6,7 +6,10 @@ import json
 import os
 import re
 import shutil
+import socket
 import sqlite3
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -16,6 +19,7 @@ from oracle import search_oracle
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_DOCS, N_QA, TOPK = 100000, 150, 80
 
 
@@ -83,3 +87,35 @@ def test_recall_lines_match_cpu_path(gpu_device, corpus, capsys):
     for k in (5, 20, 80, 10, 50):                                         # Recall@{5,20,80} of BASELINE.json (+10, 50)
         assert abs(got[k] - want[k]) <= 1e-4, (k, got[k], want[k])
     assert 0.0 < want[80] <= 1.0                                          # planted answers are being found
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_cli_under_two_ranks_prints_the_same_lines(gpu_device, corpus, tmp_path):
+    """The drop-in command line under a torchrun-style launch (WORLD_SIZE=2; both ranks share the one GPU of the test
+    box, gloo carries the exchange because RCCL refuses two ranks on one device): every rank loads only its half of
+    para_embed.npy, rank 0 prints.  stdout byte-identical to the single-process run, D and I identical."""
+    d = corpus
+    para, qry = str(d / "para_embed.npy"), str(d / "q_embed.npy")
+    if not (os.path.exists(para) and os.path.exists(qry)):
+        pytest.skip("needs the files of test_recall_lines_match_cpu_path")
+    cmd = [sys.executable, os.path.join(ROOT, "eval_retrieval.py"), str(d / "qa.txt"), para, qry, str(d / "paras.db"),
+           "--topk", str(TOPK), "--num-workers", "4", "--idx-id-map", str(d / "idx_id.json")]
+    single = subprocess.run(cmd + ["--dump-results", str(tmp_path / "single.npz")], env=os.environ.copy(),
+                            capture_output=True, text=True, timeout=900)
+    assert single.returncode == 0, single.stderr[-2000:]
+    env = dict(os.environ, PROQA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    procs = [subprocess.Popen(cmd + ["--dump-results", str(tmp_path / "sharded.npz")],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert outs[0][0] == single.stdout and len(single.stdout.splitlines()) == 5
+    assert outs[1][0] == ""                                   # only rank 0 prints
+    a, b = np.load(tmp_path / "single.npz"), np.load(tmp_path / "sharded.npz")
+    np.testing.assert_array_equal(a["I"], b["I"])
+    np.testing.assert_array_equal(a["D"], b["D"])

@@ -247,7 +247,7 @@ def test_exact_float32_shards_and_npy_index(gpu_device, tmp_path):
     np.testing.assert_array_equal(D.cpu().numpy(), Do)
     np.save(tmp_path / "index.npy", xb)
     np.save(tmp_path / "query.npy", xq)
-    D, I = search(str(tmp_path / "index.npy"), str(tmp_path / "query.npy"), 80, chunk_rows=2048)
+    D, I = search(str(tmp_path / "index.npy"), str(tmp_path / "query.npy"), 80)
     np.testing.assert_array_equal(I, Io)
     np.testing.assert_array_equal(D, Do)
     Dr, Ir = search(str(tmp_path / "index.npy"), str(tmp_path / "query.npy"), 80, allow_rounding=True)
@@ -909,3 +909,61 @@ def test_shards_with_non_finite_scores_merge_like_the_unsharded_search(gpu_devic
     np.testing.assert_array_equal(I.cpu().numpy(), Io)
     np.testing.assert_array_equal(D.cpu().numpy(), Do)
 
+
+
+def test_add_npy_streams_the_file_like_np_load_plus_add(gpu_device, tmp_path):
+    """proqa_index_add_npy (reader threads -> pinned ring -> HBM) == np.load + add: fp16 files over several ring turns,
+    row ranges (what a rank of a sharded index loads), appends, one reader and many, a float32 file whose switch to
+    exact-float32 mode happens in a later piece, and the error cases."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(41)
+    n = 5 * 131072 + 777                                    # five 32 MiB pieces and a tail: the 4-slot ring wraps
+    xb = rng.integers(-4, 5, (n, 128)).astype(np.float16)
+    xq = rng.integers(-4, 5, (33, 128)).astype(np.float16)
+    np.save(tmp_path / "f16.npy", xb)
+    Do, Io = search_oracle.topk_ip(xq, xb, 80)
+    for readers in (1, 0, 7):
+        index = IndexFlatIP(128)
+        index.add_npy(tmp_path / "f16.npy", readers=readers)
+        assert index.ntotal == n and not index.exact_f32
+        D, I = index.search(xq, 80)
+        np.testing.assert_array_equal(I, Io)
+        np.testing.assert_array_equal(D, Do)
+        index.close()
+    # a row range, then an append of another range: rows [lo, hi) ++ [0, 1000)
+    lo, hi = 200001, 600000
+    index = IndexFlatIP(128)
+    index.add_npy(tmp_path / "f16.npy", lo, hi - lo)
+    index.add_npy(tmp_path / "f16.npy", 0, 1000)
+    sub = np.concatenate([xb[lo:hi], xb[:1000]])
+    D, I = index.search(xq, 80)
+    Ds, Is = search_oracle.topk_ip(xq, sub, 80)
+    np.testing.assert_array_equal(I, Is)
+    np.testing.assert_array_equal(D, Ds)
+    # errors leave the index as it was
+    for bad in [(n - 5, 6), (-1, 3)]:
+        with pytest.raises(Exception):
+            index.add_npy(tmp_path / "f16.npy", *bad)
+    with pytest.raises(Exception):
+        index.add_npy(tmp_path / "missing.npy")
+    np.save(tmp_path / "narrow.npy", np.zeros((10, 64), np.float16))
+    with pytest.raises(Exception):
+        index.add_npy(tmp_path / "narrow.npy")
+    assert index.ntotal == hi - lo + 1000
+    index.close()
+    # float32 file: pieces of 65536 rows; the first two are fp16-exact, the switch happens in the third
+    m = 2 * 65536 + 5000
+    xf = rng.integers(-4, 5, (m, 128)).astype(np.float32)
+    xf[: 2 * 65536, 0] = rng.integers(-2000, 2001, 2 * 65536)
+    xf[2 * 65536 + 99:, 0] = 2049.0                         # not an fp16 number
+    qf = rng.integers(-3, 4, (9, 128)).astype(np.float32)
+    qf[:, 0] = 1.0
+    np.save(tmp_path / "f32.npy", xf)
+    index = IndexFlatIP(128)
+    index.add_npy(tmp_path / "f32.npy")
+    assert index.exact_f32 and index.ntotal == m
+    D, I = index.search(qf, 50)
+    De, Ie = search_oracle.topk_ip_exact(qf, xf, 50)
+    np.testing.assert_array_equal(I, Ie)
+    np.testing.assert_array_equal(D, De)
+    index.close()

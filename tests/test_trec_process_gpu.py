@@ -3,6 +3,9 @@ own retrieve_topk (tests/golden/make_trec_golden.py): byte-identical output file
 import hashlib
 import json
 import os
+import socket
+import subprocess
+import sys
 
 import pytest
 
@@ -39,3 +42,25 @@ def test_retrieve_topk_with_fewer_rows_than_k(gpu_device, tmp_path):
         rows = s["para_embed_idx"]
         assert len(rows) == 10000 and sorted(rows[:300]) == list(range(300)) and set(rows[300:]) == {-1}
         assert sum(s["para_labels"]) == len(set(s["labels"])) and not any(s["para_labels"][300:])
+
+
+def test_retrieve_topk_under_two_ranks_writes_the_same_file(gpu_device, tmp_path):
+    """retrieve_topk under a torchrun-style launch (2 ranks on the one GPU, gloo): the corpus is row-sharded, the
+    k = 10000 lists of both shards are merged, rank 0 writes -- the reference's golden bytes again."""
+    paras, queries, qfile = trec_inputs(str(tmp_path), n=GOLDEN["n"], nq=GOLDEN["nq"], seed=GOLDEN["seed"])
+    out = str(tmp_path / "processed.txt")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from proqa_amd import trec_process; "
+            "trec_process.retrieve_topk(index_path=%r, query_embeds=%r, query_input=%r, output=%r)" % (root, paras, queries, qfile, out))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PROQA_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    assert outs[0][0] == GOLDEN["stdout"] and outs[1][0] == ""
+    blob = open(out, "rb").read()
+    assert len(blob) == GOLDEN["output_bytes"]
+    assert hashlib.sha256(blob).hexdigest() == GOLDEN["output_sha256"]
