@@ -48,6 +48,7 @@ def parse():
     p.add_argument("--cli-passages", type=int, default=200_000,
                    help="text passages of the command-line encode leg (encode.cli_text); 0 skips it")
     p.add_argument("--skip-float32", action="store_true", help="skip the exact-float32 index leg")
+    p.add_argument("--skip-cli-eval", action="store_true", help="skip the eval_retrieval.py command-line leg (search_cli_eval)")
     p.add_argument("--skip-cpu", action="store_true")
     p.add_argument("--skip-varlen", action="store_true", help="encode leg: full-length steps only (PMC traffic passes)")
     p.add_argument("--skip-extras", action="store_true",
@@ -443,6 +444,160 @@ def corpus_leg(args, device, world, rank, model, sd):
     return out
 
 
+def cli_eval_leg(args, device, xb, xq, I_top, k):
+    """The drop-in command line of the search half, end to end, at the headline size (the reference's
+    retrieval/eval_retrieval.py:88-123): the resident corpus is written ONCE to a '<f2' para_embed.npy (outside every timed
+    region), with the 2032 query embeddings, a QA file, a row -> doc-id sidecar and a sqlite DB of passages in which the
+    answer of every second question is planted in that question's best passage (so the printed recall must be exactly
+    0.5: a check of the id map, not of the search).  Timed: `python eval_retrieval.py ...` as a child process (imports,
+    scorer-pool fork, file -> HBM load, search, id map, scoring), its own per-stage clock, the loader alone with a cold and
+    a warm page cache next to a dd-style single-thread read of the same file, and the host-pointer IndexFlatIP.search."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    from proqa_amd import npy
+    from proqa_amd.index import IndexFlatIP
+    n, nq = xb.shape[0], xq.shape[0]
+    base = os.environ.get("PROQA_BENCH_TMP") or tempfile.gettempdir()
+    need = n * 256 + (1 << 30)
+    if shutil.disk_usage(base).free < need:
+        return {"skipped": f"{base} has less than {need >> 20} MiB free for the index file"}
+    d = tempfile.mkdtemp(prefix="proqa_cli_eval_", dir=base)
+    try:
+        t_prep = time.perf_counter()
+        index_path = os.path.join(d, "para_embed.npy")
+        with open(index_path, "wb") as f:                   # what np.save writes, streamed from the device in pieces
+            np.lib.format.write_array_header_1_0(f, {"descr": "<f2", "fortran_order": False, "shape": (n, 128)})
+            for r0 in range(0, n, 2_000_000):
+                f.write(xb[r0:r0 + 2_000_000].cpu().numpy().data)
+        assert npy.stat(index_path)["rows"] == n
+        np.save(os.path.join(d, "q_embed.npy"), xq.cpu().numpy())
+        # passages: 100 words of a 5000-word vocabulary; row r of the index is passage r % n_docs
+        rng = np.random.default_rng(3)
+        n_docs = 200_000
+        letters = np.array(list("abcdefghijklmnopqrstuvwxyz"))
+        vocab = np.array(["".join(rng.choice(letters, size=int(rng.integers(3, 10)))) for _ in range(5000)])
+        words = vocab[rng.integers(0, len(vocab), (n_docs, 100))]
+        docs = [" ".join(w) for w in words]
+        top1 = I_top[:, 0].cpu().numpy()
+        with open(os.path.join(d, "qa.txt"), "w") as f:
+            for q in range(nq):
+                ans = f"answq{q} tokq{q}"
+                if q % 2 == 0:
+                    docs[int(top1[q]) % n_docs] += f" {ans.capitalize()} ."
+                f.write(json.dumps({"question": f"question number {q}", "answer": [ans, "never matches xyz"]}) + "\n")
+        conn = sqlite3.connect(os.path.join(d, "paras.db"))
+        conn.execute("CREATE TABLE documents (id PRIMARY KEY, text)")
+        conn.executemany("INSERT INTO documents VALUES (?,?)", ((f"d{i:07d}", t) for i, t in enumerate(docs)))
+        conn.commit()
+        conn.close()
+        # sidecar of gen_index_id_map.write_sidecar, generated in bulk: line r = '"d%07d"\n' % (r % n_docs)
+        ids = (np.arange(n, dtype=np.int64) % n_docs)
+        blob = np.empty((n, 11), dtype=np.uint8)
+        blob[:, 0], blob[:, 1], blob[:, 9], blob[:, 10] = ord('"'), ord("d"), ord('"'), ord("\n")
+        for j in range(7):
+            blob[:, 8 - j] = ord("0") + (ids // 10 ** j) % 10
+        blob.tofile(os.path.join(d, "idx_id.ids"))
+        np.save(os.path.join(d, "idx_id.off.npy"), np.arange(n + 1, dtype=np.int64) * 11)
+        del blob, ids, words, docs
+        t_prep = time.perf_counter() - t_prep
+
+        def drop_cache():
+            fd = os.open(index_path, os.O_RDONLY)
+            try:
+                os.fsync(fd)
+                os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+            finally:
+                os.close(fd)
+
+        def dd_read():
+            buf = bytearray(32 << 20)
+            t0 = time.perf_counter()
+            with open(index_path, "rb", buffering=0) as f:
+                while f.readinto(buf):
+                    pass
+            return n * 256 / (time.perf_counter() - t0) / 1e9
+
+        def load_only():
+            ix = IndexFlatIP(128, capacity=n)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ix.add_npy(index_path)
+            dt = time.perf_counter() - t0
+            return ix, n * 256 / dt / 1e9
+
+        t0 = time.perf_counter()
+        drop_cache()
+        t_drop = time.perf_counter() - t0
+        dd_cold = dd_read()
+        dd_warm = dd_read()
+        drop_cache()
+        ix, load_cold = load_only()
+        ix.close()
+        ix, load_warm = load_only()
+        # the host-pointer search of the faiss call shape (numpy in, numpy out) on the index just loaded
+        xq_np = xq.cpu().numpy()
+        ix.search(xq_np, k)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            Dh, Ih = ix.search(xq_np, k)
+        host_ms = (time.perf_counter() - t0) / 5 * 1e3
+        ids_equal = bool((Ih == I_top.cpu().numpy()).all())
+        ix.close()
+        del ix
+        torch.cuda.empty_cache()
+
+        stats_path = os.path.join(d, "stats.json")
+        cmd = [sys.executable, os.path.join(ROOT, "eval_retrieval.py"), os.path.join(d, "qa.txt"), index_path,
+               os.path.join(d, "q_embed.npy"), os.path.join(d, "paras.db"), "--topk", str(k), "--num-workers", "10",
+               "--idx-id-map", os.path.join(d, "idx_id.ids")]
+        env = {kk: v for kk, v in os.environ.items() if kk not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["PROQA_STATS_JSON"] = stats_path
+        t0 = time.perf_counter()
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        wall = time.perf_counter() - t0
+        if proc.returncode != 0:
+            return {"error": proc.stderr[-800:]}
+        st = json.load(open(stats_path))
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("Top ")]
+        recall = {ln.split()[1]: float(ln.split(": ")[1].split()[0]) for ln in lines}
+        # the reference's own id map (json.load of {"<row>": id}, eval_retrieval.py:73-74) on a 1M-entry sample
+        sample = 1_000_000
+        jpath = os.path.join(d, "idx_id_sample.json")
+        with open(jpath, "w") as f:
+            json.dump({str(i): f"d{i % n_docs:07d}" for i in range(sample)}, f)
+        t0 = time.perf_counter()
+        with open(jpath) as f:
+            m = json.load(f)
+        t_json = time.perf_counter() - t0
+        del m
+        return {
+            "metric": "seconds for the eval_retrieval.py command line, end to end", "value": wall, "unit": "s",
+            "higher_is_better": False, "rows": n, "queries": nq, "topk": k, "index_file_bytes": os.path.getsize(index_path),
+            "stages_seconds": {"python_imports_and_pool_fork": st.get("startup_seconds"), "load_index_file_to_hbm": st.get("load_seconds"),
+                               "search_incl_query_upload_and_result_download": st.get("search_seconds"),
+                               "idx2id_sidecar": st.get("idx2id_seconds"), "scoring_pool": st.get("scoring_seconds"),
+                               "main_total": st.get("total_seconds"), "process_wall": wall},
+            "load_GBs_in_cli": st.get("load_gbs"),
+            "loader": {"cold_GBs": load_cold, "warm_GBs": load_warm, "dd_style_read_cold_GBs": dd_cold, "dd_style_read_warm_GBs": dd_warm,
+                       "cache_drop_seconds": t_drop,
+                       "note": "proqa_index_add_npy (4 reader threads -> pinned ring -> HBM) on the whole file; dd-style = one thread "
+                               "readinto() of 32 MiB blocks, nothing uploaded; cold = after fsync + posix_fadvise(DONTNEED), "
+                               "best effort (a tmpfs cannot be dropped)"},
+            "host_api_search": {"ms_per_search": host_ms, "queries_per_s": nq / host_ms * 1e3, "ids_equal_device_search": ids_equal,
+                                "note": "IndexFlatIP.search(numpy xq) -> numpy D, I: the faiss call shape incl. query upload and result download"},
+            "idx2id_json_route": {"entries_sample": sample, "json_load_seconds": t_json,
+                                  "note": f"the reference's idx_id.json costs this per million rows ({n / 1e6:.0f}x at this index); "
+                                          "the CLI run above used the .ids sidecar"},
+            "recall_printed": recall, "recall_expected": 0.5, "scorer_processes": st.get("scorer_processes"),
+            "prepare_seconds_untimed": t_prep,
+            "workload": f"{n} x 128 fp16 para_embed.npy, {nq} questions, top-{k}, {n_docs} passages of 100 words in sqlite, "
+                        f"row r -> passage r % {n_docs}; answers planted for even questions in their top-1 passage"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run (one process per
     GPU, rendezvous on 127.0.0.1) and relay rank 0's JSON line and the child's exit code.  Nothing in this process has
@@ -710,6 +865,8 @@ def main():
             del ix, xq_l
         torch.cuda.empty_cache()
         line["large_k"] = large
+        if not args.skip_cli_eval:
+            line["search_cli_eval"] = cli_eval_leg(args, device, xb, xq, result["DI"][1], k)
         line["peak_measured"] = measured_peaks(device)
         # the other "next" rows of SURVEY section 8(f), on the same resident rows
         line["kmeans"] = kmeans_leg(args, device, xb)

@@ -220,6 +220,9 @@ def main(argv=None):
         print(line)
         lines.append(line)
     LAST_RUN_STATS["total_seconds"] = time.perf_counter() - t_start
+    if os.environ.get("PROQA_STATS_JSON"):      # bench.py's search_cli_eval runs this command line as a child process
+        with open(os.environ["PROQA_STATS_JSON"], "w") as f:
+            json.dump(LAST_RUN_STATS, f)
     return lines
 
 
