@@ -575,14 +575,15 @@ def cli_eval_leg(args, device, xb, xq, I_top, k):
         return {
             "metric": "seconds for the eval_retrieval.py command line, end to end", "value": wall, "unit": "s",
             "higher_is_better": False, "rows": n, "queries": nq, "topk": k, "index_file_bytes": os.path.getsize(index_path),
-            "stages_seconds": {"python_imports_and_pool_fork": st.get("startup_seconds"), "load_index_file_to_hbm": st.get("load_seconds"),
+            "stages_seconds": {"python_imports_and_pool_fork": st.get("startup_seconds"), "hip_runtime_start_and_index_alloc": st.get("gpu_init_seconds"),
+                               "load_index_file_to_hbm": st.get("load_seconds"),
                                "search_incl_query_upload_and_result_download": st.get("search_seconds"),
                                "idx2id_sidecar": st.get("idx2id_seconds"), "scoring_pool": st.get("scoring_seconds"),
                                "main_total": st.get("total_seconds"), "process_wall": wall},
             "load_GBs_in_cli": st.get("load_gbs"),
             "loader": {"cold_GBs": load_cold, "warm_GBs": load_warm, "dd_style_read_cold_GBs": dd_cold, "dd_style_read_warm_GBs": dd_warm,
                        "cache_drop_seconds": t_drop,
-                       "note": "proqa_index_add_npy (4 reader threads -> pinned ring -> HBM) on the whole file; dd-style = one thread "
+                       "note": "proqa_index_add_npy (4 reader threads -> pinned ring -> HBM) on the whole file (cold = also the first call of the process); dd-style = one thread "
                                "readinto() of 32 MiB blocks, nothing uploaded; cold = after fsync + posix_fadvise(DONTNEED), "
                                "best effort (a tmpfs cannot be dropped)"},
             "host_api_search": {"ms_per_search": host_ms, "queries_per_s": nq / host_ms * 1e3, "ids_equal_device_search": ids_equal,

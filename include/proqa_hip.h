@@ -85,7 +85,7 @@ int proqa_index_create(int d, int64_t capacity_rows, proqa_index** out);
 int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype);
 /* np.load(path) + index.add(xb[row0:row0+n]) (retrieval/eval_retrieval.py:99-102) in one call: appends rows
  * [row0, row0 + n) of a 2-D .npy file ('<f2' or '<f4', 128 columns; n < 0 = up to the last row).  n_readers host
- * threads (<= 0: 4) pread() the rows into a ring of pinned 32 MiB pieces while the pieces read before them travel to
+ * threads (<= 0: 4) pread() the rows into a ring of four pinned 8 MiB pieces while the pieces read before them travel to
  * HBM, so that the file read, the PCIe transfer and (float32 files) the conversion overlap and no pageable copy of the
  * corpus is made.  A rank of a row-sharded index loads only its own row range this way.  Same precision rules as
  * proqa_index_add.  All or nothing: on failure the index still holds the rows it had. */

@@ -213,7 +213,8 @@ int ensure_stage(proqa_index* idx, size_t bytes) {
 
 constexpr int64_t kAddPieceRows = 1 << 20;   // rows per upload piece of proqa_index_add (256 MiB of fp16 rows)
 constexpr int kLoaderSlots = 4;               // pinned pieces of proqa_index_add_npy: two being read, two on their way up
-constexpr int64_t kLoaderPieceBytes = 32 << 20;
+// pieces of 4 .. 64 MiB and 2 .. 8 readers all reach 31-34 GB/s from a warm page cache (profiles/r04_loader_timing.txt)
+constexpr int64_t kLoaderPieceBytes = 8 << 20;
 
 // One piece of float32 rows from host memory -> fp16 rows [row, row+m) of the index, with the exact-float32 bookkeeping.
 // Rows [idx->n, row) are the earlier pieces of the same call (idx->n counts the rows of completed calls only).

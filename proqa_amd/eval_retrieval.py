@@ -113,9 +113,10 @@ def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
     t0 = time.perf_counter()
     if world == 1:
         from .index import IndexFlatIP
-        index = IndexFlatIP(128, capacity=info["rows"])
+        index = IndexFlatIP(128, capacity=info["rows"])         # (the first HIP call of the process: runtime start-up)
         if allow_rounding:
             index.allow_rounding(True)
+        t0b = time.perf_counter()
         index.add_npy(indexpath, 0, info["rows"], readers)
         t1 = time.perf_counter()
         D, I = index.search(xq, topk)
@@ -132,6 +133,7 @@ def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
         index = ShardedIndexFlatIP(info["rows"])
         if allow_rounding:
             index.local_index.allow_rounding(True)
+        t0b = time.perf_counter()
         index.add_local_npy(indexpath, readers)
         t1 = time.perf_counter()
         D, I = index.search(torch.from_numpy(np.ascontiguousarray(xq)).cuda(), topk)
@@ -140,7 +142,7 @@ def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
     t2 = time.perf_counter()
     row_bytes = 128 * (2 if info["dtype"] == np.float16 else 4)
     LAST_RUN_STATS.update(world=world, rows=int(info["rows"]), rows_this_rank=int(rows_here), queries=int(xq.shape[0]),
-                          load_seconds=t1 - t0, load_gbs=rows_here * row_bytes / max(t1 - t0, 1e-9) / 1e9,
+                          gpu_init_seconds=t0b - t0, load_seconds=t1 - t0b, load_gbs=rows_here * row_bytes / max(t1 - t0b, 1e-9) / 1e9,
                           search_seconds=t2 - t1)
     index.close()
     return D, I
