@@ -15,12 +15,12 @@
 //     wave-instruction) into a two-deep ring; the 16-byte pieces of a 128-byte tile row are XOR-swizzled with
 //     (row >> 1) & 7 on the DMA SOURCE address (the LDS image stays lane-linear), which makes every
 //     ds_read_b128 fragment load conflict-free for both the permuted A rows and the plain B rows.
-//   * one barrier per K-step: it publishes the step that was prefetched during the previous one (explicit
-//     vmcnt(0): LDS-DMA completion is tracked by vmcnt only) and frees the other buffer for the next prefetch.
+//   * the schedule of the K loop (two wave groups in anti-phase, region-wise ring refill, counted vmcnt) is described
+//     in front of the kernel.
 //   * persistent workgroups, one per CU; tile order is XCD-aware: block b runs on XCD b % 8 and walks the
 //     256-row token slabs  b%8, b%8 + 8, ...  feature tile by feature tile, so a token slab is fetched from HBM
 //     by ONE XCD's L2 and re-read from there by that XCD's workgroups; the (small) weight is shared by all.
-//   * the first K-step of the next tile is prefetched before the epilogue of the current one.
+//   * the K-steps of consecutive output tiles form ONE prefetch stream (two steps ahead), across the epilogues.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -62,78 +62,105 @@ __device__ __forceinline__ void lds_wait(f16x8 (&fa)[4], f16x8 (&fb)[2]) {
                : "memory");
 }
 
-// erf-form GELU (hidden_act = 'gelu'), 0.5 x (1 + erf(x / sqrt 2)), with erf from Abramowitz & Stegun 7.1.26
-// (|error| <= 1.5e-7, three orders of magnitude below the fp16 resolution of the result) on the hardware rcp / exp2:
-// 13 VALU operations per element where libdevice's erff costs ~40 -- the epilogue of a 256 x 256 tile evaluates
-// 128 of them per lane with the matrix pipe idle.
+// erf-form GELU (hidden_act = 'gelu'):  gelu(x) = x Phi(x) = max(x, 0) - a Phi(-a),  a = |x|.
+// Phi(-a) = exp2(q(a)) with q a degree-6 minimax fit of log2 Phi(-a) on [0, 6] (|error| <= 6.5e-5 in the exponent: a
+// RELATIVE error of 4.6e-5 of Phi(-a), so the negative tail keeps its relative accuracy; the fp16 result differs from the
+// correctly rounded one in 2 % of all fp16 inputs, by one ulp -- an erf formula with a small ABSOLUTE error such as
+// Abramowitz & Stegun 7.1.26 loses the tail and needs a reciprocal on top).  Beyond a = 6 (Phi(-6) = 1e-9) a is clamped in
+// both factors: the correction is below the fp16 resolution of x, and of 0.  9 plain VALU operations + one exp2 per
+// element where libdevice's erff costs ~40; coefficients from scripts/dev_gelu_fit.py.
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float ax = __builtin_fabsf(x) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, ax, 1.0f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  p *= t;
-  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.44269504088896340736f);
-  const float erf_abs = __builtin_fmaf(-p, e, 1.0f);            // erf(|x| / sqrt 2)
-  return 0.5f * __builtin_fmaf(__builtin_fabsf(x), erf_abs, x);  // x sign(x) erf(|x|/sqrt 2) = |x| erf_abs
+  const float a = __builtin_fminf(__builtin_fabsf(x), 6.0f);
+  float q = __builtin_fmaf(2.299005791428499e-05f, a, -0.000611100229434669f);
+  q = __builtin_fmaf(q, a, 0.007195569109171629f);
+  q = __builtin_fmaf(q, a, -0.05118535831570625f);
+  q = __builtin_fmaf(q, a, -0.46127188205718994f);
+  q = __builtin_fmaf(q, a, -1.1501742601394653f);
+  q = __builtin_fmaf(q, a, -1.000064730644226f);
+  const float u = __builtin_amdgcn_exp2f(q);                   // Phi(-a)
+  return __builtin_fmaf(-a, u, __builtin_fmaxf(x, 0.0f));
 }
 
-template <int EPI>
+// The main loop runs the two waves of every SIMD in ANTI-PHASE ("ping-pong").  (Rounds 1-3 had all eight waves read their
+// fragments at the same time and then all issue MFMAs at the same time, one barrier per K-step: the matrix pipe of a SIMD
+// idled while its two waves waited for LDS; bit-identical results, 3-4 % slower.)  Waves 0-3 (group X, one per SIMD) and waves 4-7
+// (group Y, their SIMD partners) run the same instruction stream ONE INTERVAL apart: every interval ends with a workgroup
+// barrier, a wave alternates LOAD intervals (ds_reads of the next quadrant + its share of the LDS-DMA prefetch) with
+// COMPUTE intervals (8 MFMAs = one 64 x 32 quadrant of its 128 x 64 tile over the whole K-step), and while X computes Y
+// loads.  Per K-step a wave runs 4 phases (quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0)); its LOAD intervals read 8 / 4 / 8 / 4
+// fragments (A0 | B1 | A1 | B0 of the NEXT step).
+//   Ring discipline (two 64 KiB K-step buffers, prefetch distance TWO steps): a buffer is refilled region by region as
+// soon as BOTH groups have read that region -- A0 rows of step t+2 are requested in phase 1 of step t, the B rows in
+// phase 2, the A1 rows in phase 3 -- so a DMA has 8+ intervals (~2000 cycles) to land.  A wave waits for its DMAs of step
+// t+1 with a COUNTED vmcnt in phase 2 of step t (never 0 in the loop; the epilogue's stores are counted too), the reads
+// of that data start in phase 3, one barrier later for X and two for Y.  Barriers are raw s_barrier (no vmcnt drain).
+//   At the end of an output tile X takes one extra barrier (the groups fall in step), both run the epilogue at the same
+// time, then Y takes one extra barrier (anti-phase again).
+template <int EPI, int DBG = 0>   // DBG (timing experiments, wrong results): bit 0 = no fragment reads after the first step, bit 1 = no DMA after the prologue, bit 2 = no epilogue, bit 3 = every DMA from the same 64 KiB
 __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
-                                                          const _Float16* __restrict__ bias, _Float16* __restrict__ Y,
-                                                          int M, int N, int K) {
-  // [buffer][operand]: operand 0 = weight tile (A), 1 = token tile (B); the only LDS object of the kernel
-  // ... plus 4 KiB per wave of epilogue staging (160 KiB in all)
+                                                             const _Float16* __restrict__ bias, _Float16* __restrict__ Y,
+                                                             int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * kOpBytes + kWaves * 4096];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
-  const int wn = wave >> 2;   // which 128-feature half of the tile
+  const int wn = wave >> 2;   // which 128-feature half of the tile; also the phase group (0 = X, 1 = Y)
   const int wm = wave & 3;    // which 64-row quarter of the tile
 
   const int tiles_n = N / kTile, tiles_m = M / kTile;
   const int n_steps = K / kBK;
-  // XCD-aware persistent schedule
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = (gridDim.x + 7 - xcd) >> 3;
-  const int my_slabs = (tiles_m - xcd + 7) >> 3;        // token slabs xcd, xcd + 8, ...
-  const long long my_tiles = (long long)my_slabs * tiles_n;
+  const int my_slabs = (tiles_m - xcd + 7) >> 3;
+  const int my_tiles = my_slabs * tiles_n;   // (<= 2^22 slabs x a few feature tiles)
 
-  // ---- LDS-DMA addressing: wave w fetches rows [32 w, 32 w + 32) of both operand tiles, 8 rows (1 KiB) per instruction
-  const int dma_r = lane >> 3;   // row within the 8-row piece
-  const int dma_p = lane & 7;    // 16-byte slot within the 128-byte row
-  int dma_src_off[4];            // byte offset of this lane's source piece relative to (tile row 0, k0)
-  int dma_row[4];
+  // ---- LDS-DMA pieces of this wave (1 KiB = 8 tile rows each; source-side XOR swizzle as above)
+  //   A0 region (rows 0-63 and 128-191): pieces 2 wave, 2 wave + 1 of its 16;  A1 region: the same rows + 64
+  //   B0 region (rows 64 g + [0, 32), g = 0..3): pieces 2 wave, 2 wave + 1 of its 16;  B1 region: the same rows + 32
+  const int dma_r = lane >> 3, dma_p = lane & 7;
+  int a_src[2], b_src[2], a_lds[2], b_lds[2];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int row = wave * 32 + e * 8 + dma_r;
-    dma_row[e] = row;
-    dma_src_off[e] = (dma_p ^ ((row >> 1) & 7)) * 16;
+  for (int e = 0; e < 2; ++e) {
+    const int q = 2 * wave + e;
+    const int row0 = q < 8 ? 8 * q : 128 + 8 * (q - 8);
+    const int row = row0 + dma_r;
+    a_src[e] = row * K * 2 + ((dma_p ^ ((row >> 1) & 7)) << 4);
+    a_lds[e] = row0 * kRowB;
   }
-  auto issue_step = [&](const char* wbase, const char* xbase, int step, int buf) {
-    // wbase / xbase: first row of the tile, K offset 0; row pitch K*2 bytes
-    const long long koff = (long long)step * kRowB;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const char* src = wbase + (long long)dma_row[e] * K * 2 + koff + dma_src_off[e];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lds + (buf * 2 + 0) * kOpBytes + (wave * 4 + e) * 1024),
-                                       16, 0, 0);
-    }
+  for (int e = 0; e < 2; ++e) {
+    const int q = 2 * wave + e;
+    const int row0 = 64 * (q >> 2) + 8 * (q & 3);
+    const int row = row0 + dma_r;
+    b_src[e] = row * K * 2 + ((dma_p ^ ((row >> 1) & 7)) << 4);      // (+32 rows: the same swizzle term)
+    b_lds[e] = kOpBytes + row0 * kRowB;
+  }
+  auto dma = [&](const char* src, int lds_off) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + lds_off), 16, 0, 0);
+  };
+  // region 0: A0 rows, 1: B0 rows, 2: A1 rows, 3: B1 rows of K-step `step` of the tile at (wbase, xbase) into ring buffer `buf`
+  auto issue_region = [&](int region, const char* wbase, const char* xbase, int step, int buf) {
+    const long long koff = (DBG & 8) ? 0 : (long long)step * kRowB;   // DBG 8: every DMA re-reads the same 64 KiB (L2 hits)
+    if (DBG & 8) { wbase = (const char*)W; xbase = (const char*)X; }
+    const int bo = buf * 2 * kOpBytes;
+    if (region == 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const char* src = xbase + (long long)dma_row[e] * K * 2 + koff + dma_src_off[e];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lds + (buf * 2 + 1) * kOpBytes + (wave * 4 + e) * 1024),
-                                       16, 0, 0);
+      for (int e = 0; e < 2; ++e) dma(wbase + koff + a_src[e], bo + a_lds[e]);
+    } else if (region == 2) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) dma(wbase + koff + a_src[e] + 64ll * K * 2, bo + a_lds[e] + 64 * kRowB);
+    } else if (region == 1) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) dma(xbase + koff + b_src[e], bo + b_lds[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) dma(xbase + koff + b_src[e] + 32ll * K * 2, bo + b_lds[e] + 32 * kRowB);
     }
   };
 
-  // ---- fragment read addresses (LDS bytes relative to buffer 0 / weight tile), per k16 sub-step s: piece 2 s + half of
-  // the lane's row, swizzled.  The wave's other tiles are whole multiples of 16 rows away (same swizzle term), i.e.
-  // compile-time offsets: weight tiles at rows +0, +16, +64, +80 of the wave's 128, token tiles at rows +0, +32.
+  // ---- fragment read addresses (see gemm_tn_f16): A tiles of block 0 at rows +0 / +16, of block 1 at +64 / +80
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   unsigned a_addr[4], b_addr[4];
   {
@@ -144,41 +171,94 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
       b_addr[s] = lds0 + kOpBytes + brow * kRowB + (((2 * s + half) ^ ((brow >> 1) & 7)) << 4);
     }
   }
-  auto read_frags = [&](f16x8 (&fa)[4], f16x8 (&fb)[2], int s, int buf) {
-    const unsigned aa = a_addr[s] + buf * 2 * kOpBytes, bb = b_addr[s] + buf * 2 * kOpBytes;
-    fa[0] = lds_read128<0>(aa);
-    fa[1] = lds_read128<16 * kRowB>(aa);
-    fa[2] = lds_read128<64 * kRowB>(aa);
-    fa[3] = lds_read128<80 * kRowB>(aa);
-    fb[0] = lds_read128<0>(bb);
-    fb[1] = lds_read128<32 * kRowB>(bb);
+  // fa[j][s]: A tile j of the current 64-row block, k16 sub-step s; fb[s]: the current 32-row B tile
+  auto read_a = [&](f16x8 (&fa)[2][4], int blk, int buf) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const unsigned aa = a_addr[s] + buf * 2 * kOpBytes;
+      if (blk == 0) {
+        fa[0][s] = lds_read128<0>(aa);
+        fa[1][s] = lds_read128<16 * kRowB>(aa);
+      } else {
+        fa[0][s] = lds_read128<64 * kRowB>(aa);
+        fa[1][s] = lds_read128<80 * kRowB>(aa);
+      }
+    }
+  };
+  auto read_b = [&](f16x8 (&fb)[4], int mt, int buf) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const unsigned bb = b_addr[s] + buf * 2 * kOpBytes;
+      fb[s] = mt == 0 ? lds_read128<0>(bb) : lds_read128<32 * kRowB>(bb);
+    }
   };
 
-  // Tile order of this XCD's workgroups: the feature tiles are taken in groups of up to 8 (<= 3 MiB of weight, which
-  // then stays in the XCD's 4 MiB L2 while the token slabs stream past); inside a group the tile index runs
-  // feature-tile-fastest over (slab, feature tile), so the ~32 workgroups of the XCD that run side by side share
-  // 8 weight tiles and 4 token slabs per K-step.  Index t enumerates (group, slab, feature tile in group).
-  // (groups of 6 or 12 measure the same)
   constexpr int kGroup = 8;
-  auto tile_bases = [&](long long t, const char*& wbase, const char*& xbase, int& m0, int& n0) {
-    const long long per_full_group = (long long)my_slabs * kGroup;
-    const int grp = (int)(t / per_full_group);                 // all groups but the last hold kGroup feature tiles
+  auto tile_bases = [&](int t, const char*& wbase, const char*& xbase, int& m0, int& n0) {
+    const unsigned per_full_group = (unsigned)my_slabs * kGroup;
+    const int grp = (int)((unsigned)t / per_full_group);
     const int g = tiles_n - grp * kGroup < kGroup ? tiles_n - grp * kGroup : kGroup;
-    const long long r = t - grp * per_full_group;
-    const int slab = xcd + 8 * (int)(r / g);
-    const int nt = grp * kGroup + (int)(r % g);
+    const unsigned r = (unsigned)t - grp * per_full_group;
+    const int slab = xcd + 8 * (int)(r / (unsigned)g);
+    const int nt = grp * kGroup + (int)(r % (unsigned)g);
     m0 = slab * kTile;
     n0 = nt * kTile;
     wbase = (const char*)W + (long long)n0 * K * 2;
     xbase = (const char*)X + (long long)m0 * K * 2;
   };
 
-  long long t = slot;
+  int t = slot;
   if (t >= my_tiles) return;
   const char *wbase, *xbase;
   int m0, n0;
   tile_bases(t, wbase, xbase, m0, n0);
-  issue_step(wbase, xbase, 0, 0);
+
+  // prefetch cursor: the K-step whose DMA is issued next (two steps ahead of the one being computed)
+  int pf_t = t;
+  int pf_step = 0, pf_buf = 0;
+  const char *pf_w = wbase, *pf_x = xbase;
+  bool pf_valid = true;
+  auto pf_advance = [&]() {
+    pf_buf ^= 1;
+    if (++pf_step == n_steps) {
+      pf_step = 0;
+      pf_t += n_slots;
+      pf_valid = pf_t < my_tiles;
+      if (pf_valid) {
+        int um, un;
+        tile_bases(pf_t, pf_w, pf_x, um, un);
+      }
+    }
+  };
+  // prologue: steps 0 and 1 whole, then the first B0
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (pf_valid) {
+      issue_region(0, pf_w, pf_x, pf_step, pf_buf);
+      issue_region(1, pf_w, pf_x, pf_step, pf_buf);
+      issue_region(2, pf_w, pf_x, pf_step, pf_buf);
+      issue_region(3, pf_w, pf_x, pf_step, pf_buf);
+      pf_advance();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f16x8 fa[2][4], fb0[4], fb1[4], fb0n[4];
+  read_b(fb0, 0, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb0[0]), "+v"(fb0[1]), "+v"(fb0[2]), "+v"(fb0[3])::"memory");
+  int buf = 0;                 // ring buffer of the step being computed
+  bool after_epilogue = false; // the epilogue's 16 stores sit between this step's waits and the DMAs they retire
+
+  // interval ends
+#define PP_END_LOAD()                                   \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+  __builtin_amdgcn_sched_barrier(0);                    \
+  __builtin_amdgcn_s_barrier();                         \
+  __builtin_amdgcn_sched_barrier(0)
+#define PP_END_COMPUTE()                                \
+  __builtin_amdgcn_sched_barrier(0);                    \
+  __builtin_amdgcn_s_barrier();                         \
+  __builtin_amdgcn_sched_barrier(0)
 
   for (; t < my_tiles; t += n_slots) {
     f32x16 acc[4][2];
@@ -186,64 +266,80 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) acc[a][b] = f32x16{0};
+    if (wn == 1) __builtin_amdgcn_s_barrier();   // Y falls one interval behind X
 
     for (int step = 0; step < n_steps; ++step) {
-      const int buf = step & 1;
-      dma_wait_barrier();   // step `step` has landed everywhere; every wave is done with the other buffer
-      // Two fragment sets in ping-pong.  Order: reads(0) | DMA of the next step | reads(1), wait(0), MFMAs(0) |
-      // reads(2), wait(1), MFMAs(1) | reads(3), wait(2), MFMAs(2) | wait(3), MFMAs(3): a sub-step's reads are a whole
-      // sub-step (8 MFMAs) ahead of their use, and the waits are counted (6 newer reads may still be in flight).
-      f16x8 fa0[4], fb0[2], fa1[4], fb1[2];
-      read_frags(fa0, fb0, 0, buf);
-      __builtin_amdgcn_sched_barrier(0);
-      if (step + 1 < n_steps) issue_step(wbase, xbase, step + 1, buf ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-      auto mfmas = [&](f16x8 (&fa)[4], f16x8 (&fb)[2]) {
+      const bool last_of_all = step + 1 == n_steps && t + n_slots >= my_tiles;
+      auto quadrant = [&](f16x8 (&a)[2][4], f16x8 (&b)[4], int blk, int mt) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          acc[2 * blk][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][s], b[s], acc[2 * blk][mt], 0, 0, 0);
+          acc[2 * blk + 1][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][s], b[s], acc[2 * blk + 1][mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
       };
-      read_frags(fa1, fb1, 1, buf);
-      lds_wait<6>(fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags(fa0, fb0, 2, buf);
-      lds_wait<6>(fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags(fa1, fb1, 3, buf);
-      lds_wait<6>(fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      lds_wait<0>(fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfmas(fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 0: A0, DMA B0 rows of step + 2 (their last reader was phase 3 of the previous step) -> (A0, B0)
+      if (!(DBG & 1) || step == 0) read_a(fa, 0, buf);
+      if (pf_valid && !(DBG & 2)) issue_region(1, pf_w, pf_x, pf_step, pf_buf);
+      PP_END_LOAD();
+      quadrant(fa, fb0, 0, 0);
+      PP_END_COMPUTE();
+      // ---- phase 1: B1, DMA A0 rows of step + 2 -> (A0, B1)
+      if (!(DBG & 1) || step == 0) read_b(fb1, 1, buf);
+      if (pf_valid && !(DBG & 2)) issue_region(0, pf_w, pf_x, pf_step, pf_buf);
+      PP_END_LOAD();
+      quadrant(fa, fb1, 0, 1);
+      PP_END_COMPUTE();
+      // ---- phase 2: A1, retire the DMAs of step + 1 (4 younger ones stay in flight), DMA B1 rows of step + 2 -> (A1, B1)
+      if (!(DBG & 1) || step == 0) read_a(fa, 1, buf);
+      if (!pf_valid)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (after_epilogue)
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (pf_valid && !(DBG & 2)) issue_region(3, pf_w, pf_x, pf_step, pf_buf);
+      PP_END_LOAD();
+      quadrant(fa, fb1, 1, 1);
+      PP_END_COMPUTE();
+      // ---- phase 3: B0 of the next step, DMA A1 rows of step + 2 -> (A1, B0)
+      if (!last_of_all && (!(DBG & 1) || step == 0)) read_b(fb0n, 0, buf ^ 1);
+      if (pf_valid) {
+        if (!(DBG & 2)) issue_region(2, pf_w, pf_x, pf_step, pf_buf);
+        pf_advance();
+      }
+      PP_END_LOAD();
+      quadrant(fa, fb0, 1, 0);
+      PP_END_COMPUTE();
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fb0[s] = fb0n[s];
+      buf ^= 1;
+      after_epilogue = false;
     }
+    if (wn == 0) __builtin_amdgcn_s_barrier();   // X waits one interval: both groups run the epilogue together
 
-    // every wave is past its last LDS read of this tile before buffer 0 is refilled for the next one
     const int cm0 = m0, cn0 = n0;
-    const long long tn = t + n_slots;
-    __syncthreads();
-    if (tn < my_tiles) {
-      tile_bases(tn, wbase, xbase, m0, n0);
-      issue_step(wbase, xbase, 0, 0);
-    }
+    const int tn = t + n_slots;
+    if (tn < my_tiles) tile_bases(tn, wbase, xbase, m0, n0);
 
-    // ---- epilogue: lane (li, half) owns token row m and, per 64-feature block, features 32 half .. 32 half + 31.
-    // Stored straight from the registers a wave-instruction would write 64 scattered 16-byte pieces (32 rows x 2);
-    // instead every 32-row x 64-feature sub-block (4 KiB of fp16) goes through a wave-private LDS buffer and leaves as
-    // whole 128-byte row segments: 8 lanes per row, 8 rows per store instruction.
+    // ---- epilogue (as in gemm_tn_f16)
     char* stage = lds + 2 * 2 * kOpBytes + wave * 4096;
-    const int wr_sw = (li >> 1) & 7;                  // swizzle of the row this lane writes (row = li)
-    const int rd_row = lane >> 3, rd_q = lane & 7;    // row within an 8-row group / 16-byte piece this lane stores
+    const int wr_sw = (li >> 1) & 7;
+    const int rd_row = lane >> 3, rd_q = lane & 7;
+    if (DBG & 4) {   // keep the accumulators alive with one store
+      float z = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) z += acc[a][b][e];
+      if (z == 123.456f) Y[tid] = (_Float16)z;
+    } else
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-      const int nb = cn0 + wn * 128 + blk * 64;       // first feature of the block
+      const int nb = cn0 + wn * 128 + blk * 64;
       float bv[32];
       if (EPI != EPI_NONE) {
 #pragma unroll
@@ -256,7 +352,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {       // tile j of the block holds features 16 j .. 16 j + 15 of the lane's 32
+        for (int j = 0; j < 2; ++j) {
           const f32x16 v = acc[blk * 2 + j][mt];
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
@@ -268,23 +364,23 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
               if (EPI == EPI_BIAS_GELU) x = gelu_erf(x);
               o[e] = (_Float16)x;
             }
-            const int piece = 4 * half + 2 * j + c;   // 16-byte piece of the 128-byte staged row
+            const int piece = 4 * half + 2 * j + c;
             *(f16x8*)(stage + li * 128 + ((piece ^ wr_sw) << 4)) = o;
           }
         }
-        // the wave's LDS operations execute in program order: the reads below see every lane's writes
         _Float16* dst = Y + (long long)(cm0 + wm * 64 + mt * 32) * N + nb + rd_q * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = 8 * i + rd_row;
           const f16x8 o = *(const f16x8*)(stage + row * 128 + ((rd_q ^ ((row >> 1) & 7)) << 4));
-          // non-temporal: 403 MB of output per BertIntermediate launch would otherwise push the weight group and the
-          // token slabs out of the XCD's L2
           __builtin_nontemporal_store(o, (f16x8*)(dst + (long long)row * N));
         }
       }
     }
+    after_epilogue = true;
   }
+#undef PP_END_LOAD
+#undef PP_END_COMPUTE
 }
 
 }  // namespace
@@ -306,6 +402,15 @@ int proqa_gemm_tn_f16(const void* x, const void* w, const void* bias, void* y, i
   const unsigned grid = (unsigned)std::min<long long>(tiles, device_cu_count());
   hipStream_t st = as_stream(stream);
   const dim3 g(grid), b(kWaves * 64);
+  // developer switch: cut experiments on the main loop (wrong results by design; scripts/dev_gemm_ablate.py)
+  static const int kDbg = getenv("PROQA_GEMM_DBG") ? atoi(getenv("PROQA_GEMM_DBG")) : 0;
+  if (kDbg) {
+#define PP_DBG_CASE(D) case D: hipLaunchKernelGGL((gemm_tn_f16<EPI_NONE, D>), g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)y, (int)m, n, k); break;
+    switch (kDbg) { PP_DBG_CASE(4) PP_DBG_CASE(5) PP_DBG_CASE(6) PP_DBG_CASE(7) PP_DBG_CASE(12) default: return fail(PROQA_EINVAL, "gemm_tn: PROQA_GEMM_DBG=%d is not built", kDbg); }
+#undef PP_DBG_CASE
+    PROQA_LAUNCH_CHECK();
+    return PROQA_OK;
+  }
   switch (epilogue) {
     case EPI_NONE:
       hipLaunchKernelGGL(gemm_tn_f16<EPI_NONE>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
