@@ -336,18 +336,25 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
 #pragma unroll
           for (int e = 0; e < 16; ++e) z += acc[a][b][e];
       if (z == 123.456f) Y[tid] = (_Float16)z;
-    } else
+    } else {
+    // the lane's 2 x 32 bias values, requested before anything is stored: a load issued between the stores of the two
+    // 64-feature blocks would wait for the first block's stores (vmcnt retires in order)
+    f16x8 bias8[2][4];
+    if (EPI != EPI_NONE) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bias8[blk][c] = *(const f16x8*)(bias + cn0 + wn * 128 + blk * 64 + 32 * half + 8 * c);
+    }
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const int nb = cn0 + wn * 128 + blk * 64;
       float bv[32];
       if (EPI != EPI_NONE) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const f16x8 b8 = *(const f16x8*)(bias + nb + 32 * half + 8 * c);
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) bv[8 * c + e] = (float)b8[e];
-        }
+          for (int e = 0; e < 8; ++e) bv[8 * c + e] = (float)bias8[blk][c][e];
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -376,6 +383,7 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
           __builtin_nontemporal_store(o, (f16x8*)(dst + (long long)row * N));
         }
       }
+    }
     }
     after_epilogue = true;
   }
