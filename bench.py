@@ -278,10 +278,13 @@ def encode_leg(args, device, world, rank):
         del model
         torch.cuda.empty_cache()
         res["cli_text"] = cli_text_leg(args, device, sd)
+        # the same command line on a corpus in which 30 % of the passages hold accented words, Greek / Cyrillic words,
+        # Unicode punctuation and CJK runs (Wikipedia-like): the native tokenizer has to keep the GPU fed there too
+        res["cli_text_non_ascii"] = cli_text_leg(args, device, sd, non_ascii=0.3, n_pass=max(20000, args.cli_passages // 2))
     return res
 
 
-def cli_text_leg(args, device, sd):
+def cli_text_leg(args, device, sd, non_ascii=0.0, n_pass=None):
     """Encode throughput through the product's own command line on TEXT ("report separately with real
     text"): 200 000 synthetic ~100-word passages in a JSON-lines file -> proqa_amd.get_embed.main (JSONL read, WordPiece
     tokenisation on --eval-workers threads, collate, upload, encode, D2H, np.save), the reference's
@@ -292,7 +295,7 @@ def cli_text_leg(args, device, sd):
     from proqa_amd import get_embed as ge
     from proqa_amd.datasets import JsonlTexts, TextBatchLoader, TokenizeCollate
     from proqa_amd.retriever import BERT_BASE
-    n_pass = args.cli_passages
+    n_pass = n_pass or args.cli_passages
     d = tempfile.mkdtemp(prefix="proqa_cli_")
     try:
         rng = np.random.default_rng(7)
@@ -312,7 +315,17 @@ def cli_text_leg(args, device, sd):
         pieces = set()
         while len(vocab) + len(words) + len(pieces) < BERT_BASE["vocab_size"]:
             pieces.add("##" + word()[:int(rng.integers(2, 5))])
-        vocab += words + sorted(pieces)
+        # non-ASCII workload: 600 Greek / Cyrillic words and 400 CJK ideographs take the place of as many word pieces
+        foreign = []
+        if non_ascii > 0:
+            greek = [chr(c) for c in range(0x3B1, 0x3CA) if c != 0x3C2]
+            cyr = [chr(c) for c in range(0x430, 0x450)]
+            fw = set()
+            while len(fw) < 600:
+                alpha = greek if len(fw) % 2 else cyr
+                fw.add("".join(rng.choice(alpha, size=int(rng.integers(3, 9)))))
+            foreign = sorted(fw) + [chr(c) for c in range(0x4E00, 0x4E00 + 400)]
+        vocab += words + sorted(pieces)[:BERT_BASE["vocab_size"] - len(vocab) - len(words) - len(foreign)] + foreign
         assert len(vocab) == BERT_BASE["vocab_size"] and len(set(vocab)) == len(vocab)
         model_dir = os.path.join(d, "bert-base-synthetic")
         os.makedirs(model_dir)
@@ -323,14 +336,28 @@ def cli_text_leg(args, device, sd):
         torch.save(sd, os.path.join(d, "ckpt.pt"))
         warr = np.array(words)
         oov = np.array([word() + word() for _ in range(20000)])          # out-of-vocabulary: split into several pieces
-        with open(os.path.join(d, "paras.txt"), "w") as f:
+        accents = str.maketrans({"a": "\u00e1", "e": "\u00e9", "o": "\u00f6", "u": "\u00fc", "n": "\u00f1", "c": "\u00e7"})
+        farr = np.array(foreign[:600]) if foreign else None
+        with open(os.path.join(d, "paras.txt"), "w", encoding="utf-8") as f:
             for i0 in range(0, n_pass, 10000):
                 m = min(10000, n_pass - i0)
                 known = warr[rng.integers(0, len(warr), (m, 88))]
                 unknown = oov[rng.integers(0, len(oov), (m, 12))]
+                mixed = rng.random(m) < non_ascii
                 for r in range(m):
-                    text = " ".join(known[r]) + " " + " ".join(unknown[r])
-                    f.write(json.dumps({"id": f"p{i0 + r}", "text": text.capitalize() + "."}) + "\n")
+                    ws = list(known[r]) + list(unknown[r])
+                    if mixed[r]:
+                        # a passage of the non-ASCII share: a third of its words accented (they fold to the plain words), a
+                        # tenth Greek / Cyrillic, an en dash, curly quotes and a run of CJK ideographs
+                        for j in range(0, len(ws), 3):
+                            ws[j] = ws[j].translate(accents).capitalize() if j % 2 else ws[j].translate(accents)
+                        for j in range(5, len(ws), 10):
+                            ws[j] = str(farr[int(rng.integers(0, len(farr)))])
+                        ws[7] = "\u2013"
+                        ws[20] = "\u201c" + ws[20] + "\u201d"
+                        ws[40] = "".join(foreign[600 + int(v)] for v in rng.integers(0, 400, 6))
+                    text = " ".join(ws)
+                    f.write(json.dumps({"id": f"p{i0 + r}", "text": text[:1].upper() + text[1:] + "."}, ensure_ascii=False) + "\n")
         cores = host_cores()
         argv = ["--do_predict", "--predict_batch_size", str(args.encode_batch), "--bert_model_name", model_dir, "--fp16",
                 "--predict_file", os.path.join(d, "paras.txt"), "--init_checkpoint", os.path.join(d, "ckpt.pt"),
@@ -348,6 +375,20 @@ def cli_text_leg(args, device, sd):
         tok = BertTokenizer.from_pretrained(model_dir)
         ds = JsonlTexts(os.path.join(d, "paras.txt"), 30, args.seq_len, False)
         n_tok = min(n_pass, 60000)
+        native_share = None
+        if non_ascii > 0:      # how many of the mixed passages the library's own WordPiece tokenises itself
+            probe = TokenizeCollate(tok, ds.max_length, parallel=True, native_threads=max(1, cores - 2))
+            import ctypes
+            from proqa_amd import _lib
+            lib_, h_ = probe._native_handle()
+            sample = [ds[i] for i in range(min(n_pass, 20000))]
+            raw = [t.encode("utf-8") for t in sample]
+            ids_ = np.empty((len(raw), ds.max_length), dtype=np.int64)
+            lens_ = np.empty(len(raw), dtype=np.int32)
+            _lib.check(lib_.proqa_wordpiece_encode_batch(h_, (ctypes.c_char_p * len(raw))(*raw),
+                                                         np.fromiter(map(len, raw), dtype=np.int64, count=len(raw)).ctypes.data_as(ctypes.POINTER(ctypes.c_int64)),
+                                                         len(raw), ds.max_length, ids_.ctypes.data, lens_.ctypes.data, max(1, cores - 2)))
+            native_share = float((lens_ >= 0).mean())
         loader = TextBatchLoader(ds, args.encode_batch,
                                  TokenizeCollate(tok, ds.max_length, parallel=True, native_threads=max(1, cores - 2)), prefetch=8,
                                  lo=0, hi=n_tok)
@@ -363,9 +404,10 @@ def cli_text_leg(args, device, sd):
                                 "gpu_busy_seconds": st["gpu_busy_seconds"], "loader_wait_seconds": st["loader_wait_seconds"],
                                 "feed_seconds": st["feed_seconds"], "upload_seconds": st["upload_seconds"],
                                 "gpu_idle_fraction": max(0.0, 1.0 - st["gpu_busy_seconds"] / st["loop_seconds"])},
+                "non_ascii_passage_fraction": non_ascii, "tokenised_by_the_native_wordpiece": native_share,
                 "tokenise_only": {"passages_per_s": n_tok / t_tok, "passages": n_tok,
-                                  "note": "the same loader (TextBatchLoader: one producer thread; plain-ASCII sentences on "
-                                          "libproqa_hip.so's WordPiece, cores - 2 threads) with nothing consumed on the GPU"},
+                                  "note": "the same loader (TextBatchLoader: one producer thread; libproqa_hip.so's table-driven "
+                                          "WordPiece on cores - 2 threads) with nothing consumed on the GPU"},
                 "workload": f"{n_pass} synthetic passages of 100 words (88 in-vocabulary, 12 split into word pieces) in a "
                             f"JSON-lines file, bert-base-shaped 30 522-entry vocabulary, max_seq_length {args.seq_len}, batch "
                             f"{args.encode_batch}; whole call = JSONL read + tokeniser + model/checkpoint load + encode + np.save"}

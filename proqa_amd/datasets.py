@@ -121,10 +121,10 @@ class TokenizeCollate:
     def __init__(self, tokenizer, max_length, parallel=False, native_threads=0):
         """parallel: let the tokenizer library spread a batch over its own thread pool (TextBatchLoader: one producer
         thread in the process that feeds the GPU); off inside DataLoader workers, which are the parallelism there.
-        native_threads > 0: plain-ASCII sentences go through libproqa_hip.so's own WordPiece (proqa_wordpiece_*, that many
-        threads: ids written straight into the batch array, no Python object per token); every other sentence -- and every
-        sentence if the tokenizer is not a plain BERT WordPiece one -- goes through the tokenizer itself, so the batch is
-        the reference's either way."""
+        native_threads > 0: sentences go through libproqa_hip.so's own WordPiece (proqa_wordpiece_*, that many threads: ids
+        written straight into the batch array, no Python object per token); the sentences it declines (a '[', characters
+        beyond the Basic Multilingual Plane) -- and every sentence if the tokenizer is not a plain BERT WordPiece one --
+        go through the tokenizer itself, so the batch is the reference's either way."""
         self.tokenizer = tokenizer
         self.max_length = int(max_length)
         self.parallel = bool(parallel)
@@ -161,7 +161,16 @@ class TokenizeCollate:
                 import json as _json
                 spec = _json.loads(backend.to_str())
                 norm, model = spec.get("normalizer") or {}, spec.get("model") or {}
-                if norm.get("type") != "BertNormalizer" or not norm.get("clean_text", True):
+                if norm.get("type") != "BertNormalizer" or not norm.get("clean_text", True) or \
+                        not norm.get("handle_chinese_chars", True):
+                    return None
+                # accents are stripped iff the model is uncased (strip_accents None follows lowercase): the only
+                # combination the generated tables (scripts/gen_wordpiece_tables.py) describe
+                if norm.get("strip_accents") not in (None, bool(norm.get("lowercase", True))):
+                    return None
+                # tokens added on top of vocab.txt are matched in the raw text before anything else: only the five
+                # bracketed special tokens are expected (a text with a '[' goes to the tokenizer itself anyway)
+                if any("[" not in (a.get("content") or "") for a in spec.get("added_tokens") or []):
                     return None
                 if model.get("type") != "WordPiece" or model.get("continuing_subword_prefix") != "##" or \
                         model.get("max_input_chars_per_word", 100) != 100 or model.get("unk_token") != "[UNK]":
@@ -170,6 +179,13 @@ class TokenizeCollate:
                     return None
                 lower = bool(norm.get("lowercase", True))
             else:
+                # a pure-Python BertTokenizer: the defaults of its BasicTokenizer only, and no added tokens
+                if not getattr(tokenizer, "do_basic_tokenize", True) or getattr(tokenizer, "added_tokens_encoder", None):
+                    return None
+                basic = getattr(tokenizer, "basic_tokenizer", None)
+                if basic is not None and (getattr(basic, "never_split", None) or not getattr(basic, "tokenize_chinese_chars", True)
+                                          or getattr(basic, "strip_accents", None) not in (None, bool(getattr(basic, "do_lower_case", True)))):
+                    return None
                 lower = bool(getattr(tokenizer, "do_lower_case", True))
             return ("\n".join(toks).encode("utf-8"), lower)
         except Exception:
@@ -213,7 +229,7 @@ class TokenizeCollate:
         return [e.ids for e in self._backend.encode_batch(list(texts), add_special_tokens=True)]
 
     def _call_native(self, texts):
-        """The batch through proqa_wordpiece_encode_batch; sentences it declines (non-ASCII, a '[') through _encode."""
+        """The batch through proqa_wordpiece_encode_batch; sentences it declines (a '[', non-BMP characters) through _encode."""
         import ctypes
         lib, h = self._native_handle()
         n, L = len(texts), self.max_length
@@ -281,6 +297,15 @@ class TextBatchLoader:
         stop = threading.Event()
         starts = list(range(self.lo, self.hi, self.batch_size))
 
+        def put_last(q, item):
+            """The end marker / the exception: like a batch, never blocks past a consumer that has gone away."""
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return
+                except queue.Full:
+                    pass
+
         def produce(p, collate):
             try:
                 os.nice(10)          # Linux: per thread; the tokenizer's pool is started from here and inherits it
@@ -298,9 +323,9 @@ class TextBatchLoader:
                             break
                         except queue.Full:
                             pass
-                q.put(None)
+                put_last(q, None)
             except BaseException as e:      # handed to the consumer
-                q.put(e)
+                put_last(q, e)
 
         for p in range(n_prod):
             # (every producer its own collate object: TokenizeCollate keeps a private tokenizer handle)

@@ -120,7 +120,12 @@ int main(int argc, char** argv) {
     proqa_wordpiece* tok = nullptr;
     CHECK(proqa_wordpiece_create(vocab.data(), vocab.size(), 1, &tok) == 0);
     std::vector<std::string> texts = {"", "AB abcd abc. zz", std::string(100, 'x'), std::string(101, 'x'), "ab\x01" "cd \t ab",
-                                      "caf\xc3\xa9", "[CLS]", "ab ab ab ab ab ab ab ab ab ab"};
+                                      "caf\xc3\xa9", "[CLS]", "ab ab ab ab ab ab ab ab ab ab",
+                                      // malformed or out-of-table UTF-8 must be handed back, never read past: a cut-off
+                                      // three-byte sequence, a lone continuation byte, an overlong form, an emoji, a surrogate
+                                      "ab \xe4\xb8", "\x80", "\xc0\xaf", "ab \xf0\x9f\x98\x80", "\xed\xa0\x80",
+                                      // table paths: CJK spacing, Hangul decomposition, a stripped mark, Unicode punctuation
+                                      "ab\xe4\xb8\xad" "ab", "\xed\x95\x9c", "a\xcc\x81" "b.", "ab\xe2\x80\x94" "ab"};
     std::vector<const char*> ptrs;
     std::vector<int64_t> sizes;
     for (auto& t : texts) {
@@ -134,7 +139,12 @@ int main(int argc, char** argv) {
         CHECK(proqa_wordpiece_encode_batch(tok, ptrs.data(), sizes.data(), (int64_t)texts.size(), max_length, ids.data(),
                                            lens.data(), threads) == 0);
         CHECK(lens[0] == 2 && ids[0] == 2 && ids[1] == 3);                       // "" -> [CLS] [SEP]
-        CHECK(lens[5] == -1 && lens[6] == -1);                                     // non-ASCII / a '[': declined
+        CHECK(lens[6] == -1);                                                      // a '[': declined
+        // malformed / beyond the BMP: declined (unless the row was full before the bad byte was reached: what follows the
+        // truncation point changes no kept token)
+        if (max_length >= 8)
+          for (int i = 8; i <= 12; ++i) CHECK(lens[i] == -1);
+        for (int i = 13; i <= 16; ++i) CHECK(lens[i] >= 2);
         for (size_t i = 0; i < texts.size(); ++i) CHECK(lens[i] == -1 || (lens[i] >= 2 && lens[i] <= max_length));
         if (max_length == 128) {
           CHECK(lens[1] == 9);   // [CLS] ab ab ##cd ab ##c . [UNK] [SEP]
@@ -143,6 +153,10 @@ int main(int argc, char** argv) {
           CHECK(lens[2] == 102 && ids[2 * 128 + 1] == 8 && ids[2 * 128 + 100] == 9);   // 100 x: x ##x ... ##x
           CHECK(lens[3] == 3 && ids[3 * 128 + 1] == 1);                                 // 101 x: [UNK]
           CHECK(lens[4] == 5 && ids[4 * 128 + 1] == 4 && ids[4 * 128 + 2] == 5);        // the control byte vanishes: "abcd"
+          CHECK(lens[5] == 3 && ids[5 * 128 + 1] == 1);                                 // "cafe" after the accent is stripped: [UNK]
+          CHECK(lens[13] == 5 && ids[13 * 128 + 1] == 4 && ids[13 * 128 + 2] == 1 && ids[13 * 128 + 3] == 4);   // ab [UNK] ab
+          CHECK(lens[15] == 4 && ids[15 * 128 + 1] == 4 && ids[15 * 128 + 2] == 7);      // "ab" "." : the acute accent is gone
+          CHECK(lens[16] == 5 && ids[16 * 128 + 2] == 1);                                // the em dash stands alone
         }
       }
     }

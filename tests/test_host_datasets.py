@@ -2,6 +2,7 @@
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -213,6 +214,113 @@ def test_native_wordpiece_equals_the_reference_tokenizer(tmp_path, lower):
             L = case["max_query_length"] if case["is_query"] else case["max_length"]
             batch = datasets.TokenizeCollate(tok, L, native_threads=2)(gold["texts"])
             assert batch["input_ids"].tolist() == case["input_ids"] and batch["seq_lens"] == case["item_lengths"]
+
+
+def _unicode_vocab_and_texts(n_texts, seed):
+    """A synthetic vocabulary with tokens of many scripts (whole words and ## pieces of the NORMALISED forms the
+    tokenizer produces) and random strings over Latin-1 / Latin Extended / Greek / Cyrillic / Hebrew / Arabic / Devanagari /
+    Thai / Hangul / kana / CJK / punctuation / symbol / combining-mark / white-space / control blocks."""
+    import random
+    import unicodedata
+    rng = random.Random(seed)
+    blocks = [(0x00A0, 0x024F), (0x0370, 0x03FF), (0x0400, 0x04FF), (0x0590, 0x05FF), (0x0600, 0x06FF), (0x0900, 0x097F),
+              (0x0E00, 0x0E7F), (0x1100, 0x11FF), (0x1E00, 0x1FFF), (0x2000, 0x206F), (0x2070, 0x21FF), (0x2200, 0x22FF),
+              (0x3000, 0x30FF), (0x3400, 0x3500), (0x4E00, 0x4F00), (0xAC00, 0xAD00), (0xF900, 0xFA6A), (0xFE30, 0xFE6F),
+              (0xFF00, 0xFFEF), (0x0300, 0x036F), (0x0080, 0x009F), (0xE000, 0xE010), (0xFFF0, 0xFFFF)]
+    pool = [chr(c) for a, b in blocks for c in range(a, b + 1) if not 0xD800 <= c <= 0xDFFF]
+    ascii_words = ["the", "of", "and", "cafe", "naive", "resume", "uber", "strasse", "hello", "world", "tokyo", "a", "i", "x"]
+
+    def one():
+        out = []
+        for _ in range(rng.randrange(0, 30)):
+            r = rng.random()
+            if r < 0.25:
+                out.append(rng.choice(ascii_words))
+            elif r < 0.35:
+                out.append(rng.choice(ascii_words).upper())
+            elif r < 0.75:
+                out.append("".join(rng.choice(pool) for _ in range(rng.randrange(1, 6))))
+            elif r < 0.85:
+                out.append(rng.choice(ascii_words) + rng.choice(pool) + rng.choice(ascii_words))
+            elif r < 0.9:
+                out.append("".join(chr(rng.randrange(0, 128)) for _ in range(3)).replace("[", "("))
+            else:
+                out.append(unicodedata.normalize("NFC", rng.choice("aeiounc") + rng.choice("\u0301\u0308\u0303\u0327\u030c")))
+        return (" " if rng.random() < 0.7 else "").join(out)
+
+    texts = [one() for _ in range(n_texts)] + ["Ελληνικά ΚΑΙ Σ", "İstanbul ǅ ß ẞ", "한국어 텍스트", "日本語のテキスト。", "a\u00adb\u200bc\ufeffd",
+                                               "x\u2028y\u3000z", "≠ ≤ ≥ ∑", "ﬁne ﬂow", "Ⅷ ½ ²", "e\u0301\u0327 o\u0327\u0301", "ॐ नमः", "ไทย", "\ufffd\x00"]
+    return pool, ascii_words, texts
+
+
+@pytest.mark.parametrize("lower", [True, False])
+def test_native_wordpiece_handles_non_ascii_text_itself(tmp_path, lower):
+    """Integer parity of the table-driven Unicode path of proqa_wordpiece_encode_batch: 20 000 random strings over
+    two dozen blocks of the Basic Multilingual Plane, ids / lengths identical to transformers' BertTokenizer at two
+    truncation limits, uncased and cased -- and the native code must tokenise them ITSELF (only a '[', a character beyond
+    the BMP or one of the 15 reordering-sensitive marks may be handed back)."""
+    import ctypes
+    from tokenizers import normalizers
+    from transformers import BertTokenizer
+    from proqa_amd import _lib
+    pool, ascii_words, texts = _unicode_vocab_and_texts(20000, 41 + lower)
+    # vocabulary: specials, ASCII characters, every NORMALISED character of a sample of the pool (whole and ##), words
+    norm = normalizers.BertNormalizer(lowercase=lower)
+    import random
+    rng = random.Random(3)
+    chars = set()
+    for c in rng.sample(pool, len(pool) // 2):
+        chars.update(ch for ch in norm.normalize_str(c) if not ch.isspace())
+    chars.update(chr(c) for c in range(33, 127))
+    chars.discard("[")
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + sorted(chars) + ["##" + c for c in sorted(chars) if c.isalnum() or ord(c) > 0x2FF]
+    vocab += ascii_words + [w.upper() for w in ascii_words if not lower] + ["##" + w for w in ascii_words]
+    pairs = sorted({a + b for a in rng.sample(sorted(chars), 200) for b in rng.sample(sorted(chars), 5)})
+    vocab += [p_ for p_ in pairs if p_ not in chars] + ["##" + p_ for p_ in pairs[::3]]
+    vocab = list(dict.fromkeys(vocab))
+    d = tmp_path / "model"
+    d.mkdir()
+    (d / "vocab.txt").write_text("\n".join(vocab) + "\n", encoding="utf-8")
+    tok = BertTokenizer.from_pretrained(str(d), do_lower_case=lower)
+    spec = datasets.TokenizeCollate._native_vocab(tok)
+    assert spec is not None and spec[1] == lower
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.proqa_wordpiece_create(spec[0], len(spec[0]), 1 if lower else 0, ctypes.byref(h)))
+    try:
+        raw = [t.encode("utf-8") for t in texts]
+        n = len(raw)
+        ptrs = (ctypes.c_char_p * n)(*raw)
+        sizes = np.fromiter(map(len, raw), dtype=np.int64, count=n)
+        for L in (24, 512):
+            ids = np.empty((n, L), dtype=np.int64)
+            lens = np.empty(n, dtype=np.int32)
+            _lib.check(lib.proqa_wordpiece_encode_batch(h, ptrs, sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n, L,
+                                                        ids.ctypes.data, lens.ctypes.data, 4))
+            declined = int((lens < 0).sum())
+            assert declined <= n // 100, declined            # (the pool holds two of the reordering-sensitive marks: ~0.6 % of the texts)
+            unk = vocab.index("[UNK]")
+            known = 0
+            for i, text in enumerate(texts):
+                if lens[i] < 0:
+                    continue
+                want = tok.encode(text, max_length=L, truncation=True)
+                assert ids[i, :lens[i]].tolist() == want and not ids[i, lens[i]:].any(), (L, i, text)
+                known += sum(1 for v in want if v != unk)
+            assert known > 5 * n                             # the comparison is not [UNK] == [UNK]
+    finally:
+        lib.proqa_wordpiece_free(h)
+    # texts the native code hands back
+    for text in ("a [SEP] b", "emoji \U0001F600", "tone \u302e mark"):
+        b = text.encode("utf-8")
+        one = np.empty((1, 16), dtype=np.int64)
+        ln = np.empty(1, dtype=np.int32)
+        h2 = ctypes.c_void_p()
+        _lib.check(lib.proqa_wordpiece_create(spec[0], len(spec[0]), 1 if lower else 0, ctypes.byref(h2)))
+        _lib.check(lib.proqa_wordpiece_encode_batch(h2, (ctypes.c_char_p * 1)(b), (ctypes.c_int64 * 1)(len(b)), 1, 16,
+                                                    one.ctypes.data, ln.ctypes.data, 1))
+        lib.proqa_wordpiece_free(h2)
+        assert ln[0] == -1, text
 
 
 def test_native_wordpiece_is_declined_for_other_tokenizers(tokenizer):
