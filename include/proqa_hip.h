@@ -331,19 +331,30 @@ int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* 
 
 /* ------------------------------------------------------------------------------------
  * WordPiece tokenisation on the host, native and multi-threaded: `tokenizer.encode(sent, max_length=L)` of
- * retrieval/datasets.py:285-286 (transformers' BertTokenizer) for the texts it reproduces exactly -- pure 7-bit ASCII
- * without a '[' -- so that get_embed.py's loader does not depend on ~3.5 k passages/s per thread of Python-bound
- * tokenizer calls.  Other texts are flagged (length -1) and left to the caller's reference tokenizer.
+ * retrieval/datasets.py:285-286 (transformers' BertTokenizer: clean-up, CJK spacing, NFD + accent stripping + lower-casing
+ * for uncased models, punctuation splitting, greedy WordPiece) for every text of the Basic Multilingual Plane without a
+ * '[', table-driven (csrc/wordpiece_tables.inc, generated from the tokenizers library), so that get_embed.py's loader does
+ * not depend on ~3.5 k passages/s per thread of Python-bound tokenizer calls.  The few other texts are flagged and left to
+ * the caller's reference tokenizer.
  * ---------------------------------------------------------------------------------- */
 typedef struct proqa_wordpiece proqa_wordpiece;
 /* vocab: the tokens of vocab.txt joined by '\n' (token i has id i), vocab_bytes long; do_lower_case as the model's */
 int proqa_wordpiece_create(const char* vocab, size_t vocab_bytes, int do_lower_case, proqa_wordpiece** out);
 int proqa_wordpiece_free(proqa_wordpiece* tok);
 /* texts[i] (text_bytes[i] bytes, UTF-8, not NUL-terminated) -> ids_out[i, 0..max_length) = [CLS] pieces [SEP] truncated
- * to max_length, zero-padded; lens_out[i] = its length, or -1 if text i is not plain ASCII (row i of ids_out is then
- * unspecified).  n_threads host threads share the batch. */
+ * to max_length, zero-padded; lens_out[i] = its length, or -1 if text i is left to the caller's reference tokenizer (a '[',
+ * a character beyond the Basic Multilingual Plane, one of 15 reordering-sensitive marks, malformed UTF-8; row i of ids_out
+ * is then unspecified).  n_threads host threads share the batch. */
 int proqa_wordpiece_encode_batch(const proqa_wordpiece* tok, const char* const* texts, const int64_t* text_bytes, int64_t n,
                                  int max_length, int64_t* ids_out, int32_t* lens_out, int n_threads);
+/* The same straight from the records of the JSON-lines input file (retrieval/datasets.py:271-283: json.loads(line) and
+ * sample['text'] / sample['question']): lines[i] (line_bytes[i] bytes, surrounding white space allowed) is one JSON object,
+ * the string value of its top-level member `key` (NUL-terminated) is tokenised.  lens_out[i] = -2 for a record this parser
+ * does not take -- anything but a flat object of strings, numbers and true / false / null, a surrogate escape, a missing or
+ * non-string member, any deviation from the JSON grammar: the caller's json module reads (or rejects) those lines. */
+int proqa_wordpiece_encode_jsonl_batch(const proqa_wordpiece* tok, const char* const* lines, const int64_t* line_bytes,
+                                       int64_t n, const char* key, int max_length, int64_t* ids_out, int32_t* lens_out,
+                                       int n_threads);
 
 /* ------------------------------------------------------------------------------------
  * Multi-GPU search without PyTorch (BASELINE.json configs[3]).  One process (or thread)

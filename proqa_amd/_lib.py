@@ -130,6 +130,8 @@ SIGNATURES = {
     "proqa_wordpiece_free": (c_int, [c_void_p]),
     "proqa_wordpiece_encode_batch": (c_int, [c_void_p, ctypes.POINTER(c_char_p), ctypes.POINTER(c_int64), c_int64, c_int,
                                              c_void_p, c_void_p, c_int]),
+    "proqa_wordpiece_encode_jsonl_batch": (c_int, [c_void_p, ctypes.POINTER(c_char_p), ctypes.POINTER(c_int64), c_int64,
+                                                   c_char_p, c_int, c_void_p, c_void_p, c_int]),
     "proqa_comm_get_unique_id": (c_int, [c_void_p]),
     "proqa_comm_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
     "proqa_comm_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),

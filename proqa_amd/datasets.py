@@ -96,7 +96,8 @@ class JsonlTexts(Dataset):
         self.is_query_embed = is_query_embed
         self.key = "question" if is_query_embed else "text"
         print(f"Loading data from {data_path}")
-        with open(data_path) as f:
+        # (raw bytes: json.loads takes them as they are, and the native tokenizer reads the member out of the line itself)
+        with open(data_path, "rb") as f:
             self.lines = f.readlines()
         self.max_length = max_query_length if is_query_embed else max_length
         print(f"Max sequence length: {self.max_length}")
@@ -241,9 +242,32 @@ class TokenizeCollate:
         from . import _lib
         _lib.check(lib.proqa_wordpiece_encode_batch(h, ptrs, sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n, L,
                                                     ids.ctypes.data, lens.ctypes.data, self.native_threads))
+        return self._finish_native(ids, lens, lambda i: texts[i])
+
+    def call_lines(self, lines, key):
+        """The batch straight from JSON-lines records (bytes): == self([json.loads(l)[key] for l in lines]).  With the
+        native tokenizer the member is read out of every record by the library (proqa_wordpiece_encode_jsonl_batch: no
+        Python object per passage); records it does not take (-2) are parsed here, texts it declines (-1) are tokenised by
+        the tokenizer itself."""
+        if self._native_spec is None or len(lines) == 0:
+            return self([json.loads(line.strip())[key] for line in lines])
+        import ctypes
+        from . import _lib
+        lib, h = self._native_handle()
+        n, L = len(lines), self.max_length
+        ptrs = (ctypes.c_char_p * n)(*lines)
+        sizes = np.fromiter(map(len, lines), dtype=np.int64, count=n)
+        ids = np.empty((n, L), dtype=np.int64)
+        lens = np.empty(n, dtype=np.int32)
+        _lib.check(lib.proqa_wordpiece_encode_jsonl_batch(h, ptrs, sizes.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), n,
+                                                          key.encode("utf-8"), L, ids.ctypes.data, lens.ctypes.data,
+                                                          self.native_threads))
+        return self._finish_native(ids, lens, lambda i: json.loads(lines[i].strip())[key])
+
+    def _finish_native(self, ids, lens, text_of):
         rest = np.nonzero(lens < 0)[0]
         if len(rest):
-            for i, x in zip(rest.tolist(), self._encode([texts[i] for i in rest.tolist()])):
+            for i, x in zip(rest.tolist(), self._encode([text_of(i) for i in rest.tolist()])):
                 ids[i, :len(x)] = x
                 ids[i, len(x):] = 0
                 lens[i] = len(x)
@@ -296,6 +320,7 @@ class TextBatchLoader:
         queues = [queue.Queue(maxsize=max(1, self.prefetch // n_prod)) for _ in range(n_prod)]
         stop = threading.Event()
         starts = list(range(self.lo, self.hi, self.batch_size))
+        by_line = isinstance(self.texts, JsonlTexts) and hasattr(self.collate, "call_lines")
 
         def put_last(q, item):
             """The end marker / the exception: like a batch, never blocks past a consumer that has gone away."""
@@ -316,7 +341,11 @@ class TextBatchLoader:
                 for b0 in starts[p::n_prod]:
                     if stop.is_set():
                         return
-                    item = collate([self.texts[i] for i in range(b0, min(b0 + self.batch_size, self.hi))])
+                    b1 = min(b0 + self.batch_size, self.hi)
+                    if by_line:          # JsonlTexts: the records go to the collate as they are
+                        item = collate.call_lines(self.texts.lines[b0:b1], self.texts.key)
+                    else:
+                        item = collate([self.texts[i] for i in range(b0, b1)])
                     while not stop.is_set():
                         try:
                             q.put(item, timeout=0.1)

@@ -160,6 +160,29 @@ int main(int argc, char** argv) {
         }
       }
     }
+    {
+      // records of a JSON-lines file: plain ones are tokenised, everything cut off or unusual is handed back (-2) without a
+      // read past the end of the line
+      std::vector<std::string> recs = {"{\"id\": 1, \"text\": \"ab abcd\"}\n", "{\"text\": \"a\\", "{\"text\": \"\\u12", "{\"text\": \"\\u00e9x\"}",
+                                       "{\"text\"", "{", "", "{\"text\": \"ab\", \"n\": -", "{\"text\": \"ab\", \"n\": 1e", "{\"text\": \"ab\"} x",
+                                       "{\"n\": tru", "  {\"text\":\"ab\",\"k\":null}  "};
+      std::vector<const char*> rp;
+      std::vector<int64_t> rs;
+      for (auto& r : recs) {
+        rp.push_back(r.data());
+        rs.push_back((int64_t)r.size());
+      }
+      for (int threads : {1, 5}) {
+        std::vector<int64_t> ids(recs.size() * 8, -7);
+        std::vector<int32_t> lens(recs.size(), -7);
+        CHECK(proqa_wordpiece_encode_jsonl_batch(tok, rp.data(), rs.data(), (int64_t)recs.size(), "text", 8, ids.data(), lens.data(),
+                                                 threads) == 0);
+        CHECK(lens[0] == 5 && ids[1] == 4 && ids[2] == 4 && ids[3] == 5);   // [CLS] ab ab ##cd [SEP]
+        CHECK(lens[3] == 3 && lens[11] == 3);
+        for (int i : {1, 2, 4, 5, 6, 7, 8, 9, 10}) CHECK(lens[i] == -2);
+      }
+      CHECK(proqa_wordpiece_encode_jsonl_batch(tok, rp.data(), rs.data(), 1, nullptr, 8, nullptr, nullptr, 1) == PROQA_EINVAL);
+    }
     CHECK(proqa_wordpiece_encode_batch(tok, ptrs.data(), sizes.data(), 1, 1, nullptr, nullptr, 1) == PROQA_EINVAL);
     CHECK(proqa_wordpiece_free(tok) == 0);
     const std::string no_special = "a\nb";

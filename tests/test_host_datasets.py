@@ -323,6 +323,68 @@ def test_native_wordpiece_handles_non_ascii_text_itself(tmp_path, lower):
         assert ln[0] == -1, text
 
 
+def test_native_jsonl_records_equal_json_loads(tokenizer, tmp_path):
+    """proqa_wordpiece_encode_jsonl_batch reads sample[key] out of the JSON-lines record itself: on 5000 random records
+    (key order, escapes of every kind, \\uXXXX incl. surrogate pairs, numbers, literals, white space, repeated keys) and on
+    malformed / unusual ones the batch equals the one made from json.loads(line)[key]; whatever the native parser does
+    not take is parsed by Python, and a line Python rejects still raises."""
+    import random
+    rng = random.Random(17)
+    texts = _random_strings(2500, 31) + _random_ascii(2500, 32)
+    lines = []
+    for i, t in enumerate(texts):
+        rec = {"id": rng.choice([i, f"doc{i}", -i, 1.5e3, None, True]), "text": t, "title": rng.choice(["T", "q\"uote", "tab\there", ""])}
+        if rng.random() < 0.3:
+            rec = dict(reversed(list(rec.items())))
+        line = json.dumps(rec, ensure_ascii=rng.random() < 0.5, separators=rng.choice([(",", ":"), (", ", ": "), (" ,\t", " : ")]))
+        if rng.random() < 0.1:
+            line = "  " + line + " \r"
+        lines.append((line + "\n").encode("utf-8"))
+    special = [b'{"text": "first", "text": "second value"}\n',                      # a repeated key: the last one counts
+               b'{"text": "nested next", "meta": {"a": [1, 2]}}\n',                 # nested container: Python's business
+               b'{"meta": ["x"], "text": "list first"}\n',
+               b'{"text": "pair \\ud83d\\ude00 end"}\n',                              # surrogate escape pair
+               b'{"text": "sol\\/idus \\b\\f"}\n', b'{"text":"","id":0}\n', b'{"id": -0.5e-3, "text": "num"}\n',
+               '{"text": "caf\u00e9 na\u00efve"}\n'.encode("utf-8")]
+    lines += special
+    key = "text"
+    for limit in (12, 64):
+        ref = datasets.TokenizeCollate(tokenizer, limit)
+        nat = datasets.TokenizeCollate(tokenizer, limit, native_threads=3)
+        for b0 in range(0, len(lines), 211):
+            chunk = lines[b0:b0 + 211]
+            a = ref([json.loads(ln.strip())[key] for ln in chunk])
+            b = nat.call_lines(chunk, key)
+            assert torch.equal(a["input_ids"], b["input_ids"]) and a["seq_lens"] == b["seq_lens"], (limit, b0)
+    # what the native parser takes and what it leaves (lens -2) -- and it must take the plain records
+    import ctypes
+    from proqa_amd import _lib
+    lib, h = datasets.TokenizeCollate(tokenizer, 32, native_threads=1)._native_handle()
+
+    def native_len(line):
+        ids = np.empty((1, 32), dtype=np.int64)
+        ln = np.empty(1, dtype=np.int32)
+        _lib.check(lib.proqa_wordpiece_encode_jsonl_batch(h, (ctypes.c_char_p * 1)(line), (ctypes.c_int64 * 1)(len(line)), 1, b"text", 32,
+                                                          ids.ctypes.data, ln.ctypes.data, 1))
+        return int(ln[0])
+    assert native_len(b'{"id": 3, "text": "plain record"}\n') > 0
+    assert native_len(special[0]) > 0 and native_len(special[4]) > 0 and native_len(special[6]) > 0
+    for odd in (special[1], special[2], special[3], b'{"text": 5}', b'{"id": 1}', b'{"text": "x"} trailing', b'{"text": "x",}',
+                b'{"text": "bad \\x escape"}', b'{"text": "ctrl \x01"}', b'{"id": 01, "text": "x"}', b'{"id": NaN, "text": "x"}',
+                b'["text"]', b'', b'{"text": "unterminated'):
+        assert native_len(odd) == -2, odd
+    # a record Python rejects raises from the collate, as it does in EmDataset
+    with pytest.raises(ValueError):
+        datasets.TokenizeCollate(tokenizer, 32, native_threads=2).call_lines([b'{"text": "ok"}', b'{"text": "x",}'], "text")
+    # the loader takes this path for a JsonlTexts view and yields the same batches as the per-item path
+    path = tmp_path / "paras.txt"
+    path.write_bytes(b"".join(lines[:700]))
+    view = datasets.JsonlTexts(str(path), 30, 48, False)
+    fast = list(datasets.TextBatchLoader(view, 64, datasets.TokenizeCollate(tokenizer, 48, native_threads=2)))
+    slow = [datasets.TokenizeCollate(tokenizer, 48)([view[i] for i in range(b0, min(b0 + 64, 700))]) for b0 in range(0, 700, 64)]
+    assert len(fast) == len(slow) and all(torch.equal(x["input_ids"], y["input_ids"]) for x, y in zip(fast, slow))
+
+
 def test_native_wordpiece_is_declined_for_other_tokenizers(tokenizer):
     """A tokenizer the native code does not restate (here: a vocabulary with a gap in its ids) keeps the library path."""
     class Odd:
