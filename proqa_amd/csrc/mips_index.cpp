@@ -478,6 +478,7 @@ struct RoundShape {
   unsigned want_chunks = 0;   // corpus chunks to aim at
   unsigned lane_cap = 0;      // records per lane list
   int sort_cap = 0;           // keys the merge holds
+  bool compact = false;       // lane lists of 8-byte keys instead of column records (the dense one-pass launch)
 };
 
 int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
@@ -498,6 +499,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   fa.store = store_of(idx, nq_pad, n_qtiles, lane_cap, round_up<unsigned>(g.chunks, 8));
   fa.overflow = overflow_word;
   fa.flags = kFilterFlags;
+  fa.compact = shape.compact ? 1 : 0;
   if (f0) PROQA_HIP(hipEventRecord(f0, st));
   PROQA_HIP(launch_filter(fa, qw, inclusive, g.grid, st));
   if (f1) PROQA_HIP(hipEventRecord(f1, st));
@@ -520,6 +522,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.margin = idx->exact ? idx->margin : nullptr;
   ma.tau_filter = idx->exact ? idx->tau_filter : nullptr;
   ma.dbg = nullptr;
+  ma.compact = shape.compact ? 1 : 0;
 #ifdef PROQA_MERGE_STAMPS
   {
     static unsigned long long* dbg_buf = nullptr;
@@ -743,10 +746,13 @@ struct OnePassPlan {
   long long n_sample = 0;   // sample rows
   int sort_cap = 0;         // keys the final merge holds
   unsigned want_chunks = 0;
+  unsigned lane_cap = 0;       // records per lane list of the big launch
+  bool compact = false;        // the big launch logs 8-byte keys (mips_filter_f16<COMPACT>)
   long long max_queries = 0;   // per launch, within kOnePassMaxStoreBytes of candidate store
 };
 
 const bool kOnePass = !(getenv("PROQA_ONE_PASS") && atoi(getenv("PROQA_ONE_PASS")) == 0);   // developer A/B switch
+const bool kOnePassCompact = !(getenv("PROQA_ONE_PASS_COMPACT") && atoi(getenv("PROQA_ONE_PASS_COMPACT")) == 0);   // the same, for its compact lists
 const bool kOnePassTwoStep = !(getenv("PROQA_ONE_PASS_TWO_STEP") && atoi(getenv("PROQA_ONE_PASS_TWO_STEP")) == 0);   // the same, for its sample
 constexpr size_t kOnePassMaxStoreBytes = 24ull << 30;   // a batch whose store would be larger is searched in groups
 
@@ -773,16 +779,21 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool la
   p.sort_cap = most <= kMaxSortKeys ? kMaxSortKeys : (most <= kBigSortKeys ? kBigSortKeys : kOnePassSortKeys);
   p.n_sample = round_up<long long>((long long)(p.r * (double)idx->n / expected), kStageRows);
   if (p.n_sample > idx->n / 4) return p;                       // k is a large part of the shard
-  p.want_chunks = round_up<unsigned>((unsigned)std::ceil(expected / 16.0), 8);   // two lists per chunk, ~8 records each
+  // Dense regime (thousands of queries x a large k: more than every second 32-row unit of a wave holds a score above its
+  // threshold): compact lists of 8-byte keys, ~24 per list of 70; otherwise column records, ~8 per list of 24.
+  p.compact = kOnePassCompact && !latency_bound && expected / (double)idx->n * 2048.0 > 0.5;
+  p.lane_cap = p.compact ? (unsigned)kCompactLaneCap : (unsigned)kOnePassLaneCap;
+  const double per_list = p.compact ? 24.0 : 8.0;
+  p.want_chunks = round_up<unsigned>((unsigned)std::ceil(expected / (2.0 * per_list)), 8);   // two lists per chunk
   if ((long long)p.want_chunks * kStageRows > idx->n) return p;
   {
     // chunks are whole stages: a shard of few stages per chunk may end up with fewer chunks than asked for
     const long long rpc = round_up<long long>(ceil_div<long long>(idx->n, p.want_chunks), kStageRows);
     const long long chunks = ceil_div<long long>(idx->n, rpc);
-    if (expected / (2.0 * chunks) > 12.0) return p;            // lists of 24 would spill: pages
+    if (expected / (2.0 * chunks) > 1.5 * per_list) return p;  // the lists would spill: pages
   }
   // queries one launch can take within the store budget (whole query tiles)
-  const size_t per_query = (size_t)(p.want_chunks + 8) * 2 * kOnePassLaneCap * sizeof(WaveRecord);
+  const size_t per_query = (size_t)(p.want_chunks + 8) * 2 * p.lane_cap * sizeof(WaveRecord);
   size_t budget = kOnePassMaxStoreBytes;
   if (const char* v = getenv("PROQA_ONE_PASS_STORE_MB")) budget = (size_t)atoll(v) << 20;   // tests: force the grouping
   p.max_queries = (long long)(budget / per_query) / 512 * 512;
@@ -815,7 +826,7 @@ int one_pass_big_launch(proqa_index* idx, const OnePassPlan& pl, const RoundShap
 int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int k,
                     const PageOut& out, hipStream_t st, bool* done) {
   *done = false;
-  const RoundShape shape{pl.want_chunks, (unsigned)kOnePassLaneCap, pl.sort_cap};
+  const RoundShape shape{pl.want_chunks, pl.lane_cap, pl.sort_cap, pl.compact};
   // the big launch's store first, so that the sample rounds do not allocate a small one that is thrown away
   {
     const LaunchGeom g = geometry(idx->n, n_qtiles, false, k, shape.want_chunks);

@@ -67,6 +67,10 @@ struct CandidateStore {
   unsigned n_chunks;     // corpus chunks of this launch, rounded up to 8: stride of the query-major / slot-major counters
 };
 
+constexpr int kKeysPerRecord = 10;  // compact lists: 8-byte keys in the room of one WaveRecord
+static_assert(kKeysPerRecord * 8 == 80, "compact list addressing");
+constexpr int kCompactLaneCap = 7;  // records' worth per lane list of a compact launch: 70 keys (the chunk count aims at ~24)
+
 struct FilterArgs {
   const void* xq;        // fp16 [nq_pad,128], zero rows beyond nq
   const char* xb;        // fp16 corpus rows of this shard
@@ -78,6 +82,7 @@ struct FilterArgs {
   CandidateStore store;
   unsigned* overflow;    // set to 1 if a record had to be dropped in this launch
   unsigned flags;        // developer experiments (PROQA_FILTER_FLAGS), 0 in production
+  int compact;           // lane lists hold the passing scores as 8-byte keys (mips_filter_f16<COMPACT>), not column records
 };
 
 struct MergeArgs {
@@ -101,6 +106,7 @@ struct MergeArgs {
   const float* margin;           // [nq_pad] bound on |float32 score - fp16 score| for any row
   float* tau_filter;             // [nq_pad] threshold of the next filter launch
   unsigned long long* dbg;       // developer build (PROQA_MERGE_STAMPS): [nq_pad, 8] s_memtime stamps of the phases, or NULL
+  int compact;                   // the launch logged compact lists (FilterArgs::compact)
 };
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);

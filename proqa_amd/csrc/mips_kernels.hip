@@ -145,9 +145,16 @@ __device__ __forceinline__ void log_columns(const f32x16& acc, bool hit, float t
 //     At the barrier of stage s (before its unit 2): every wave is past stage s-1, whose buffer
 //     is therefore free for DMA(s+3); and every wave has retired its pieces of DMA(s+1), issued two
 //     stages earlier (counted vmcnt: DMA(s+2) stays in flight), so stage s+1 is readable from unit 3 on.
-template <int QW, int NW, bool INCLUSIVE, bool BOUNDED>
+//
+// COMPACT (the one-pass launch of a large k over thousands of queries, where almost every unit holds a score above its
+// threshold): no column records.  Every accumulator register is tested on its own (one wave-wide branch per register,
+// taken for ~10 % of them at 13 000 survivors per query over 8.8M rows) and a passing score is appended as the 8-byte key the
+// merge sorts -- (score, row) -- to the lane's own list in HBM: 10 x fewer bytes than the 80-byte column that carries one
+// such score, and a list's consecutive 8-byte appends are combined in the XCD's L2 (the open lines of a launch's lists fit).
+template <int QW, int NW, bool INCLUSIVE, bool BOUNDED, bool COMPACT = false>
 __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   static_assert(((QW == 1 || QW == 2) && NW == 8) || (QW == 4 && NW == 4), "8 waves x 32/64 queries or 4 waves x 128 queries");
+  static_assert(!COMPACT || (!INCLUSIVE && !BOUNDED), "compact lists: first page, strict threshold only");
   // the only LDS object of the kernel (a second one makes hipcc drain vmcnt before ds_reads)
   __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytes];
 
@@ -194,6 +201,7 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
     lane_n[blk] = 0u;
     lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
   }
+  const unsigned compact_cap = a.store.lane_cap * kKeysPerRecord;   // COMPACT: 8-byte keys a lane list holds
   const unsigned wave_slot = (chunk * a.store.n_qtiles + qt) * kFilterWaves + wave;
   WaveRecord* spill_log = a.store.spill_log + (size_t)wave_slot * kSpillCap;
   int spill_n = 0;  // wave-uniform
@@ -268,6 +276,25 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   int pend_rel0 = -1;  // no pending unit yet
 
   auto test_and_log = [&](bool valid) {
+    if constexpr (COMPACT) {
+      if (!valid) return;
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk) {
+        unsigned long long* list = (unsigned long long*)lane_list[blk];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool h = pend[blk][r] > tau[blk];
+          if (__any(h)) {   // wave-uniform
+            const int rel = pend_rel0 + 4 * half + (r & 3) + 8 * (r >> 2);
+            if (h && rel < n_rows) {
+              if (lane_n[blk] < compact_cap) list[lane_n[blk]] = pack_key(pend[blk][r], row_begin32 + (unsigned)rel);
+              ++lane_n[blk];   // (counted beyond the capacity: the end of the kernel reports the overflow)
+            }
+          }
+        }
+      }
+      return;
+    }
     bool hit[QW];
     bool any_hit = false;
 #pragma unroll
@@ -366,8 +393,13 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   test_and_log(true);  // drain the last unit
 
 #pragma unroll
-  for (int blk = 0; blk < QW; ++blk)
+  for (int blk = 0; blk < QW; ++blk) {
+    if (COMPACT && lane_n[blk] > compact_cap) {
+      *a.overflow = 1u;
+      lane_n[blk] = compact_cap;
+    }
     a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
+  }
   if (lane == 0) a.store.spill_cnt[spill_cnt_index(a.store, chunk, qt, wave)] = (unsigned)spill_n;
 }
 
@@ -664,6 +696,48 @@ void topk_merge(MergeArgs a) {
 
   if (tid == 0) s_n_keys = 0;
 
+  if (!EXACT && a.compact) {
+    // Compact lists (see mips_filter_f16<COMPACT>): every entry is a key that passed its threshold.  Per sweep of up to
+    // kSweep lists: one thread per list reads its length and reserves the slots (LDS atomic; the order of the keys does
+    // not matter, they are sorted below); then a wave per list copies it, eight lists in flight per wave.
+    unsigned* s_cnt = (unsigned*)s_work;
+    constexpr unsigned kSweep = kWorkCap * sizeof(unsigned short) / (2 * sizeof(unsigned));
+    unsigned* s_off = s_cnt + kSweep;
+    const unsigned ccap = lane_cap * kKeysPerRecord;
+    const int lane = tid & 63, w = tid >> 6;
+    __syncthreads();
+    for (unsigned base = 0; base < n_lists; base += kSweep) {
+      const unsigned n_here = n_lists - base < kSweep ? n_lists - base : kSweep;
+      for (unsigned t = tid; t < n_here; t += T) {
+        const unsigned l = base + t;
+        unsigned c = st.lane_cnt[lane_cnt_index(st, l >> 1, q, (int)(l & 1))];
+        c = c < ccap ? c : ccap;
+        s_cnt[t] = c;
+        s_off[t] = c ? atomicAdd(&s_n_keys, c) : 0u;
+      }
+      __syncthreads();
+      for (unsigned t0 = (unsigned)w * 8; t0 < n_here; t0 += (T / 64) * 8) {
+        unsigned long long v[8][2];
+        unsigned c[8], off[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned t = t0 + e;
+          c[e] = t < n_here ? s_cnt[t] : 0u;
+          off[e] = t < n_here ? s_off[t] : 0u;
+          const unsigned l = base + (t < n_here ? t : 0u);
+          const unsigned long long* list = (const unsigned long long*)(st.lane_log + lane_list_index(st, l >> 1, q, (int)(l & 1)) * lane_cap);
+          v[e][0] = (unsigned)lane < c[e] ? list[lane] : 0ull;
+          v[e][1] = (unsigned)lane + 64 < c[e] ? list[lane + 64] : 0ull;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if ((unsigned)lane < c[e] && off[e] + lane < (unsigned)CAP) keys[off[e] + lane] = v[e][0];
+          if ((unsigned)lane + 64 < c[e] && off[e] + lane + 64 < (unsigned)CAP) keys[off[e] + lane + 64] = v[e][1];
+        }
+      }
+      __syncthreads();
+    }
+  } else
   for (unsigned base = 0; base < n_lists; base += 2 * T) {
     if (tid == 0) s_n_work = 0;
     __syncthreads();
@@ -1552,6 +1626,11 @@ static void launch_filter_bounded(const FilterArgs& a, dim3 g, hipStream_t st) {
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st) {
   dim3 g(grid);
+  if (a.compact) {
+    if (qw != 2 || inclusive || a.ub) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((mips_filter_f16<2, 8, false, false, true>), g, dim3(8 * 64), 0, st, a);
+    return hipGetLastError();
+  }
   if (qw == 4) {
     if (inclusive)
       launch_filter_bounded<4, 4, true>(a, g, st);
