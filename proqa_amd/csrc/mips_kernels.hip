@@ -276,6 +276,7 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   int pend_rel0 = -1;  // no pending unit yet
 
   auto test_and_log = [&](bool valid) {
+    if (a.flags & 8u) return;   // experiment: no threshold test at all (what hiding it completely would give)
     if constexpr (COMPACT) {
       if (!valid) return;
 #pragma unroll
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const bool h = pend[blk][r] > tau[blk];
-          if (__any(h)) {   // wave-uniform
+          if (__builtin_expect(__any(h), 0)) {   // wave-uniform; the common case (no lane passes) must be the fall-through
             const int rel = pend_rel0 + 4 * half + (r & 3) + 8 * (r >> 2);
             if (h && rel < n_rows) {
               if (lane_n[blk] < compact_cap) list[lane_n[blk]] = pack_key(pend[blk][r], row_begin32 + (unsigned)rel);

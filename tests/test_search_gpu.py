@@ -449,11 +449,13 @@ def test_large_k_random_scores(gpu_device):
 
 @pytest.mark.parametrize("n,nq,k", [(300000, 40, 10000), (300000, 3, 5000), (200000, 300, 1500), (400000, 1, 5000),
                                     (250000, 70, 3000), (500000, 9, 11000), (200000, 200, 1000), (100000, 33, 700),
-                                    (300000, 256, 1024)])
+                                    (300000, 256, 1024), (300000, 700, 10000), (150000, 513, 4000)])
 def test_large_k_one_pass_is_exact(gpu_device, n, nq, k):
     """1024 < k <= ~11700 (from ~670 for batches of <= 256 queries) on a shard much larger than k goes through ONE filter launch against thresholds estimated
     from a sample (search_one_pass, mips_index.cpp).  Integer data in [-8, 8]: scores are exact, a score level holds
-    ~100 rows (ties across the k-th place are the rule), and ids must match the oracle bit for bit."""
+    ~100 rows (ties across the k-th place are the rule), and ids must match the oracle bit for bit.  Batches of more than
+    256 queries are dense enough here for the compact lists of 8-byte keys (mips_filter_f16<COMPACT>); the smaller batches
+    log column records."""
     from proqa_amd.index import IndexFlatIP
     rng = np.random.default_rng(n + k)
     xb = _int_corpus(rng, n, lo=-8, hi=8)
@@ -470,15 +472,16 @@ def test_large_k_one_pass_is_exact(gpu_device, n, nq, k):
 
 
 def test_large_k_batches_beyond_the_store_budget_run_in_groups(gpu_device, monkeypatch):
-    """Thousands of queries x a large k would need tens of GB of candidate lists in one launch: the search runs in
-    groups of whole query tiles instead (here: a 1 GB budget, 1300 queries -> groups of 512)."""
+    """Thousands of queries x a large k can need more candidate-list memory in one launch than the budget allows: the
+    search runs in groups of whole query tiles instead (here: a 128 MB budget, 1300 queries at 170 KB of compact lists
+    each -> groups of 512)."""
     from proqa_amd.index import IndexFlatIP
     rng = np.random.default_rng(5)
     xb = _int_corpus(rng, 150000, lo=-8, hi=8)
     xq = _int_corpus(rng, 1300, lo=-8, hi=8)
     index = IndexFlatIP(128)
     index.add(xb)
-    monkeypatch.setenv("PROQA_ONE_PASS_STORE_MB", "1024")
+    monkeypatch.setenv("PROQA_ONE_PASS_STORE_MB", "128")
     D, I = index.search(xq, 5000)
     st = index.last_stats()
     assert st["fallback_rounds"] == 0 and st["rounds"] >= 3 * 5, st
@@ -504,6 +507,16 @@ def test_large_k_one_pass_falls_back_on_an_ordered_corpus(gpu_device):
         np.testing.assert_array_equal(I, Io, err_msg=name)
         np.testing.assert_array_equal(D, Do, err_msg=name)
     assert index.last_stats()["fallback_rounds"] > 0   # descending: the head of the shard holds every good row
+    # the same with a batch that takes the compact lists (more than 256 queries): in the descending order the lane lists of
+    # the head chunks overflow for the first query (70 keys each), the launch reports it, the pages repeat the search
+    xq2 = np.concatenate([xq[:1], _int_corpus(rng, 299, lo=-8, hi=8)])
+    index = IndexFlatIP(128)
+    index.add(xb[order[::-1]])
+    D, I = index.search(xq2, 3000)
+    Do, Io = search_oracle.topk_ip(xq2, xb[order[::-1]], 3000)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert index.last_stats()["fallback_rounds"] > 0
 
 
 def test_randomised_shapes_against_oracle(gpu_device):
