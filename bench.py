@@ -691,7 +691,11 @@ def kmeans_leg(args, device, xb):
            "objective": km.obj[-1],
            "roofline": {"bound": "mfma", "kernel": "kmeans_assign", "achieved": tf, "peak": PEAK_MFMA_F16_TFLOPS,
                         "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_F16_TFLOPS, "assign_ms": assign_s * 1e3,
-                        "note": "2 n k 272 flop per iteration / HIP-event time of the assign launch (mean of the timed iterations)"}}
+                        "achieved_algorithmic": 2.0 * n * k * 128 / assign_s / 1e12,
+                        "frac_algorithmic": 2.0 * n * k * 128 / assign_s / 1e12 / PEAK_MFMA_F16_TFLOPS,
+                        "note": "frac counts the flops EXECUTED, 2 n k 272 per iteration (the fp32 centroids enter as hi + lo fp16 "
+                                "halves, plus the norm step); frac_algorithmic the 2 n k 128 of the reference's fp32 search; both over the "
+                                "HIP-event time of the assign launch (mean of the timed iterations)"}}
     if not args.skip_cpu:
         from oracle import kmeans_oracle
         ns = min(20_000, n)
@@ -848,7 +852,7 @@ def main():
                    "scores_sha256": hashlib.sha256(Dm.cpu().numpy().tobytes()).hexdigest()},
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_MFMA_F16_TFLOPS, "traffic": pmc_traffic((hi - lo) / n),
-                     "traffic_measured_on_commit": pmc_traffic_commit(),
+                     "traffic_measured_on_commit": pmc_traffic_commit(), "traffic_age_commits": pmc_traffic_age(),
                      "kernel": "mips_filter_f16", "filter_ms_per_search": st["filter_ms"],
                      "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / PEAK_HBM_GBS},
     }
@@ -996,6 +1000,21 @@ def pmc_traffic(shard_fraction):
     try:
         with open(path) as f:
             return json.load(f).get("hbm_bytes_per_search") * shard_fraction
+    except Exception:
+        return None
+
+
+def pmc_traffic_age():
+    """Commits that touched csrc/mips_kernels.hip since the commit profiles/pmc_traffic.json was measured on (None if git
+    cannot tell): a non-zero value says the `traffic` reading predates the kernel that ran."""
+    import subprocess
+    c = pmc_traffic_commit()
+    if not c:
+        return None
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "rev-list", "--count", f"{c}..HEAD", "--", "proqa_amd/csrc/mips_kernels.hip"],
+                             capture_output=True, text=True, timeout=10)
+        return int(out.stdout.strip()) if out.returncode == 0 and out.stdout.strip() else None
     except Exception:
         return None
 
