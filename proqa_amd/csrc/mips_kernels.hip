@@ -276,7 +276,6 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   int pend_rel0 = -1;  // no pending unit yet
 
   auto test_and_log = [&](bool valid) {
-    if (a.flags & 8u) return;   // experiment: no threshold test at all (what hiding it completely would give)
     if constexpr (COMPACT) {
       if (!valid) return;
 #pragma unroll
