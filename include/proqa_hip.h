@@ -154,9 +154,11 @@ int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
  * (the layout an RCCL all-gather of per-rank [nq, k] produces); every list as a search reports it (scores descending,
  * ties by ascending id, the I = -1 slots of a short shard at its tail), parts in ascending order of their row ranges.
- * Same ordering rule.  Up to 4096 gathered keys per query (8 shards x top-80) are merged by rank without a sort; up to
- * 16384 gathered keys per query are sorted in LDS; larger merges (k = 10000 x 8 shards) run as a
- * segmented radix sort in HBM (temporary buffers are allocated for the call). */
+ * Same ordering rule.  These two entry points SORT what they are given (no assumption about the order inside a part: a
+ * caller's own local search may have produced it): up to 16384 gathered keys per query in LDS, larger merges (k = 10000 x
+ * 8 shards) as a segmented radix sort in HBM (temporary buffers are allocated for the call).  The sharded search's own
+ * merge (proqa_topk_merge_gathered_device, below) knows its parts are search results and merges up to 4096 keys per query
+ * (8 shards x top-80) by rank, without a sort. */
 int proqa_topk_merge_device(const float* D_parts_dev, const int64_t* I_parts_dev, int n_parts,
                             int64_t nq, int k, float* D_dev, int64_t* I_dev, void* stream);
 /* The same merge over parts that are not back to back: part p's [nq, k] scores / ids start stride_d / stride_i ELEMENTS

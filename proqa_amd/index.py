@@ -209,7 +209,8 @@ def _is_torch(x):
 
 
 def merge_topk_device(D_parts, I_parts):
-    """Merge [n_parts, nq, k] per-shard lists (ascending shard order) into [nq, k] on the GPU."""
+    """Merge [n_parts, nq, k] per-shard lists (ascending shard order) into [nq, k] on the GPU.  The parts need not be
+    sorted inside (this entry point sorts); slots with I = -1 are missing rows wherever they sit."""
     import torch
     lib = _lib.load()
     D_parts = D_parts.contiguous()
