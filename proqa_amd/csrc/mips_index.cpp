@@ -1340,6 +1340,9 @@ int proqa_index_add_npy(proqa_index* idx, const char* path, int64_t row0, int64_
   if (ring.fd < 0) return fail(PROQA_EIO, "index_add_npy: cannot open %s: %s", path, strerror(errno));
   const off_t base = (off_t)info.data_offset + (off_t)row0 * (off_t)row_bytes;
   (void)posix_fadvise(ring.fd, base, (off_t)n * (off_t)row_bytes, POSIX_FADV_SEQUENTIAL);
+  // a file that is not in the page cache: ask the kernel for the whole range now (asynchronous read-ahead at the device's
+  // queue depth) -- the four readers' interleaved 8 MiB pieces do not look sequential to the per-descriptor read-ahead
+  (void)posix_fadvise(ring.fd, base, (off_t)n * (off_t)row_bytes, POSIX_FADV_WILLNEED);
   PROQA_HIP(hipHostMalloc((void**)&ring.pinned, piece_bytes * n_slots, hipHostMallocDefault));
   for (int s = 0; s < n_slots; ++s) PROQA_HIP(hipEventCreateWithFlags(&ring.uploaded[s], hipEventDisableTiming));
   ring.n_slots = n_slots;
