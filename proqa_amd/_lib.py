@@ -158,8 +158,12 @@ def _promote_hip_runtime():
     """
     dirs = []
     try:
-        import torch  # noqa: F401  (loads its libamdhip64.so / librocblas.so)
-        dirs.append(os.path.join(os.path.dirname(torch.__file__), "lib"))
+        # torch's bundled runtime, located WITHOUT importing torch (1-2 s the eval_retrieval.py command line does not need);
+        # if torch is imported later in the process it finds the same libraries already loaded
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            dirs.append(os.path.join(list(spec.submodule_search_locations)[0], "lib"))
     except Exception:
         pass
     dirs += ["", "/opt/rocm/lib"]

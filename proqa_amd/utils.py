@@ -6,11 +6,11 @@ move_to_cuda (:5-22), normalize (:63-65) and DocDB (:68-105).
 import sqlite3
 import unicodedata
 
-import torch
-
 
 def move_to_cuda(sample, device=None):
     """Recursively move tensors in dicts/lists to the GPU (reference: unconditional .cuda())."""
+    import torch   # (not at module level: the eval_retrieval.py command line needs DocDB / normalize only, and runs
+    #                without PyTorch in the process -- a second of start-up and a lighter fork for its scorer pool)
     if len(sample) == 0:
         return {}
     if torch.is_tensor(sample):
@@ -23,6 +23,7 @@ def move_to_cuda(sample, device=None):
 
 
 def _container_or_tensor(v):
+    import torch
     return torch.is_tensor(v) or isinstance(v, (dict, list))
 
 

@@ -1,7 +1,7 @@
 # Final round-end collection on the GPU box: profiles (rocprofv3 passes), default bench line, single-rank RCCL runs,
 # the self-launched two-rank run (gloo: both ranks share the one GPU of the box).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r03}
+R=${1:-r04}
 bash scripts/collect_profiles.sh ${R}_prof
 O=gpurun_out/${R}_final; mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
