@@ -150,6 +150,9 @@ def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
 
 def finish_distributed():
     """After the sharded search: ranks leave the process group together (rank 0 goes on to score alone)."""
+    import sys
+    if dist_env()[0] == 1 and "torch.distributed" not in sys.modules:
+        return               # a plain single-process run never imported PyTorch: nothing to leave
     try:
         import torch.distributed as dist
     except ImportError:
