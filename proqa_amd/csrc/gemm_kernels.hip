@@ -99,7 +99,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 template <int EPI, int DBG = 0>   // DBG (timing experiments, wrong results): bit 0 = no fragment reads after the first step, bit 1 = no DMA after the prologue, bit 2 = no epilogue, bit 3 = every DMA from the same 64 KiB
 __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                              const _Float16* __restrict__ bias, _Float16* __restrict__ Y,
-                                                             int M, int N, int K, int kGroup) {
+                                                             int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) char lds[2 * 2 * kOpBytes + kWaves * 4096];
 
   const int tid = threadIdx.x;
@@ -193,6 +193,8 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
     }
   };
 
+  // (groups of 3, 4, 9 or 12 feature tiles measure the same on all four encoder shapes)
+  constexpr int kGroup = 8;
   auto tile_bases = [&](int t, const char*& wbase, const char*& xbase, int& m0, int& n0) {
     const unsigned per_full_group = (unsigned)my_slabs * kGroup;
     const int grp = (int)((unsigned)t / per_full_group);
@@ -409,12 +411,10 @@ int proqa_gemm_tn_f16(const void* x, const void* w, const void* bias, void* y, i
   const unsigned grid = (unsigned)std::min<long long>(tiles, device_cu_count());
   hipStream_t st = as_stream(stream);
   const dim3 g(grid), b(kWaves * 64);
-  static const int kGroupEnv = getenv("PROQA_GEMM_GROUP") ? atoi(getenv("PROQA_GEMM_GROUP")) : 0;   // developer experiment
-  const int group = kGroupEnv > 0 ? kGroupEnv : 8;
   // developer switch: cut experiments on the main loop (wrong results by design; scripts/dev_gemm_ablate.py)
   static const int kDbg = getenv("PROQA_GEMM_DBG") ? atoi(getenv("PROQA_GEMM_DBG")) : 0;
   if (kDbg) {
-#define PP_DBG_CASE(D) case D: hipLaunchKernelGGL((gemm_tn_f16<EPI_NONE, D>), g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)y, (int)m, n, k, group); break;
+#define PP_DBG_CASE(D) case D: hipLaunchKernelGGL((gemm_tn_f16<EPI_NONE, D>), g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias, (_Float16*)y, (int)m, n, k); break;
     switch (kDbg) { PP_DBG_CASE(4) PP_DBG_CASE(5) PP_DBG_CASE(6) PP_DBG_CASE(7) PP_DBG_CASE(12) default: return fail(PROQA_EINVAL, "gemm_tn: PROQA_GEMM_DBG=%d is not built", kDbg); }
 #undef PP_DBG_CASE
     PROQA_LAUNCH_CHECK();
@@ -423,15 +423,15 @@ int proqa_gemm_tn_f16(const void* x, const void* w, const void* bias, void* y, i
   switch (epilogue) {
     case EPI_NONE:
       hipLaunchKernelGGL(gemm_tn_f16<EPI_NONE>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
-                         (_Float16*)y, (int)m, n, k, group);
+                         (_Float16*)y, (int)m, n, k);
       break;
     case EPI_BIAS:
       hipLaunchKernelGGL(gemm_tn_f16<EPI_BIAS>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
-                         (_Float16*)y, (int)m, n, k, group);
+                         (_Float16*)y, (int)m, n, k);
       break;
     default:
       hipLaunchKernelGGL(gemm_tn_f16<EPI_BIAS_GELU>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w,
-                         (const _Float16*)bias, (_Float16*)y, (int)m, n, k, group);
+                         (const _Float16*)bias, (_Float16*)y, (int)m, n, k);
   }
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
