@@ -90,10 +90,12 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // loads.  Per K-step a wave runs 4 phases (quadrants (A0,B0) (A0,B1) (A1,B1) (A1,B0)); its LOAD intervals read 8 / 4 / 8 / 4
 // fragments (A0 | B1 | A1 | B0 of the NEXT step).
 //   Ring discipline (two 64 KiB K-step buffers, prefetch distance TWO steps): a buffer is refilled region by region as
-// soon as BOTH groups have read that region -- A0 rows of step t+2 are requested in phase 1 of step t, the B rows in
-// phase 2, the A1 rows in phase 3 -- so a DMA has 8+ intervals (~2000 cycles) to land.  A wave waits for its DMAs of step
-// t+1 with a COUNTED vmcnt in phase 2 of step t (never 0 in the loop; the epilogue's stores are counted too), the reads
-// of that data start in phase 3, one barrier later for X and two for Y.  Barriers are raw s_barrier (no vmcnt drain).
+// soon as BOTH groups have read that region -- of step t+2, the B0 rows (the first 32 of every 64-row token quarter; their
+// last reader was phase 3 of step t-1) are requested in phase 0 of step t, the A0 rows in phase 1, the B1 rows in phase 2,
+// the A1 rows in phase 3: two 1 KiB pieces per wave and LOAD interval -- so a DMA has 8+ intervals (~2000 cycles) to land.
+// A wave waits for its DMAs of step t+1 with a COUNTED vmcnt in phase 2 of step t (vmcnt(4): the four pieces of step t+2
+// issued in phases 0 and 1 stay in flight; never 0 in the loop; the 16 stores of an epilogue are counted too), the reads of
+// that data start in phase 3, one barrier later for X and two for Y.  Barriers are raw s_barrier (no vmcnt drain).
 //   At the end of an output tile X takes one extra barrier (the groups fall in step), both run the epilogue at the same
 // time, then Y takes one extra barrier (anti-phase again).
 template <int EPI, int DBG = 0>   // DBG (timing experiments, wrong results): bit 0 = no fragment reads after the first step, bit 1 = no DMA after the prologue, bit 2 = no epilogue, bit 3 = every DMA from the same 64 KiB
