@@ -282,13 +282,20 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
       for (int blk = 0; blk < QW; ++blk) {
         unsigned long long* list = (unsigned long long*)lane_list[blk];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool h = pend[blk][r] > tau[blk];
-          if (__builtin_expect(__any(h), 0)) {   // wave-uniform; the common case (no lane passes) must be the fall-through
-            const int rel = pend_rel0 + 4 * half + (r & 3) + 8 * (r >> 2);
-            if (h && rel < n_rows) {
-              if (lane_n[blk] < compact_cap) list[lane_n[blk]] = pack_key(pend[blk][r], row_begin32 + (unsigned)rel);
-              ++lane_n[blk];   // (counted beyond the capacity: the end of the kernel reports the overflow)
+        for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 behind ONE pre-test of their maximum (a third of the quads pass it)
+          const float m4 = max2_f32(max3_f32(pend[blk][4 * g], pend[blk][4 * g + 1], pend[blk][4 * g + 2]), pend[blk][4 * g + 3]);
+          if (__builtin_expect(__any(m4 > tau[blk]), 0)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e;
+              const bool h = pend[blk][r] > tau[blk];
+              if (__builtin_expect(__any(h), 0)) {   // wave-uniform; the common case (no lane passes) must be the fall-through
+                const int rel = pend_rel0 + 4 * half + (r & 3) + 8 * (r >> 2);
+                if (h && rel < n_rows) {
+                  if (lane_n[blk] < compact_cap) list[lane_n[blk]] = pack_key(pend[blk][r], row_begin32 + (unsigned)rel);
+                  ++lane_n[blk];   // (counted beyond the capacity: the end of the kernel reports the overflow)
+                }
+              }
             }
           }
         }
