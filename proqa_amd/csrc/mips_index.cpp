@@ -955,6 +955,16 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
 int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
                   float* D_dev, int64_t* I_dev, hipStream_t st, bool defer = false, uint32_t* status_dev = nullptr) {
   const int rc = search_device_impl(idx, xq_dev, nq, dtype, k, idx_offset, D_dev, I_dev, st, defer, status_dev);
+#ifdef PROQA_FILTER_STAMPS
+  {
+    unsigned long long h[5];
+    read_filter_stamps(h);
+    if (h[4])
+      fprintf(stderr, "filter stamps (one wave per workgroup, %llu workgroups over all launches of the search): per unit MFMA section %.1f "
+              "ticks, test section %.1f ticks; units per wave %.0f, wave lifetime per unit %.1f ticks\n", h[4], (double)h[0] / h[2],
+              (double)h[1] / h[2], (double)h[2] / h[4], (double)h[3] / h[2]);
+  }
+#endif
   // a search that ran to completion has a final result: its status word is 0 (the deferred kind writes the word itself)
   if (rc == PROQA_OK && status_dev && !idx->pending.active) PROQA_HIP(hipMemsetAsync(status_dev, 0, sizeof(uint32_t), st));
   return rc;

@@ -110,6 +110,9 @@ struct MergeArgs {
 };
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);
+#ifdef PROQA_FILTER_STAMPS
+void read_filter_stamps(unsigned long long* out5);   // developer build: sums of the s_memtime stamps, then reset
+#endif
 // margin/ub_filter: exact-float32 mode (NULL otherwise): ub_filter[q] = ub[q] + margin[q]
 hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                                unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,

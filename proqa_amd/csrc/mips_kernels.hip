@@ -87,6 +87,9 @@ __device__ __forceinline__ size_t spill_cnt_index(const CandidateStore& st, unsi
 // ---------------------------------------------------------------------------------------
 // filter kernel
 // ---------------------------------------------------------------------------------------
+#ifdef PROQA_FILTER_STAMPS
+__device__ unsigned long long g_filter_stamps[8];   // developer build: see the end of mips_filter_f16
+#endif
 __device__ __forceinline__ void write_record(WaveRecord* dst, const f32x16& acc, unsigned q, unsigned row0,
                                              int rows_left, float tau) {
   uint4* d = (uint4*)dst;
@@ -354,6 +357,10 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
     return;
   }
 
+#ifdef PROQA_FILTER_STAMPS
+  unsigned long long stamp_mfma = 0, stamp_test = 0, stamp_units = 0;
+  const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int s = 0; s < nstages; ++s) {
 #pragma unroll
     for (int u = 0; u < kSubs; ++u) {
@@ -365,6 +372,9 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
       const char* nxt = (u + 1 < kSubs) ? lds + off0 + (u + 1) * kSubBytes : lds + off1;
 
       f32x16 cur[QW];
+#ifdef PROQA_FILTER_STAMPS
+      const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
       for (int blk = 0; blk < QW; ++blk) cur[blk] = f32x16{0};
 #pragma unroll
@@ -384,8 +394,20 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 #pragma unroll
       for (int j = 4; j < 8; ++j) af[j] = *(const f16x8*)(nxt + rd_off[j]);
 
+#ifdef PROQA_FILTER_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       // lane-local test of the PREVIOUS unit, scheduled under the MFMAs just issued
       test_and_log(pend_rel0 >= 0);
+#ifdef PROQA_FILTER_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+      stamp_mfma += st1 - st0;
+      stamp_test += st2 - st1;
+      ++stamp_units;
+#endif
 
 #pragma unroll
       for (int blk = 0; blk < QW; ++blk) pend[blk] = cur[blk];
@@ -398,6 +420,16 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
     off3 = t;
   }
   test_and_log(true);  // drain the last unit
+#ifdef PROQA_FILTER_STAMPS
+  if (lane == 0 && wave == 3) {   // one wave per workgroup reports: sums over its units (s_memtime ticks)
+    unsigned long long* dbg = g_filter_stamps;
+    atomicAdd(dbg + 0, stamp_mfma);
+    atomicAdd(dbg + 1, stamp_test);
+    atomicAdd(dbg + 2, stamp_units);
+    atomicAdd(dbg + 3, __builtin_amdgcn_s_memtime() - stamp_t0);
+    atomicAdd(dbg + 4, 1ull);
+  }
+#endif
 
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk) {
@@ -1656,6 +1688,15 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
   }
   return hipGetLastError();
 }
+
+#ifdef PROQA_FILTER_STAMPS
+void read_filter_stamps(unsigned long long* out5) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_filter_stamps), 5 * sizeof(unsigned long long));
+  unsigned long long z[8] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_stamps), z, sizeof z);
+}
+#endif
 
 hipError_t launch_advance_page(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                                unsigned long long* bound_keys, float* ub, unsigned char* done, const float* margin,
