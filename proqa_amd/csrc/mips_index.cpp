@@ -790,7 +790,7 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool la
     // chunks are whole stages: a shard of few stages per chunk may end up with fewer chunks than asked for
     const long long rpc = round_up<long long>(ceil_div<long long>(idx->n, p.want_chunks), kStageRows);
     const long long chunks = ceil_div<long long>(idx->n, rpc);
-    if (expected / (2.0 * chunks) > 1.5 * per_list) return p;  // the lists would spill: pages
+    if (expected / (2.0 * chunks) > 1.5 * per_list) return p;  // the lists would spill (24 / 64 keys per list): pages
   }
   // queries one launch can take within the store budget (whole query tiles)
   const size_t per_query = (size_t)(p.want_chunks + 8) * 2 * p.lane_cap * sizeof(WaveRecord);

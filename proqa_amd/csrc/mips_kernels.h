@@ -69,7 +69,9 @@ struct CandidateStore {
 
 constexpr int kKeysPerRecord = 10;  // compact lists: 8-byte keys in the room of one WaveRecord
 static_assert(kKeysPerRecord * 8 == 80, "compact list addressing");
-constexpr int kCompactLaneCap = 7;  // records' worth per lane list of a compact launch: 70 keys (the chunk count aims at ~24)
+constexpr int kCompactLaneCap = 7;  // records' worth per lane list of a compact launch: room for 70 keys (the chunk count aims at ~24)
+constexpr unsigned kCompactKeys = 64;  // keys a compact list holds: a power of two, so that the append position is n & 63 without a capacity branch
+static_assert(kCompactKeys <= kCompactLaneCap * kKeysPerRecord, "compact list size");
 
 struct FilterArgs {
   const void* xq;        // fp16 [nq_pad,128], zero rows beyond nq

@@ -26,6 +26,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "mips_kernels.h"
 
@@ -62,6 +64,29 @@ __device__ __forceinline__ unsigned long long pack_key(float score, unsigned row
 __device__ __forceinline__ float max3_f32(float a, float b, float c) {
   float r;
   asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// max of four / sixteen floats as ONE asm statement each: between separate asm statements hipcc puts an `s_nop` (it does not
+// know the instruction behind the string), which costs an issue slot per instruction of the threshold test
+__device__ __forceinline__ float max4_f32(float a, float b, float c, float d) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+  return r;
+}
+__device__ __forceinline__ float max16_f32(const float (&v)[16]) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3\n\t"
+      "v_max3_f32 %0, %0, %4, %5\n\t"
+      "v_max3_f32 %0, %0, %6, %7\n\t"
+      "v_max3_f32 %0, %0, %8, %9\n\t"
+      "v_max3_f32 %0, %0, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %12, %13\n\t"
+      "v_max3_f32 %0, %0, %14, %15\n\t"
+      "v_max_f32 %0, %0, %16"
+      : "=&v"(r)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]), "v"(v[10]),
+        "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
   return r;
 }
 
@@ -204,7 +229,6 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
     lane_n[blk] = 0u;
     lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
   }
-  const unsigned compact_cap = a.store.lane_cap * kKeysPerRecord;   // COMPACT: 8-byte keys a lane list holds
   const unsigned wave_slot = (chunk * a.store.n_qtiles + qt) * kFilterWaves + wave;
   WaveRecord* spill_log = a.store.spill_log + (size_t)wave_slot * kSpillCap;
   int spill_n = 0;  // wave-uniform
@@ -278,31 +302,43 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
   for (int blk = 0; blk < QW; ++blk) pend[blk] = f32x16{0};
   int pend_rel0 = -1;  // no pending unit yet
 
-  auto test_and_log = [&](bool valid) {
-    if constexpr (COMPACT) {
-      if (!valid) return;
+  // COMPACT: one hit = one 8-byte key appended at position n & 63 of the lane's list -- no capacity branch (a list that
+  // wraps is reported at the end of the kernel by its count), no row check outside the chunk's last stage: the body of a hit
+  // is ONE exec-masked region (a hit's price is its chain of dependent scalar branches, ABLATIONS R4.3)
+  auto compact_test = [&](auto check_rows) {
+    constexpr bool kCheckRows = decltype(check_rows)::value;
 #pragma unroll
-      for (int blk = 0; blk < QW; ++blk) {
-        unsigned long long* list = (unsigned long long*)lane_list[blk];
+    for (int blk = 0; blk < QW; ++blk) {
+      unsigned long long* list = (unsigned long long*)lane_list[blk];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 behind ONE pre-test of their maximum (a third of the quads pass it)
-          const float m4 = max2_f32(max3_f32(pend[blk][4 * g], pend[blk][4 * g + 1], pend[blk][4 * g + 2]), pend[blk][4 * g + 3]);
-          if (__builtin_expect(__any(m4 > tau[blk]), 0)) {
+      for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 behind ONE pre-test of their maximum (a third of the quads pass it)
+        const float m4 = max4_f32(pend[blk][4 * g], pend[blk][4 * g + 1], pend[blk][4 * g + 2], pend[blk][4 * g + 3]);
+        if (__builtin_expect(__any(m4 > tau[blk]), 0)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int r = 4 * g + e;
-              const bool h = pend[blk][r] > tau[blk];
-              if (__builtin_expect(__any(h), 0)) {   // wave-uniform; the common case (no lane passes) must be the fall-through
-                const int rel = pend_rel0 + 4 * half + (r & 3) + 8 * (r >> 2);
-                if (h && rel < n_rows) {
-                  if (lane_n[blk] < compact_cap) list[lane_n[blk]] = pack_key(pend[blk][r], row_begin32 + (unsigned)rel);
-                  ++lane_n[blk];   // (counted beyond the capacity: the end of the kernel reports the overflow)
-                }
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const int rel = pend_rel0 + 4 * half + (r & 3) + 8 * (r >> 2);
+            const bool h = pend[blk][r] > tau[blk] && (!kCheckRows || rel < n_rows);
+            if (__builtin_expect(__any(h), 0)) {   // wave-uniform; the common case (no lane passes) must be the fall-through
+              if (h) {
+                list[lane_n[blk] & (kCompactKeys - 1)] = pack_key(pend[blk][r], row_begin32 + (unsigned)rel);
+                ++lane_n[blk];
               }
             }
           }
         }
       }
+    }
+  };
+  auto test_and_log = [&](bool valid) {
+    if constexpr (COMPACT) {
+      if (!valid) return;
+      // rows past the end of the chunk (they re-read its last row) exist in the chunk's LAST stage only: the per-score
+      // row check is compiled into a second copy of the test that only that stage's units take
+      if (pend_rel0 >= (nstages - 1) * kStageRows)
+        compact_test(std::true_type());
+      else
+        compact_test(std::false_type());
       return;
     }
     bool hit[QW];
@@ -315,11 +351,10 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
       }
       // v_max3_f32 by hand: fmaxf() makes hipcc quiet possible NaNs of the MFMA results first (two more VALU ops per
       // block and unit); a NaN score cannot beat a threshold either way
-      float m = max3_f32(pend[blk][0], pend[blk][1], pend[blk][2]);
-      m = max3_f32(m, pend[blk][3], pend[blk][4]);
+      float sc16[16];
 #pragma unroll
-      for (int r = 5; r < 15; r += 2) m = max3_f32(m, pend[blk][r], pend[blk][r + 1]);
-      m = max2_f32(m, pend[blk][15]);
+      for (int r = 0; r < 16; ++r) sc16[r] = pend[blk][r];
+      const float m = max16_f32(sc16);
       hit[blk] = INCLUSIVE ? (m >= tau[blk]) : (m > tau[blk]);
       any_hit = any_hit || hit[blk];
     }
@@ -433,9 +468,9 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk) {
-    if (COMPACT && lane_n[blk] > compact_cap) {
+    if (COMPACT && lane_n[blk] > kCompactKeys) {   // the list wrapped: the launch is void (the caller searches page by page)
       *a.overflow = 1u;
-      lane_n[blk] = compact_cap;
+      lane_n[blk] = kCompactKeys;
     }
     a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
   }
@@ -742,7 +777,7 @@ void topk_merge(MergeArgs a) {
     unsigned* s_cnt = (unsigned*)s_work;
     constexpr unsigned kSweep = kWorkCap * sizeof(unsigned short) / (2 * sizeof(unsigned));
     unsigned* s_off = s_cnt + kSweep;
-    const unsigned ccap = lane_cap * kKeysPerRecord;
+    const unsigned ccap = kCompactKeys;
     const int lane = tid & 63, w = tid >> 6;
     __syncthreads();
     for (unsigned base = 0; base < n_lists; base += kSweep) {
