@@ -89,3 +89,16 @@ def test_sidecar_map_equals_json_route(gold, tmp_path):
         ev.convert_idx2id(np.array([[n]]), str(tmp_path / "idx_id.ids"))
     with pytest.raises(KeyError):
         ev.convert_idx2id(np.array([[n]]), str(out))
+
+
+def test_eval_retrieval_command_line_does_not_import_pytorch():
+    """The single-process eval_retrieval.py path needs numpy, sqlite and the C library only: importing PyTorch costs a second
+    or two of a ~2 s command and makes the scorer pool's fork heavier.  (The row-sharded path under torchrun imports it.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import proqa_amd.eval_retrieval as e, proqa_amd._lib as l; l.load(); "
+            "e.finish_distributed(); assert 'torch' not in sys.modules, 'torch was imported'" % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-1500:]
