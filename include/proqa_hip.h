@@ -207,6 +207,18 @@ int proqa_encoder_free(proqa_encoder* enc);
  * it on the real operands (~0.3 s per shape) and keeps the winner if an interleaved re-match confirms >= 2 %;
  * same arithmetic (fp16 in, fp32 accumulate), possibly another summation order. */
 int proqa_encoder_set_gemm_tuning(proqa_encoder* enc, int enable);
+/* Which library kernel runs the large dense layers (QKV, attention output, FFN2; FFN1 is proqa_gemm_tn_f16).  hipBLASLt's
+ * own choice for these shapes is 3-20 % slower than the best kernel it holds, so the encoder calls hipBLASLt itself with an
+ * algorithm chosen BY KERNEL NAME from a fixed preference list (csrc/lt_gemm.cpp) -- deterministic, no timing at run time;
+ * with a library build that does not know the names, or without hipBLASLt in the process, the layers run on
+ * rocblas_gemm_ex.  name_out receives the pinned kernel's name ("" = rocblas_gemm_ex: no name matched, or no large product
+ * has run yet on this handle), truncated to name_len - 1 characters. */
+int proqa_encoder_gemm_kernel(const proqa_encoder* enc, char* name_out, size_t name_len);
+/* The library dense layer of this handle on its own (tests): out[m, n] = x[m, k] . w[n, k]^T, fp16 row-major device
+ * pointers, fp32 accumulate -- the pinned hipBLASLt kernel where it applies, else rocblas_gemm_ex (small_dense_mfma for
+ * <= 256 rows).  Asynchronous on `stream`. */
+int proqa_encoder_dense(proqa_encoder* enc, const void* x_dev, const void* w_dev, void* out_dev, int64_t m, int n, int k,
+                        void* stream);
 /* ids_dev: [batch, seq_len] int64, right-padded (retrieval/datasets.py:29-45); seq_lens_dev: [batch]
  * int32 valid lengths (>= 1); n_valid_tokens: their sum if the host knows it, else -1 (then the
  * padded layout is evaluated whatever the flags say); out: [batch, 128] of out_dtype.

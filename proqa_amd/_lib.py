@@ -95,6 +95,8 @@ SIGNATURES = {
     "proqa_encoder_create": (c_int, [ctypes.POINTER(BertWeights), ctypes.POINTER(c_void_p)]),
     "proqa_encoder_free": (c_int, [c_void_p]),
     "proqa_encoder_set_gemm_tuning": (c_int, [c_void_p, c_int]),
+    "proqa_encoder_gemm_kernel": (c_int, [c_void_p, c_char_p, c_size_t]),
+    "proqa_encoder_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "proqa_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p]),
     "proqa_embed_layernorm_f16": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int64,

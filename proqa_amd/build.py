@@ -25,6 +25,7 @@ SOURCES = [
     "encoder_kernels.hip",
     "gemm_kernels.hip",
     "attention_kernel.hip",
+    "lt_gemm.cpp",
     "encoder.cpp",
     "kmeans_kernels.hip",
     "microbench.hip",

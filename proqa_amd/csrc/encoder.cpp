@@ -7,6 +7,7 @@
 #include <rocblas/rocblas.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <new>
@@ -16,6 +17,7 @@
 
 #include "attention.h"
 #include "common.h"
+#include "lt_gemm.h"
 
 using namespace proqa;
 
@@ -53,6 +55,7 @@ struct proqa_encoder {
   proqa_bert_weights w;
   std::vector<proqa_bert_layer> layers;
   rocblas_handle blas = nullptr;
+  LtGemm* lt = nullptr;   // large products on a hipBLASLt kernel pinned by name (lt_gemm.cpp); nullptr: rocblas_gemm_ex for everything
   Workspace ws;
   int device = 0;
   // opt-in GEMM solution tuning (proqa_encoder_set_gemm_tuning): shape -> rocBLAS solution index (0 = default)
@@ -151,6 +154,10 @@ inline bool small_dense_ok(int64_t M, int N, int K) { return M <= kSmallDenseRow
 int gemm_tn(proqa_encoder* e, const _Float16* x, const void* w, _Float16* out, int64_t M, int N, int K, hipStream_t st) {
   if (M == 0) return PROQA_OK;
   if (small_dense_ok(M, N, K)) return launch_small_dense(x, (int)M, w, nullptr, N, K, 0, out, st);
+  if (e->lt && M >= 4096) {   // (the pinned kernel is a 256 x 256 macro-tile scheme: large token counts only)
+    const int r = lt_gemm_tn(e->lt, x, w, out, M, N, K, st);
+    if (r <= 0) return r;     // launched, or failed; 1 = this library / shape has no pinned kernel: rocBLAS below
+  }
   int solution = 0;
   if (e->tune && M >= 4096) {
     const auto key = std::make_tuple(M, N, K);
@@ -233,6 +240,8 @@ int proqa_encoder_create(const proqa_bert_weights* w, proqa_encoder** out) {
     delete e;
     return blas_fail(s, "rocblas_create_handle");
   }
+  // the large library products on a hipBLASLt kernel pinned by name (lt_gemm.cpp); PROQA_LT_GEMM=0: rocblas_gemm_ex as in rounds 1-3
+  if (!(getenv("PROQA_LT_GEMM") && atoi(getenv("PROQA_LT_GEMM")) == 0)) e->lt = lt_gemm_create();
   *out = e;
   return PROQA_OK;
 }
@@ -243,10 +252,25 @@ int proqa_encoder_set_gemm_tuning(proqa_encoder* e, int enable) {
   return PROQA_OK;
 }
 
+int proqa_encoder_gemm_kernel(const proqa_encoder* e, char* name_out, size_t name_len) {
+  if (!e || !name_out || name_len == 0) return fail(PROQA_EINVAL, "encoder_gemm_kernel: bad argument");
+  snprintf(name_out, name_len, "%s", lt_gemm_kernel_name(e->lt));
+  return PROQA_OK;
+}
+
+int proqa_encoder_dense(proqa_encoder* e, const void* x, const void* w, void* out, int64_t m, int n, int k, void* stream) {
+  if (!e || !x || !w || !out || m < 0 || n <= 0 || k <= 0) return fail(PROQA_EINVAL, "encoder_dense: bad argument");
+  PROQA_ON_DEVICE(e->device);
+  hipStream_t st = as_stream(stream);
+  PROQA_BLAS(rocblas_set_stream(e->blas, st));
+  return gemm_tn(e, (const _Float16*)x, w, (_Float16*)out, m, n, k, st);
+}
+
 int proqa_encoder_free(proqa_encoder* e) {
   if (!e) return PROQA_OK;
   if (e->ws.base) (void)hipFree(e->ws.base);
   if (e->blas) (void)rocblas_destroy_handle(e->blas);
+  lt_gemm_destroy(e->lt);
   delete e;
   return PROQA_OK;
 }

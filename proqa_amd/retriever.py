@@ -175,6 +175,16 @@ class BertForRetriever:
             _lib.check(self._lib.proqa_encoder_set_gemm_tuning(tw._handle, 1 if enable else 0))
         return self
 
+    def gemm_kernels(self):
+        """{tower: name of the hipBLASLt kernel pinned for its large dense layers, "" = rocblas_gemm_ex} (proqa_encoder_gemm_kernel)."""
+        import ctypes
+        out = {}
+        for key, tw in self.towers.items():
+            buf = ctypes.create_string_buffer(640)
+            _lib.check(self._lib.proqa_encoder_gemm_kernel(tw._handle, buf, len(buf)))
+            out[key] = buf.value.decode()
+        return out
+
     def to(self, device):
         device = torch.device(device)
         if device.type != "cuda":

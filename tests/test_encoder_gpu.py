@@ -570,6 +570,56 @@ def test_hand_written_dense_layer_is_race_free_under_load(gpu_device):
         assert bool(((y[rows].float() - want).abs() <= 2.0 ** -10 * want.abs() + 2e-3).all())
 
 
+def test_pinned_library_kernel_equals_the_rocblas_path(gpu_device, monkeypatch):
+    """The large dense layers on the hipBLASLt kernel pinned by name (csrc/lt_gemm.cpp; the default wherever the library
+    holds one of the preferred names) against rocblas_gemm_ex (PROQA_LT_GEMM=0): same embeddings to fp16 round-off on a
+    bert-base-width stack, full-length and packed batches; the handle reports which kernel it pinned, and ragged products
+    (a feature count that is not a multiple of 256) stay on rocBLAS."""
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
+    cfg = dict(BERT_BASE, num_hidden_layers=2)
+    sd = random_state_dict(cfg, seed=6)
+    B, S = 160, 128
+    ids = torch.randint(1000, 30000, (B, S), device=gpu_device)
+    lens = torch.randint(40, S + 1, (B,), device=gpu_device)
+    names = {}
+    for mask in (torch.ones((B, S), dtype=torch.bool, device=gpu_device), torch.arange(S, device=gpu_device)[None, :] < lens[:, None]):
+        outs = []
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PROQA_LT_GEMM", mode)
+            model = BertForRetriever(cfg, device=gpu_device)
+            model.load_state_dict(sd)
+            outs.append(model.get_embed({"input_ids": ids, "input_mask": mask}, False)["embed"].float())
+            names[mode] = model.gemm_kernels()[False]
+        assert float((outs[0] - outs[1]).abs().max()) < 5e-3
+    assert names["0"] == ""                                   # switched off: rocblas_gemm_ex
+    if names["1"]:                                            # (a library build without the preferred names pins nothing)
+        assert "MT256x256x64" in names["1"]
+
+
+def test_library_dense_layer_grid(gpu_device):
+    """proqa_encoder_dense (the handle's library dense layer: the pinned hipBLASLt kernel for whole-tile products with
+    >= 4 K steps and >= 4096 rows, rocblas_gemm_ex otherwise) against an fp32 product, on both sides of every edge of
+    that class -- K = 64 and 128 are shapes the pinned kernel claims to support and computes wrongly."""
+    from proqa_amd import _lib
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
+    cfg = dict(BERT_BASE, num_hidden_layers=1)
+    model = BertForRetriever(cfg, device=gpu_device)
+    model.load_state_dict(random_state_dict(cfg, seed=0))
+    lib, h = _lib.load(), model.towers[False]._handle
+    g = torch.Generator(device=gpu_device).manual_seed(0)
+    for M in (300, 4096, 4100, 6400, 33024):
+        for N in (64, 256, 768, 2304):
+            for K in (64, 128, 192, 256, 320, 768, 3072):
+                x = torch.randn((M, K), generator=g, device=gpu_device).half()
+                w = (torch.randn((N, K), generator=g, device=gpu_device) * 0.05).half()
+                out = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu_device)
+                _lib.check(lib.proqa_encoder_dense(h, x.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, K, _lib.current_stream_ptr()))
+                ref = x.float() @ w.float().t()
+                assert torch.isfinite(out).all(), (M, N, K)
+                err = float((out.float() - ref).abs().max())
+                assert err <= 2e-3 * max(1.0, float(ref.abs().max())), (M, N, K, err)
+
+
 def test_fused_ffn1_path_equals_library_path(gpu_device, monkeypatch):
     """The encoder with BertIntermediate on the hand-written GEMM (default for >= 64 row tiles) and on the library GEMM +
     bias_gelu (PROQA_FFN1=lib) agree to fp16 round-off on a bert-base-width layer stack."""
