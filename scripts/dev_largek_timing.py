@@ -23,4 +23,9 @@ t = time.time()
 D, I = ix.search_device(xq, k)
 torch.cuda.synchronize()
 dt = time.time() - t
+import os
+ts = []
+for _ in range(5):
+    torch.cuda.synchronize(); t = time.time(); D, I = ix.search_device(xq, k); torch.cuda.synchronize(); ts.append(time.time() - t)
+print("flags", os.environ.get("PROQA_FILTER_FLAGS"), "ms", [round(x * 1e3, 2) for x in ts], "digest", int(I.sum().item()), float(D.double().sum().item()))
 print(f"n={n} nq={nq} k={k}: {dt*1e3:.1f} ms ({nq/dt:.0f} q/s), stats {ix.last_stats()}")
