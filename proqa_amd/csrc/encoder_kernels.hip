@@ -215,8 +215,7 @@ __global__ __launch_bounds__(256) void small_dense_mfma(const _Float16* __restri
   const _Float16* wrow = w + (long long)(m0 + li) * k_dim + wave * kq + half * 8;
   const _Float16* xrow = x + (long long)(n < n_rows ? n : n_rows - 1) * k_dim + wave * kq + half * 8;
   f32x16 acc0 = {0}, acc1 = {0};
-#pragma unroll 2
-  for (int k = 0; k < kq; k += 32) {
+  for (int k = 0; k < kq; k += 32) {   // (hipcc declines to unroll this loop: no pragma)
     const f16x8 a0 = *(const f16x8*)(wrow + k), b0 = *(const f16x8*)(xrow + k);
     const f16x8 a1 = *(const f16x8*)(wrow + k + 16), b1 = *(const f16x8*)(xrow + k + 16);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc0, 0, 0, 0);
