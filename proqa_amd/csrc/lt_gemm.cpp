@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <tuple>
@@ -154,10 +155,15 @@ Pinned& pinned() {
   static Pinned p;
   return p;
 }
+std::mutex& pinned_mutex() {   // encoder handles may meet their first large product on different threads
+  static std::mutex m;
+  return m;
+}
 
 void search_by_name(LtGemm* g, int64_t M, int N, int K) {
   const Api& a = api();
   g->searched = true;
+  std::lock_guard<std::mutex> lock(pinned_mutex());
   Pinned& pin = pinned();
   const bool dbg = getenv("PROQA_LT_DEBUG") != nullptr;
   if (!pin.searched) {
