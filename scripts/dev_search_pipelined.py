@@ -15,7 +15,7 @@ for r0 in range(0, n, 2_000_000):
     xb[r0:r0 + 2_000_000] = torch.randn((2_000_000, 128), generator=g, device=dev).to(torch.float16)
 xq = torch.randn((nq, 128), generator=g, device=dev).to(torch.float16)
 lib = _lib.load()
-for rows in (18_000_000, 4_500_000, 2_250_000):
+for rows in ([int(a) for a in sys.argv[1:]] or [18_000_000, 4_500_000, 2_250_000]):
     hs = [IndexFlatIP(128), IndexFlatIP(128)]
     for h in hs: h.adopt_device(xb[:rows])
     D = [torch.empty((nq, k), dtype=torch.float32, device=dev) for _ in range(2)]
