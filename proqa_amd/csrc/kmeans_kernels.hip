@@ -22,6 +22,9 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
+#include <cmath>
+#include <cstdio>
+#include <cstring>
 #include <new>
 
 #include "common.h"
@@ -39,19 +42,26 @@ constexpr int kD = PROQA_EMBED_DIM;            // 128
 // slots, so the LDS image needs no swizzle
 constexpr int kOpCols = 2 * kD + 16 + 8;
 constexpr int kOpRowBytes = kOpCols * 2;       // 560 B = 35 pieces of 16 B
-constexpr int kPieces = kOpRowBytes / 16;      // 35
 constexpr int kKSteps = (2 * kD + 16) / 16;    // 17
 constexpr int kStageRowsKm = 64;               // centroid rows per LDS stage
-constexpr int kStageBytesKm = kStageRowsKm * kOpRowBytes;  // 35840
+// (64 rows x 560 B = 35 KiB per LDS stage of the full operand)
+// the nominating pass of the assignment streams hi | norm step | pad only: 152 fp16 = 304 B per row (76 dwords: the same
+// 12-mod-64 bank stride as the full row), 19 KiB per stage -- half the operand traffic for half the k-steps
+constexpr int kHiCols = kD + 16 + 8;
+constexpr int kHiRowBytes = kHiCols * 2;                   // 304
 constexpr int kAssignWaves = 8;
 constexpr int kAssignThreads = kAssignWaves * 64;
 constexpr int kPointsPerBlock = kAssignWaves * 64;         // 2 blocks of 32 points per wave
 
 // fp32 centroids -> MFMA operand rows [k_pad][280] fp16: c_hi | c_lo | (-|c|^2/2 as 3 fp16) | 0
-__global__ void prep_centroids(const float* __restrict__ c, int k, int k_pad, int l2, _Float16* __restrict__ op) {
+// stats (optional): {max_c |c_lo|^2, max_c |c_hi + c_lo|^2} as float bits (non-negative: unsigned order = float order),
+// zeroed by the caller -- what the nominating pass of the assignment bounds its error with
+__global__ void prep_centroids(const float* __restrict__ c, int k, int k_pad, int l2, _Float16* __restrict__ op,
+                               unsigned* __restrict__ stats, _Float16* __restrict__ op_hi) {
   const int row = blockIdx.x;
   const int t = threadIdx.x;  // 128 threads
   __shared__ float red[128];
+  __shared__ float red_lo[128];
   float v = 0.f;
   if (row < k) v = c[(long long)row * kD + t];
   const _Float16 hi = (_Float16)v;
@@ -59,13 +69,23 @@ __global__ void prep_centroids(const float* __restrict__ c, int k, int k_pad, in
   _Float16* dst = op + (long long)row * kOpCols;
   dst[t] = hi;
   dst[kD + t] = lo;
+  _Float16* dst_hi = op_hi ? op_hi + (long long)row * kHiCols : nullptr;
+  if (dst_hi) dst_hi[t] = hi;
   // the norm uses the values the matrix pipe will actually see (hi + lo)
   const float seen = (float)hi + (float)lo;
   red[t] = seen * seen;
+  red_lo[t] = (float)lo * (float)lo;
   __syncthreads();
   for (int s = 64; s > 0; s >>= 1) {
-    if (t < s) red[t] += red[t + s];
+    if (t < s) {
+      red[t] += red[t + s];
+      red_lo[t] += red_lo[t + s];
+    }
     __syncthreads();
+  }
+  if (stats && t == 0 && row < k) {
+    atomicMax(stats, __float_as_uint(red_lo[0]));
+    atomicMax(stats + 1, __float_as_uint(red[0]));
   }
   if (t < 24) {  // norm step (16) + row padding (8)
     float term = 0.f;
@@ -77,35 +97,41 @@ __global__ void prep_centroids(const float* __restrict__ c, int k, int k_pad, in
       term = t == 0 ? (float)a : t == 1 ? (float)b : t == 2 ? (float)cc : 0.f;
     }
     dst[2 * kD + t] = (_Float16)term;
+    if (dst_hi) dst_hi[kD + t] = (_Float16)term;
   }
 }
 
-template <bool L2>
+// MODE_FULL: the assignment at full precision (hi + lo + norm: 17 k-steps) of points [0, n).
+// MODE_NOMINATE: hi + norm only (9 k-steps).  A centroid's score is then off by x.c_lo, at most |x| max|c_lo| in size, so
+//   the best centroid of this pass is THE best one whenever it leads the runner-up by more than twice that (+ a generous
+//   allowance for fp32 summation); the pass keeps best and runner-up, reports the leader with its score corrected by the
+//   exact x.c_lo of that one centroid, and appends the points it cannot decide (a few per cent; ties always) to `sel`.
+// MODE_SELECTED: MODE_FULL over the points listed in sel[0, *sel_count), persistent workgroups.
+enum { MODE_FULL = 0, MODE_NOMINATE = 1, MODE_SELECTED = 2 };
+
+template <bool L2, int MODE>
 __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* __restrict__ x, long long n,
                                                                 const char* __restrict__ op, int k, int k_pad,
                                                                 int* __restrict__ out_idx,
-                                                                float* __restrict__ out_dist) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * kStageBytesKm];
+                                                                float* __restrict__ out_dist, unsigned* __restrict__ sel,
+                                                                unsigned* __restrict__ sel_count,
+                                                                const unsigned* __restrict__ stats,
+                                                                const char* __restrict__ op_hi) {
+  constexpr int kRowB = MODE == MODE_NOMINATE ? kHiRowBytes : kOpRowBytes;
+  constexpr int kStageB = kStageRowsKm * kRowB;
+  constexpr int kSteps = MODE == MODE_NOMINATE ? 9 : kKSteps;   // hi (8) [+ lo (8)] + norm (1)
+  // Ring of four stages, the DMA of three in flight: a stage of the nominating pass is ~1 us of MFMA work, less than one
+  // trip to the L2 / Infinity Cache the operand lives in.  Every wave issues the SAME number of 1 KiB pieces per stage (a
+  // wave whose share is one short repeats its last piece), so one counted vmcnt per stage says "stage s has landed".
+  constexpr int kRing = 4;
+  constexpr int kStagePieces = kStageB / 1024;                                      // 35 (19)
+  constexpr int kPiecesPerWave = (kStagePieces + kAssignWaves - 1) / kAssignWaves;  // 5 (3)
+  __shared__ __attribute__((aligned(16))) char lds[kRing * kStageB];
+  const char* stream_op = MODE == MODE_NOMINATE ? op_hi : op;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
-  const long long p0 = (long long)blockIdx.x * kPointsPerBlock + wave * 64;
-
-  // resident point fragments (MFMA B operand) + |x|^2 of the lane's half rows
-  f16x8 qf[2][8];
-  float xx[2] = {0.f, 0.f};
-#pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    long long p = p0 + blk * 32 + li;
-    if (p >= n) p = n - 1;
-    const _Float16* row = x + p * kD;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      qf[blk][j] = *(const f16x8*)(row + (2 * j + half) * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xx[blk] += (float)qf[blk][j][e] * (float)qf[blk][j][e];
-    }
-  }
+  if (MODE == MODE_SELECTED) n = (long long)*sel_count;
   // operand of the norm k-step: lanes of half 0 multiply the three norm terms by 1
   f16x8 ones = {0, 0, 0, 0, 0, 0, 0, 0};
   if (half == 0) {
@@ -113,76 +139,181 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
     ones[1] = (_Float16)1.0f;
     ones[2] = (_Float16)1.0f;
   }
-
-  float best_s[2] = {-__builtin_inff(), -__builtin_inff()};
-  int best_i[2] = {0, 0};
-
   const int nstages = k_pad / kStageRowsKm;
   auto issue_stage = [&](int s) {
-    char* buf = lds + (s & 1) * kStageBytesKm;
-    const char* src0 = op + (long long)s * kStageBytesKm;
-    // 64 rows x 35 pieces = 35 wave-instructions of 1 KiB (a straight copy), round-robin over the waves
-    for (int e = wave; e < kStageRowsKm * kPieces / 64; e += kAssignWaves) {
+    char* buf = lds + (s & (kRing - 1)) * kStageB;
+    const char* src0 = stream_op + (long long)s * kStageB;
+    // 64 rows x 35 (19) pieces of 1 KiB (a straight copy), round-robin over the waves
+#pragma unroll
+    for (int i = 0; i < kPiecesPerWave; ++i) {
+      int e = wave + i * kAssignWaves;
+      if (e >= kStagePieces) e -= kAssignWaves;   // this wave's share is one short: its last piece once more
       const char* src = src0 + (e * 64 + lane) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(buf + e * 1024), 16, 0, 0);
     }
   };
+  // stage s has landed (the pieces of at most `younger` later stages stay in flight) and every wave has left stage s - 1
+  auto publish = [&](bool full_depth) {
+    if (full_depth)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kRing - 2) * kPiecesPerWave) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
 
-  issue_stage(0);
-  for (int s = 0; s < nstages; ++s) {
-    dma_wait_barrier();  // stage s landed (explicit vmcnt 0), every wave left the other buffer
-    if (s + 1 < nstages) issue_stage(s + 1);
-    const char* buf = lds + (s & 1) * kStageBytesKm;
+  for (long long tile = blockIdx.x; tile * kPointsPerBlock < n; tile += gridDim.x) {
+    const long long p0 = tile * kPointsPerBlock + wave * 64;
+    // resident point fragments (MFMA B operand) + |x|^2 of the lane's half rows
+    f16x8 qf[2][8];
+    float xx[2] = {0.f, 0.f};
+    long long prow[2];
 #pragma unroll
-    for (int sub = 0; sub < kStageRowsKm / 32; ++sub) {
-      const int row = sub * 32 + li;
-      const char* rbase = buf + row * kOpRowBytes;
-      f32x16 acc[2] = {{0}, {0}};
+    for (int blk = 0; blk < 2; ++blk) {
+      long long p = p0 + blk * 32 + li;
+      if (p >= n) p = n - 1;
+      prow[blk] = MODE == MODE_SELECTED ? (long long)sel[p] : p;
+      const _Float16* row = x + prow[blk] * kD;
 #pragma unroll
-      for (int j = 0; j < kKSteps; ++j) {
-        const f16x8 a = *(const f16x8*)(rbase + (2 * j + half) * 16);
+      for (int j = 0; j < 8; ++j) {
+        qf[blk][j] = *(const f16x8*)(row + (2 * j + half) * 8);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const f16x8 b = j < 8 ? qf[blk][j] : j < 16 ? qf[blk][j - 8] : ones;
-          if (j < 16 || L2) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[blk], 0, 0, 0);
-        }
+        for (int e = 0; e < 8; ++e) xx[blk] += (float)qf[blk][j][e] * (float)qf[blk][j][e];
       }
-      const int crow0 = s * kStageRowsKm + sub * 32 + 4 * half;
+    }
+
+    float best_s[2] = {-__builtin_inff(), -__builtin_inff()};
+    float second_s[2] = {-__builtin_inff(), -__builtin_inff()};   // MODE_NOMINATE
+    // MODE_NOMINATE: a score is off by x.c_lo, at most |x| max|c_lo|; a lead of twice that (+ a generous allowance for
+    // the fp32 summation) decides
+    float margin[2] = {0.f, 0.f};
+    if (MODE == MODE_NOMINATE) {
+      const float lo_max = __builtin_sqrtf(__uint_as_float(stats[0])), c_max = __builtin_sqrtf(__uint_as_float(stats[1]));
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
-        float m = acc[blk][0];
+        const float xn = __builtin_sqrtf(xx[blk] + __shfl_xor(xx[blk], 32, 64));
+        margin[blk] = 2.0f * (xn * lo_max + 4e-5f * (xn * c_max + 0.5f * c_max * c_max + 1.0f));
+      }
+    }
+    int best_i[2] = {0, 0};
+
+    if (MODE == MODE_SELECTED && tile != (long long)blockIdx.x) __syncthreads();   // every wave has left the previous tile's buffers
 #pragma unroll
-        for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, acc[blk][r]);
-        if (__any(m > best_s[blk])) {
+    for (int s = 0; s < kRing - 1; ++s)
+      if (s < nstages) issue_stage(s);
+    for (int s = 0; s < nstages; ++s) {
+      publish(s + kRing - 2 < nstages);   // (near the end fewer stages are in flight: wait for all)
+      if (s + kRing - 1 < nstages) issue_stage(s + kRing - 1);
+      const char* buf = lds + (s & (kRing - 1)) * kStageB;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {  // ascending centroid index: strict > keeps the lowest on ties
-            const int c = crow0 + (r & 3) + 8 * (r >> 2);
-            if (acc[blk][r] > best_s[blk] && c < k) {
-              best_s[blk] = acc[blk][r];
-              best_i[blk] = c;
+      for (int sub = 0; sub < kStageRowsKm / 32; ++sub) {
+        const int row = sub * 32 + li;
+        const char* rbase = buf + row * kRowB;
+        f32x16 acc[2] = {{0}, {0}};
+#pragma unroll
+        for (int j = 0; j < kSteps; ++j) {
+          const bool norm_step = j == kSteps - 1;
+          if (norm_step && !L2) continue;
+          const f16x8 a = *(const f16x8*)(rbase + (2 * j + half) * 16);
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk) {
+            const f16x8 b = norm_step ? ones : qf[blk][j & 7];
+            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[blk], 0, 0, 0);
+          }
+        }
+        const int crow0 = s * kStageRowsKm + sub * 32 + 4 * half;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          float m = acc[blk][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, acc[blk][r]);
+          if (MODE == MODE_NOMINATE) {
+            // Only scores within `margin` of the leader (at the time, hence of the final one) can make a point undecided:
+            // a unit none of whose scores gets that close is skipped, as in the full-precision kernel.  Otherwise: the top
+            // two of the unit's 16 scores by a tournament (37 operations), merged into (leader, runner-up); the leader's
+            // index only when it changed (the lowest centroid with that score: ties go to the lowest index).
+            if (__any(m > best_s[blk] - margin[blk])) {
+              float v[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) v[r] = acc[blk][r];
+              if ((s + 1) * kStageRowsKm > k) {   // wave-uniform: rows >= k (operand padding) exist in the last stage only
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                  if (crow0 + (r & 3) + 8 * (r >> 2) >= k) v[r] = -__builtin_inff();
+              }
+              float hi8[8], lo8[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                hi8[i] = __builtin_fmaxf(v[2 * i], v[2 * i + 1]);
+                lo8[i] = __builtin_fminf(v[2 * i], v[2 * i + 1]);
+              }
+#pragma unroll
+              for (int w = 4; w >= 1; w >>= 1)
+#pragma unroll
+                for (int i = 0; i < w; ++i) {
+                  const float a1 = hi8[i], b1 = hi8[i + w];
+                  lo8[i] = __builtin_fmaxf(__builtin_fmaxf(lo8[i], lo8[i + w]), __builtin_fminf(a1, b1));
+                  hi8[i] = __builtin_fmaxf(a1, b1);
+                }
+              const float m1 = hi8[0], m2 = lo8[0];
+              second_s[blk] = __builtin_fmaxf(__builtin_fmaxf(second_s[blk], m2), __builtin_fminf(best_s[blk], m1));
+              if (__any(m1 > best_s[blk])) {
+                int first = 0;
+#pragma unroll
+                for (int r = 15; r >= 0; --r) first = v[r] == m1 ? crow0 + (r & 3) + 8 * (r >> 2) : first;
+                best_i[blk] = m1 > best_s[blk] ? first : best_i[blk];
+              }
+              best_s[blk] = __builtin_fmaxf(best_s[blk], m1);
+            }
+          } else if (__any(m > best_s[blk])) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {  // ascending centroid index: strict > keeps the lowest on ties
+              const int c = crow0 + (r & 3) + 8 * (r >> 2);
+              if (acc[blk][r] > best_s[blk] && c < k) {
+                best_s[blk] = acc[blk][r];
+                best_i[blk] = c;
+              }
             }
           }
         }
       }
     }
-  }
 
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk) {
-    // combine the two accumulator halves of the point (they saw interleaved centroid rows)
-    const float os = __shfl_xor(best_s[blk], 32, 64);
-    const int oi = __shfl_xor(best_i[blk], 32, 64);
-    if (os > best_s[blk] || (os == best_s[blk] && oi < best_i[blk])) {
-      best_s[blk] = os;
-      best_i[blk] = oi;
-    }
-    const float xx_all = xx[blk] + __shfl_xor(xx[blk], 32, 64);
-    const long long p = p0 + blk * 32 + li;
-    if (half == 0 && p < n) {
-      out_idx[p] = best_i[blk];
-      // faiss IndexFlatL2 reports |x|^2 + |c|^2 - 2 x.c clipped at 0; IndexFlatIP the inner product
-      out_dist[p] = L2 ? __builtin_fmaxf(xx_all - 2.0f * best_s[blk], 0.f) : best_s[blk];
+    for (int blk = 0; blk < 2; ++blk) {
+      // combine the two accumulator halves of the point (they saw interleaved centroid rows)
+      const float os = __shfl_xor(best_s[blk], 32, 64);
+      const int oi = __shfl_xor(best_i[blk], 32, 64);
+      const float o2 = __shfl_xor(second_s[blk], 32, 64);
+      float runner = __builtin_fmaxf(__builtin_fminf(os, best_s[blk]), __builtin_fmaxf(o2, second_s[blk]));
+      if (os > best_s[blk] || (os == best_s[blk] && oi < best_i[blk])) {
+        best_s[blk] = os;
+        best_i[blk] = oi;
+      }
+      const float xx_all = xx[blk] + __shfl_xor(xx[blk], 32, 64);
+      const long long p = p0 + blk * 32 + li;
+      float score = best_s[blk];
+      if (MODE == MODE_NOMINATE) {
+        // the leader's score, corrected by the lo part of that one centroid (each half adds its 64 dimensions)
+        const _Float16* lo = (const _Float16*)(op + (long long)best_i[blk] * kOpRowBytes) + kD;
+        float corr = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f16x8 cl = *(const f16x8*)(lo + (2 * j + half) * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) corr += (float)qf[blk][j][e] * (float)cl[e];
+        }
+        corr += __shfl_xor(corr, 32, 64);
+        score += corr;
+        // undecided: the runner-up is within the margin of the leader
+        if (half == 0 && p < n && !(best_s[blk] - runner > margin[blk])) sel[atomicAdd(sel_count, 1u)] = (unsigned)p;
+      }
+      if (half == 0 && p < n) {
+        out_idx[prow[blk]] = best_i[blk];
+        // faiss IndexFlatL2 reports |x|^2 + |c|^2 - 2 x.c clipped at 0; IndexFlatIP the inner product
+        out_dist[prow[blk]] = L2 ? __builtin_fmaxf(xx_all - 2.0f * score, 0.f) : score;
+      }
     }
   }
 }
@@ -269,6 +400,7 @@ struct proqa_kmeans {
   int64_t n_max = 0;
   int k = 0, k_pad = 0;
   _Float16* op = nullptr;       // centroid operand rows
+  _Float16* op_hi = nullptr;    // the same without the lo parts (nominating pass)
   unsigned* counts = nullptr;   // [k]
   unsigned* begin = nullptr;    // [k]
   unsigned* keys_in = nullptr;  // [n_max] (assignment as unsigned)
@@ -277,6 +409,7 @@ struct proqa_kmeans {
   unsigned* vals_out = nullptr;
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
+  unsigned* words = nullptr;    // {max |c_lo|^2, max |c|^2 (float bits), undecided points} of the two-pass assignment
 };
 
 using namespace proqa;
@@ -285,7 +418,7 @@ extern "C" {
 
 int proqa_kmeans_free(proqa_kmeans* h) {
   if (!h) return PROQA_OK;
-  void* ptrs[] = {h->op, h->counts, h->begin, h->keys_in, h->keys_out, h->vals_in, h->vals_out, h->sort_tmp};
+  void* ptrs[] = {h->op, h->counts, h->begin, h->keys_in, h->keys_out, h->vals_in, h->vals_out, h->sort_tmp, h->words, h->op_hi};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -311,12 +444,14 @@ int proqa_kmeans_create(int d, int64_t n_max, int k, proqa_kmeans** out) {
     if (e == hipSuccess) e = hipMalloc(p, bytes);
   };
   alloc((void**)&h->op, (size_t)h->k_pad * kOpRowBytes);
+  alloc((void**)&h->op_hi, (size_t)h->k_pad * kHiRowBytes);
   alloc((void**)&h->counts, (size_t)k * sizeof(unsigned));
   alloc((void**)&h->begin, (size_t)k * sizeof(unsigned));
   alloc((void**)&h->keys_in, (size_t)n_max * sizeof(unsigned));
   alloc((void**)&h->keys_out, (size_t)n_max * sizeof(unsigned));
   alloc((void**)&h->vals_in, (size_t)n_max * sizeof(unsigned));
   alloc((void**)&h->vals_out, (size_t)n_max * sizeof(unsigned));
+  alloc((void**)&h->words, 4 * sizeof(unsigned));
   if (e == hipSuccess)
     e = hipcub::DeviceRadixSort::SortPairs(nullptr, h->sort_tmp_bytes, h->keys_in, h->keys_out, h->vals_in, h->vals_out,
                                            (int)n_max, 0, 32, nullptr);
@@ -335,17 +470,47 @@ int proqa_kmeans_assign_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n
   if (n < 0 || n >= (1ll << 31)) return fail(PROQA_EINVAL, "kmeans_assign: n=%lld", (long long)n);
   if (n == 0) return PROQA_OK;
   hipStream_t st = as_stream(stream);
+  // Two passes (the default wherever the handle's index buffer holds n points): hi-only nomination of every point, then the
+  // full-precision kernel over the few it could not decide.  PROQA_KMEANS_TWO_PASS=0: the full-precision kernel over all.
+  static const bool kTwoPass = !(getenv("PROQA_KMEANS_TWO_PASS") && atoi(getenv("PROQA_KMEANS_TWO_PASS")) == 0);
+  const bool two_pass = kTwoPass && n <= h->n_max;
+  PROQA_HIP(hipMemsetAsync(h->words, 0, 4 * sizeof(unsigned), st));
   hipLaunchKernelGGL(prep_centroids, dim3(h->k_pad), dim3(128), 0, st, centroids_dev, h->k, h->k_pad, metric_l2 ? 1 : 0,
-                     h->op);
+                     h->op, h->words, two_pass ? h->op_hi : nullptr);
   PROQA_LAUNCH_CHECK();
   const unsigned grid = (unsigned)ceil_div<int64_t>(n, kPointsPerBlock);
-  if (metric_l2)
-    hipLaunchKernelGGL((kmeans_assign<true>), dim3(grid), dim3(kAssignThreads), 0, st, (const _Float16*)x_f16_dev,
-                       (long long)n, (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev);
-  else
-    hipLaunchKernelGGL((kmeans_assign<false>), dim3(grid), dim3(kAssignThreads), 0, st, (const _Float16*)x_f16_dev,
-                       (long long)n, (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev);
-  PROQA_LAUNCH_CHECK();
+  const _Float16* x = (const _Float16*)x_f16_dev;
+#define PROQA_KM_LAUNCH(MODE, GRID)                                                                                          \
+  do {                                                                                                                       \
+    if (metric_l2)                                                                                                           \
+      hipLaunchKernelGGL((kmeans_assign<true, MODE>), dim3(GRID), dim3(kAssignThreads), 0, st, x, (long long)n,              \
+                         (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev, h->vals_in, h->words + 2, h->words,      \
+                         (const char*)h->op_hi);                                                                             \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((kmeans_assign<false, MODE>), dim3(GRID), dim3(kAssignThreads), 0, st, x, (long long)n,             \
+                         (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev, h->vals_in, h->words + 2, h->words,      \
+                         (const char*)h->op_hi);                                                                             \
+    PROQA_LAUNCH_CHECK();                                                                                                    \
+  } while (0)
+  if (!two_pass) {
+    PROQA_KM_LAUNCH(MODE_FULL, grid);
+  } else {
+    PROQA_KM_LAUNCH(MODE_NOMINATE, grid);
+    static const bool kDebug = getenv("PROQA_DEBUG_KMEANS") != nullptr;   // developer: undecided points per call (adds a sync)
+    if (kDebug) {
+      unsigned w[4] = {};
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(w, h->words, sizeof w, hipMemcpyDeviceToHost);
+      float lo2, c2;
+      memcpy(&lo2, &w[0], 4);
+      memcpy(&c2, &w[1], 4);
+      fprintf(stderr, "[kmeans] nominating pass: %u of %lld points undecided (max |c_lo| %.3g, max |c| %.3g)\n", w[2], (long long)n,
+              std::sqrt(lo2), std::sqrt(c2));
+    }
+    // (the count of undecided points stays on the device: a persistent grid walks over however many there are)
+    PROQA_KM_LAUNCH(MODE_SELECTED, std::min<unsigned>(grid, 4u * (unsigned)device_cu_count()));
+  }
+#undef PROQA_KM_LAUNCH
   return PROQA_OK;
 }
 

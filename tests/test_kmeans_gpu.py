@@ -169,3 +169,45 @@ def test_group_paras_cli_writes_splits(gpu_device, tmp_path):
     for i in range(4):
         want = [f'{{"q": {j}}}\n' for j in range(300) if I[j][0] == i]
         assert open(os.path.join(out, f"split_{i}.txt")).readlines() == want
+
+
+_TWO_PASS_CHILD = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from proqa_amd.group_paras import KMeans
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(9)
+out = []
+for name, n, k, l2 in (("clustered", 50000, 700, True), ("clustered-ip", 30000, 257, False), ("near-ties", 20000, 128, True),
+                      ("ragged", 1537, 65, True)):
+    centers = rng.standard_normal((k, 128)).astype(np.float32)
+    if name == "near-ties":                       # every centroid has a twin a few fp16 ulps away, and an exact duplicate
+        centers[1::2] = centers[0::2] * (1 + 2e-4 * rng.standard_normal((k // 2, 1)).astype(np.float32))
+        centers[5] = centers[2]
+    x = (centers[rng.integers(0, k, n)] + 0.3 * rng.standard_normal((n, 128))).astype(np.float16)
+    km = KMeans(128, k, spherical_metric=not l2)
+    km.centroids = torch.from_numpy(centers).to(dev)
+    D, I = km.assign(torch.from_numpy(x).to(dev))
+    out.append(name + ":" + hashlib.sha256(I.cpu().numpy().tobytes()).hexdigest()[:16] + ":%.9e" % float(D.double().sum()))
+print("RESULT " + " ".join(out))
+"""
+
+
+def test_two_pass_assignment_equals_the_full_precision_pass(gpu_device, tmp_path):
+    """The default assignment (hi-only nomination of every point + the full-precision kernel over the undecided ones) gives
+    the labels of the full-precision kernel over all points (PROQA_KMEANS_TWO_PASS=0): clustered data, inner-product metric,
+    centroids with twins a few ulps apart and exact duplicates, ragged sizes; the summed distances agree to 1e-6."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", _TWO_PASS_CHILD, root], env=dict(os.environ, PROQA_KMEANS_TWO_PASS=mode),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][0]
+        res[mode] = [t.split(":") for t in line.split()[1:]]
+    for a, b in zip(res["1"], res["0"]):
+        assert a[0] == b[0] and a[1] == b[1], (a, b)                      # identical labels
+        assert abs(float(a[2]) - float(b[2])) <= 1e-6 * abs(float(b[2])), (a, b)
