@@ -312,6 +312,12 @@ int proqa_kmeans_free(proqa_kmeans* h);
  * (metric_l2 != 0) or inner product; exact ties go to the lowest centroid index */
 int proqa_kmeans_assign_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n, const float* centroids_dev,
                                int metric_l2, int32_t* assign_dev, float* dist_dev, void* stream);
+/* the same with a hint per point (int32 [n], may be NULL, may alias assign_dev): any centroid index -- a Lloyd loop passes
+ * the assignment of its previous iteration.  The result does not depend on the hint; a good one lets the nominating pass
+ * skip most of its bookkeeping (a hint out of [0, k) is ignored for that point). */
+int proqa_kmeans_assign_hinted_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n, const float* centroids_dev,
+                                      int metric_l2, const int32_t* hint_dev, int32_t* assign_dev, float* dist_dev,
+                                      void* stream);
 /* centroid c = mean of its points, summed in fp32 in point order (faiss km_update_centroids);
  * counts uint32 [k]; centroids of empty clusters are left untouched */
 int proqa_kmeans_update_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n, const int32_t* assign_dev,

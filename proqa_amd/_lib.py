@@ -121,6 +121,8 @@ SIGNATURES = {
     "proqa_kmeans_free": (c_int, [c_void_p]),
     "proqa_kmeans_assign_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p]),
+    "proqa_kmeans_assign_hinted_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p]),
     "proqa_kmeans_update_device": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "proqa_rand_perm": (c_int, [c_int64, c_int64, c_void_p]),
     "proqa_npy_stat": (c_int, [c_char_p, ctypes.POINTER(NpyInfo)]),

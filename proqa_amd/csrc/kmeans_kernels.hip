@@ -14,6 +14,9 @@
 //            x.c_hi + x.c_lo, 16 k-steps) and, for L2, one extra k-step carries -|c|^2/2 split
 //            into three fp16 terms against a constant 1 in the point operand:
 //            argmin |x-c|^2 = argmax (x.c - |c|^2/2).
+//            Two passes: the hi parts alone nominate (half the k-steps; the lo parts move a score by at most
+//            |x| max|c_lo|, so a lead larger than twice that decides), the full-precision kernel runs over the few
+//            per cent of the points the nomination leaves undecided -- see kmeans_assign's MODEs.
 //   update   new centroid = mean of its points, accumulated in fp32 IN POINT ORDER (the order of
 //            faiss' km_update_centroids), so equal assignments give bit-equal centroids: points
 //            are stably sorted by assignment (hipCUB radix sort), one wave per centroid then adds
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
                                                                 float* __restrict__ out_dist, unsigned* __restrict__ sel,
                                                                 unsigned* __restrict__ sel_count,
                                                                 const unsigned* __restrict__ stats,
-                                                                const char* __restrict__ op_hi) {
+                                                                const char* __restrict__ op_hi,
+                                                                const int* __restrict__ hint) {
   constexpr int kRowB = MODE == MODE_NOMINATE ? kHiRowBytes : kOpRowBytes;
   constexpr int kStageB = kStageRowsKm * kRowB;
   constexpr int kSteps = MODE == MODE_NOMINATE ? 9 : kKSteps;   // hi (8) [+ lo (8)] + norm (1)
@@ -196,6 +200,31 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
         margin[blk] = 2.0f * (xn * lo_max + 4e-5f * (xn * c_max + 0.5f * c_max * c_max + 1.0f));
       }
     }
+    // MODE_NOMINATE with a hint (the point's centroid of the previous Lloyd iteration, any value allowed): the hinted
+    // centroid's score, computed here on the vector pipe, is a floor under the final leader's -- no score more than the
+    // margin below it can lead or come close, so the units that hold none are skipped from the FIRST unit on instead of
+    // from whenever the running maximum has grown that high (which takes a wave of 64 independent points most of the pass)
+    float floor_s[2] = {-__builtin_inff(), -__builtin_inff()};
+    if (MODE == MODE_NOMINATE && hint) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const int hc = hint[prow[blk]];
+        float dot = 0.f;
+        if (hc >= 0 && hc < k) {
+          const _Float16* crow = (const _Float16*)(op_hi + (long long)hc * kHiRowBytes);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const f16x8 ch = *(const f16x8*)(crow + (2 * j + half) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot += (float)qf[blk][j][e] * (float)ch[e];
+          }
+          if (L2 && half == 0) dot += (float)crow[kD] + (float)crow[kD + 1] + (float)crow[kD + 2];   // -|c|^2 / 2
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        // (the matrix pipe sums the same products in another order: the margin holds twice that allowance)
+        if (hc >= 0 && hc < k) floor_s[blk] = dot - margin[blk];
+      }
+    }
     int best_i[2] = {0, 0};
 
     if (MODE == MODE_SELECTED && tile != (long long)blockIdx.x) __syncthreads();   // every wave has left the previous tile's buffers
@@ -233,7 +262,7 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
             // a unit none of whose scores gets that close is skipped, as in the full-precision kernel.  Otherwise: the top
             // two of the unit's 16 scores by a tournament (37 operations), merged into (leader, runner-up); the leader's
             // index only when it changed (the lowest centroid with that score: ties go to the lowest index).
-            if (__any(m > best_s[blk] - margin[blk])) {
+            if (__any(m > __builtin_fmaxf(best_s[blk], floor_s[blk]) - margin[blk])) {
               float v[16];
 #pragma unroll
               for (int r = 0; r < 16; ++r) v[r] = acc[blk][r];
@@ -466,6 +495,12 @@ int proqa_kmeans_create(int d, int64_t n_max, int k, proqa_kmeans** out) {
 
 int proqa_kmeans_assign_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n, const float* centroids_dev,
                                int metric_l2, int32_t* assign_dev, float* dist_dev, void* stream) {
+  return proqa_kmeans_assign_hinted_device(h, x_f16_dev, n, centroids_dev, metric_l2, nullptr, assign_dev, dist_dev, stream);
+}
+
+int proqa_kmeans_assign_hinted_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n, const float* centroids_dev,
+                                      int metric_l2, const int32_t* hint_dev, int32_t* assign_dev, float* dist_dev,
+                                      void* stream) {
   if (!h || !x_f16_dev || !centroids_dev || !assign_dev || !dist_dev) return fail(PROQA_EINVAL, "kmeans_assign: NULL argument");
   if (n < 0 || n >= (1ll << 31)) return fail(PROQA_EINVAL, "kmeans_assign: n=%lld", (long long)n);
   if (n == 0) return PROQA_OK;
@@ -485,11 +520,11 @@ int proqa_kmeans_assign_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n
     if (metric_l2)                                                                                                           \
       hipLaunchKernelGGL((kmeans_assign<true, MODE>), dim3(GRID), dim3(kAssignThreads), 0, st, x, (long long)n,              \
                          (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev, h->vals_in, h->words + 2, h->words,      \
-                         (const char*)h->op_hi);                                                                             \
+                         (const char*)h->op_hi, hint_dev);                                                                   \
     else                                                                                                                     \
       hipLaunchKernelGGL((kmeans_assign<false, MODE>), dim3(GRID), dim3(kAssignThreads), 0, st, x, (long long)n,             \
                          (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev, h->vals_in, h->words + 2, h->words,      \
-                         (const char*)h->op_hi);                                                                             \
+                         (const char*)h->op_hi, hint_dev);                                                                   \
     PROQA_LAUNCH_CHECK();                                                                                                    \
   } while (0)
   if (!two_pass) {

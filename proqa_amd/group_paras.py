@@ -59,12 +59,14 @@ class KMeans:
         _lib.check(self._lib.proqa_kmeans_create(self.d, int(n), self.k, ctypes.byref(h)))
         return h
 
-    def _assign(self, h, x, centroids):
+    def _assign(self, h, x, centroids, hint=None):
         n = x.shape[0]
         I = torch.empty(n, dtype=torch.int32, device=x.device)
         D = torch.empty(n, dtype=torch.float32, device=x.device)
-        _lib.check(self._lib.proqa_kmeans_assign_device(h, x.data_ptr(), n, centroids.data_ptr(), 1 if self.l2 else 0,
-                                                        I.data_ptr(), D.data_ptr(), _lib.current_stream_ptr()))
+        # `hint` (the labels of the previous Lloyd iteration): same result, less bookkeeping in the nominating pass
+        _lib.check(self._lib.proqa_kmeans_assign_hinted_device(h, x.data_ptr(), n, centroids.data_ptr(), 1 if self.l2 else 0,
+                                                               hint.data_ptr() if hint is not None else None, I.data_ptr(),
+                                                               D.data_ptr(), _lib.current_stream_ptr()))
         return D, I
 
     def _split_empty(self, centroids, counts, n):
@@ -112,10 +114,11 @@ class KMeans:
         try:
             import time
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            I = None
             for it in range(self.niter):
                 t_it = time.perf_counter()
                 ev[0].record()
-                D, I = self._assign(h, x, centroids)
+                D, I = self._assign(h, x, centroids, hint=I)
                 ev[1].record()
                 err = float(D.double().sum())
                 self.obj.append(err)

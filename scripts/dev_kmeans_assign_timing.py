@@ -25,3 +25,12 @@ for name, cen in (("centroids = random points", x[torch.randperm(n, generator=g,
     torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 5 * 1e3
     digest = hashlib.sha256(lab.cpu().numpy().tobytes()).hexdigest()[:10]
     print(f"{name}: {ms:.1f} ms per assignment; labels {digest}; objective {dist.double().sum().item():.6e}")
+    # hinted: the exact labels as the hint (a converged Lloyd loop), and labels of which 30 % are wrong
+    for hname, hint in (("own labels", lab.clone()), ("30 % random", torch.where(torch.rand(n, device=dev) < 0.3, torch.randint(0, k, (n,), device=dev, dtype=torch.int32), lab))):
+        lab2 = torch.empty_like(lab)
+        fh = lambda: _lib.check(lib.proqa_kmeans_assign_hinted_device(h, x.data_ptr(), n, cen.data_ptr(), 1, hint.data_ptr(), lab2.data_ptr(), dist.data_ptr(), _lib.current_stream_ptr()))
+        for _ in range(2): fh()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(5): fh()
+        torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 5 * 1e3
+        print(f"   hint = {hname}: {ms:.1f} ms; labels {hashlib.sha256(lab2.cpu().numpy().tobytes()).hexdigest()[:10]}")
