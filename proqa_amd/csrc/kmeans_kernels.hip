@@ -120,7 +120,8 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
                                                                 unsigned* __restrict__ sel_count,
                                                                 const unsigned* __restrict__ stats,
                                                                 const char* __restrict__ op_hi,
-                                                                const int* __restrict__ hint) {
+                                                                const int* __restrict__ hint,
+                                                                const unsigned* __restrict__ order) {
   constexpr int kRowB = MODE == MODE_NOMINATE ? kHiRowBytes : kOpRowBytes;
   constexpr int kStageB = kStageRowsKm * kRowB;
   constexpr int kSteps = MODE == MODE_NOMINATE ? 9 : kKSteps;   // hi (8) [+ lo (8)] + norm (1)
@@ -177,7 +178,10 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
     for (int blk = 0; blk < 2; ++blk) {
       long long p = p0 + blk * 32 + li;
       if (p >= n) p = n - 1;
-      prow[blk] = MODE == MODE_SELECTED ? (long long)sel[p] : p;
+      // MODE_NOMINATE with `order` (the points sorted by their previous centroid, a by-product of the last update): the
+      // 64 points of a wave then share one or two leaders, so the units in which SOME lane has bookkeeping to do are a
+      // handful per wave instead of one or two per lane -- any permutation of the points is a valid processing order
+      prow[blk] = MODE == MODE_SELECTED ? (long long)sel[p] : (MODE == MODE_NOMINATE && order ? (long long)order[p] : p);
       const _Float16* row = x + prow[blk] * kD;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
         corr += __shfl_xor(corr, 32, 64);
         score += corr;
         // undecided: the runner-up is within the margin of the leader
-        if (half == 0 && p < n && !(best_s[blk] - runner > margin[blk])) sel[atomicAdd(sel_count, 1u)] = (unsigned)p;
+        if (half == 0 && p < n && !(best_s[blk] - runner > margin[blk])) sel[atomicAdd(sel_count, 1u)] = (unsigned)prow[blk];
       }
       if (half == 0 && p < n) {
         out_idx[prow[blk]] = best_i[blk];
@@ -439,6 +443,7 @@ struct proqa_kmeans {
   void* sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   unsigned* words = nullptr;    // {max |c_lo|^2, max |c|^2 (float bits), undecided points} of the two-pass assignment
+  int64_t order_n = 0;          // vals_out holds the ids of this many points sorted by assignment (the last update's)
 };
 
 using namespace proqa;
@@ -509,6 +514,9 @@ int proqa_kmeans_assign_hinted_device(proqa_kmeans* h, const void* x_f16_dev, in
   // full-precision kernel over the few it could not decide.  PROQA_KMEANS_TWO_PASS=0: the full-precision kernel over all.
   static const bool kTwoPass = !(getenv("PROQA_KMEANS_TWO_PASS") && atoi(getenv("PROQA_KMEANS_TWO_PASS")) == 0);
   const bool two_pass = kTwoPass && n <= h->n_max;
+  // a hinted call right behind an update of the same n points (a Lloyd loop): walk the points in that update's sorted order
+  static const bool kSorted = !(getenv("PROQA_KMEANS_SORTED") && atoi(getenv("PROQA_KMEANS_SORTED")) == 0);
+  const unsigned* order = two_pass && hint_dev && kSorted && h->order_n == n ? h->vals_out : nullptr;
   PROQA_HIP(hipMemsetAsync(h->words, 0, 4 * sizeof(unsigned), st));
   hipLaunchKernelGGL(prep_centroids, dim3(h->k_pad), dim3(128), 0, st, centroids_dev, h->k, h->k_pad, metric_l2 ? 1 : 0,
                      h->op, h->words, two_pass ? h->op_hi : nullptr);
@@ -520,11 +528,11 @@ int proqa_kmeans_assign_hinted_device(proqa_kmeans* h, const void* x_f16_dev, in
     if (metric_l2)                                                                                                           \
       hipLaunchKernelGGL((kmeans_assign<true, MODE>), dim3(GRID), dim3(kAssignThreads), 0, st, x, (long long)n,              \
                          (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev, h->vals_in, h->words + 2, h->words,      \
-                         (const char*)h->op_hi, hint_dev);                                                                   \
+                         (const char*)h->op_hi, hint_dev, order);                                                            \
     else                                                                                                                     \
       hipLaunchKernelGGL((kmeans_assign<false, MODE>), dim3(GRID), dim3(kAssignThreads), 0, st, x, (long long)n,             \
                          (const char*)h->op, h->k, h->k_pad, assign_dev, dist_dev, h->vals_in, h->words + 2, h->words,      \
-                         (const char*)h->op_hi, hint_dev);                                                                   \
+                         (const char*)h->op_hi, hint_dev, order);                                                            \
     PROQA_LAUNCH_CHECK();                                                                                                    \
   } while (0)
   if (!two_pass) {
@@ -556,6 +564,7 @@ int proqa_kmeans_update_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n
   if (n <= 0 || n > h->n_max) return fail(PROQA_EINVAL, "kmeans_update: n=%lld exceeds n_max=%lld", (long long)n, (long long)h->n_max);
   hipStream_t st = as_stream(stream);
   const unsigned blocks = (unsigned)ceil_div<int64_t>(n, 256);
+  h->order_n = 0;   // (set again once the sorted ids of this call are on the stream)
   PROQA_HIP(hipMemsetAsync(h->counts, 0, (size_t)h->k * sizeof(unsigned), st));
   hipLaunchKernelGGL(histogram_assign, dim3(blocks), dim3(256), 0, st, assign_dev, (long long)n, h->counts);
   PROQA_LAUNCH_CHECK();
@@ -572,6 +581,7 @@ int proqa_kmeans_update_device(proqa_kmeans* h, const void* x_f16_dev, int64_t n
                      h->vals_out, h->begin, h->counts, h->k, centroids_dev);
   PROQA_LAUNCH_CHECK();
   PROQA_HIP(hipMemcpyAsync(counts_dev, h->counts, (size_t)h->k * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+  h->order_n = n;
   return PROQA_OK;
 }
 
