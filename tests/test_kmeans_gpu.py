@@ -211,3 +211,53 @@ def test_two_pass_assignment_equals_the_full_precision_pass(gpu_device, tmp_path
     for a, b in zip(res["1"], res["0"]):
         assert a[0] == b[0] and a[1] == b[1], (a, b)                      # identical labels
         assert abs(float(a[2]) - float(b[2])) <= 1e-6 * abs(float(b[2])), (a, b)
+
+
+def test_hinted_assignment_in_sorted_order_gives_the_same_labels(gpu_device):
+    """A Lloyd loop's second assignment -- hinted with the previous labels and walking the points in the sorted order the
+    update in between left behind -- returns exactly what an unhinted assignment on a fresh handle returns, for right,
+    wrong and out-of-range hints."""
+    import ctypes
+    from proqa_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(21)
+    n, k = 40000, 300
+    x_np, _ = blobs(rng, n, k, spread=0.4)
+    x = torch.from_numpy(x_np).to(gpu_device)
+    cent = torch.from_numpy(rng.standard_normal((k, 128)).astype(np.float32)).to(gpu_device)
+
+    def handle():
+        h = ctypes.c_void_p()
+        _lib.check(lib.proqa_kmeans_create(128, n, k, ctypes.byref(h)))
+        return h
+
+    def assign(h, c, hint=None):
+        lab = torch.empty(n, dtype=torch.int32, device=gpu_device)
+        dist = torch.empty(n, dtype=torch.float32, device=gpu_device)
+        _lib.check(lib.proqa_kmeans_assign_hinted_device(h, x.data_ptr(), n, c.data_ptr(), 1, hint.data_ptr() if hint is not None else None,
+                                                         lab.data_ptr(), dist.data_ptr(), _lib.current_stream_ptr()))
+        return lab, dist
+
+    h = handle()
+    lab0, _ = assign(h, cent)
+    cent1 = cent.clone()
+    counts = torch.empty(k, dtype=torch.int32, device=gpu_device)
+    _lib.check(lib.proqa_kmeans_update_device(h, x.data_ptr(), n, lab0.data_ptr(), cent1.data_ptr(), counts.data_ptr(),
+                                              _lib.current_stream_ptr()))
+    fresh = handle()
+    want, want_d = assign(fresh, cent1)
+    hints = {"previous labels": lab0, "random": torch.randint(0, k, (n,), device=gpu_device, dtype=torch.int32),
+             "out of range": torch.full((n,), k + 7, device=gpu_device, dtype=torch.int32),
+             "negative": torch.full((n,), -1, device=gpu_device, dtype=torch.int32)}
+    for name, hint in hints.items():
+        got, got_d = assign(h, cent1, hint)           # (the handle still holds the update's sorted order)
+        assert torch.equal(got, want), name
+        torch.testing.assert_close(got_d, want_d, rtol=1e-5, atol=1e-4)
+    got, _ = assign(h, cent1, lab0.clone())            # in place: the hint buffer is the output buffer
+    lab_io = lab0.clone()
+    dist = torch.empty(n, dtype=torch.float32, device=gpu_device)
+    _lib.check(lib.proqa_kmeans_assign_hinted_device(h, x.data_ptr(), n, cent1.data_ptr(), 1, lab_io.data_ptr(), lab_io.data_ptr(),
+                                                     dist.data_ptr(), _lib.current_stream_ptr()))
+    assert torch.equal(lab_io, want)
+    for hh in (h, fresh):
+        lib.proqa_kmeans_free(hh)
