@@ -204,17 +204,17 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
         margin[blk] = 2.0f * (xn * lo_max + 4e-5f * (xn * c_max + 0.5f * c_max * c_max + 1.0f));
       }
     }
-    // MODE_NOMINATE with a hint (the point's centroid of the previous Lloyd iteration, any value allowed): the hinted
-    // centroid's score, computed here on the vector pipe, is a floor under the final leader's -- no score more than the
-    // margin below it can lead or come close, so the units that hold none are skipped from the FIRST unit on instead of
-    // from whenever the running maximum has grown that high (which takes a wave of 64 independent points most of the pass)
-    float floor_s[2] = {-__builtin_inff(), -__builtin_inff()};
+    // MODE_NOMINATE with a hint (the point's centroid of the previous Lloyd iteration; any value allowed): the hinted
+    // centroid's score, computed here on the vector pipe, less twice the margin is below the final leader's and further than
+    // the margin from it -- the pass starts with that as its (virtual) leader, so nothing below it costs any bookkeeping
+    int best_i[2] = {0, 0};
     if (MODE == MODE_NOMINATE && hint) {
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         const int hc = hint[prow[blk]];
+        const bool ok = hc >= 0 && hc < k;
         float dot = 0.f;
-        if (hc >= 0 && hc < k) {
+        if (ok) {
           const _Float16* crow = (const _Float16*)(op_hi + (long long)hc * kHiRowBytes);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -226,10 +226,12 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
         }
         dot += __shfl_xor(dot, 32, 64);
         // (the matrix pipe sums the same products in another order: the margin holds twice that allowance)
-        if (hc >= 0 && hc < k) floor_s[blk] = dot - margin[blk];
+        if (ok) {
+          best_s[blk] = dot - 2.0f * margin[blk];
+          best_i[blk] = hc;
+        }
       }
     }
-    int best_i[2] = {0, 0};
 
     if (MODE == MODE_SELECTED && tile != (long long)blockIdx.x) __syncthreads();   // every wave has left the previous tile's buffers
 #pragma unroll
@@ -258,23 +260,25 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
         const int crow0 = s * kStageRowsKm + sub * 32 + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
+          if (MODE == MODE_NOMINATE && (s + 1) * kStageRowsKm > k) {   // wave-uniform: operand padding rows (>= k), last stage only
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (crow0 + (r & 3) + 8 * (r >> 2) >= k) acc[blk][r] = -__builtin_inff();
+          }
           float m = acc[blk][0];
 #pragma unroll
           for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, acc[blk][r]);
           if (MODE == MODE_NOMINATE) {
-            // Only scores within `margin` of the leader (at the time, hence of the final one) can make a point undecided:
-            // a unit none of whose scores gets that close is skipped, as in the full-precision kernel.  Otherwise: the top
-            // two of the unit's 16 scores by a tournament (37 operations), merged into (leader, runner-up); the leader's
-            // index only when it changed (the lowest centroid with that score: ties go to the lowest index).
-            if (__any(m > __builtin_fmaxf(best_s[blk], floor_s[blk]) - margin[blk])) {
+            // A runner-up in ANOTHER unit than the leader's shows in that unit's maximum: two operations per unit, no
+            // branch.  Only a unit that takes the lead needs more -- its second-best score (a tournament over the 16: 37
+            // operations) and the index of its best (the lowest centroid with that score) -- and with the leader starting
+            // at the hinted centroid's score that happens once or twice per point, in the same units for the whole wave
+            // when the points arrive sorted by their previous centroid.
+            second_s[blk] = __builtin_fmaxf(second_s[blk], __builtin_fminf(best_s[blk], m));
+            if (__any(m > best_s[blk])) {
               float v[16];
 #pragma unroll
               for (int r = 0; r < 16; ++r) v[r] = acc[blk][r];
-              if ((s + 1) * kStageRowsKm > k) {   // wave-uniform: rows >= k (operand padding) exist in the last stage only
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                  if (crow0 + (r & 3) + 8 * (r >> 2) >= k) v[r] = -__builtin_inff();
-              }
               float hi8[8], lo8[8];
 #pragma unroll
               for (int i = 0; i < 8; ++i) {
@@ -289,15 +293,14 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
                   lo8[i] = __builtin_fmaxf(__builtin_fmaxf(lo8[i], lo8[i + w]), __builtin_fminf(a1, b1));
                   hi8[i] = __builtin_fmaxf(a1, b1);
                 }
-              const float m1 = hi8[0], m2 = lo8[0];
-              second_s[blk] = __builtin_fmaxf(__builtin_fmaxf(second_s[blk], m2), __builtin_fminf(best_s[blk], m1));
-              if (__any(m1 > best_s[blk])) {
-                int first = 0;
+              const float m2 = lo8[0];   // (hi8[0] == m)
+              int first = 0;
 #pragma unroll
-                for (int r = 15; r >= 0; --r) first = v[r] == m1 ? crow0 + (r & 3) + 8 * (r >> 2) : first;
-                best_i[blk] = m1 > best_s[blk] ? first : best_i[blk];
-              }
-              best_s[blk] = __builtin_fmaxf(best_s[blk], m1);
+              for (int r = 15; r >= 0; --r) first = v[r] == m ? crow0 + (r & 3) + 8 * (r >> 2) : first;
+              const bool lead = m > best_s[blk];   // strict: an equal score in a later unit stays the runner-up
+              second_s[blk] = lead ? __builtin_fmaxf(second_s[blk], m2) : second_s[blk];
+              best_i[blk] = lead ? first : best_i[blk];
+              best_s[blk] = __builtin_fmaxf(best_s[blk], m);
             }
           } else if (__any(m > best_s[blk])) {
 #pragma unroll
