@@ -104,6 +104,44 @@ __global__ void prep_centroids(const float* __restrict__ c, int k, int k_pad, in
   }
 }
 
+// ds_read_b128 and its counted wait as inline assembly: hipcc sinks every fragment load of a unit to its use, into ONE
+// register, and waits lgkmcnt(0) in front of each pair of MFMAs -- an LDS round trip per k-step, which two waves per SIMD do
+// not cover.  A read issued this way is invisible to the compiler's wait insertion; lds_landed<N>() names the fragment it
+// retires (reads return in order: N younger ones may still be in flight), so its use is ordered after the wait.
+template <int IMM>
+__device__ __forceinline__ f16x8 lds_read128(unsigned addr) {
+  f16x8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(IMM) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_landed(f16x8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N) : "memory");
+}
+// the k-steps of one unit: every fragment requested up front, each MFMA pair behind the wait for its own fragment
+template <int J, int STEPS, bool L2>
+struct UnitSteps {
+  static __device__ __forceinline__ void read(f16x8 (&fa)[STEPS], unsigned addr) {
+    fa[J] = lds_read128<J * 32>(addr);
+    UnitSteps<J + 1, STEPS, L2>::read(fa, addr);
+  }
+  static __device__ __forceinline__ void run(f16x8 (&fa)[STEPS], const f16x8 (&qf)[2][8], const f16x8& ones, f32x16 (&acc)[2]) {
+    constexpr bool norm_step = J == STEPS - 1;
+    lds_landed<(STEPS - 1 - J < 15 ? STEPS - 1 - J : 15)>(fa[J]);   // (the counter holds 15: a stricter wait for the first of 17)
+    if (!norm_step || L2) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+        acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[J], norm_step ? ones : qf[blk][J & 7], acc[blk], 0, 0, 0);
+    }
+    UnitSteps<J + 1, STEPS, L2>::run(fa, qf, ones, acc);
+  }
+};
+template <int STEPS, bool L2>
+struct UnitSteps<STEPS, STEPS, L2> {
+  static __device__ __forceinline__ void read(f16x8 (&)[STEPS], unsigned) {}
+  static __device__ __forceinline__ void run(f16x8 (&)[STEPS], const f16x8 (&)[2][8], const f16x8&, f32x16 (&)[2]) {}
+};
+
 // MODE_FULL: the assignment at full precision (hi + lo + norm: 17 k-steps) of points [0, n).
 // MODE_NOMINATE: hi + norm only (9 k-steps).  A centroid's score is then off by x.c_lo, at most |x| max|c_lo| in size, so
 //   the best centroid of this pass is THE best one whenever it leads the runner-up by more than twice that (+ a generous
@@ -133,6 +171,7 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
   constexpr int kPiecesPerWave = (kStagePieces + kAssignWaves - 1) / kAssignWaves;  // 5 (3)
   __shared__ __attribute__((aligned(16))) char lds[kRing * kStageB];
   const char* stream_op = MODE == MODE_NOMINATE ? op_hi : op;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
@@ -240,23 +279,14 @@ __global__ __launch_bounds__(kAssignThreads) void kmeans_assign(const _Float16* 
     for (int s = 0; s < nstages; ++s) {
       publish(s + kRing - 2 < nstages);   // (near the end fewer stages are in flight: wait for all)
       if (s + kRing - 1 < nstages) issue_stage(s + kRing - 1);
-      const char* buf = lds + (s & (kRing - 1)) * kStageB;
 #pragma unroll
       for (int sub = 0; sub < kStageRowsKm / 32; ++sub) {
         const int row = sub * 32 + li;
-        const char* rbase = buf + row * kRowB;
         f32x16 acc[2] = {{0}, {0}};
-#pragma unroll
-        for (int j = 0; j < kSteps; ++j) {
-          const bool norm_step = j == kSteps - 1;
-          if (norm_step && !L2) continue;
-          const f16x8 a = *(const f16x8*)(rbase + (2 * j + half) * 16);
-#pragma unroll
-          for (int blk = 0; blk < 2; ++blk) {
-            const f16x8 b = norm_step ? ones : qf[blk][j & 7];
-            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[blk], 0, 0, 0);
-          }
-        }
+        f16x8 fa[kSteps];
+        const unsigned frag_addr = lds0 + (unsigned)((s & (kRing - 1)) * kStageB + row * kRowB + half * 16);
+        UnitSteps<0, kSteps, L2>::read(fa, frag_addr);
+        UnitSteps<0, kSteps, L2>::run(fa, qf, ones, acc);
         const int crow0 = s * kStageRowsKm + sub * 32 + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
