@@ -51,5 +51,42 @@ while time.time() < t_end:
     if not ((cnt.cpu().numpy() == cn).all() and (cg.cpu().numpy() == ref).all()):
         print(f"UPDATE MISMATCH n={n} k={k} seed={seed}")
         sys.exit(1)
+    # float data through the two-pass assignment (hi-only nomination + full precision for the undecided): labels may differ from
+    # the float64 oracle only where its two best centroids are closer than fp32 round-off; then a Lloyd step (update, hinted
+    # assignment in the update's sorted order) against an unhinted assignment on a fresh handle: identical labels
+    if n >= 64 and k >= 2:
+        centers = rng.standard_normal((k, 128)).astype(np.float32) * np.float32(rng.choice([0.05, 1.0, 8.0]))
+        if k > 4:
+            centers[1::2] = centers[0::2][: len(centers[1::2])] * np.float32(1 + 1e-4)      # twins a few fp16 ulps apart
+        xs = (centers[rng.integers(0, k, n)] + np.float32(rng.choice([0.01, 0.3])) * rng.standard_normal((n, 128))).astype(np.float16)
+        tx = torch.from_numpy(xs).to(dev)
+        tc = torch.from_numpy(centers).to(dev)
+        def assign(handle, cen, hint=None):
+            lab = torch.empty(n, dtype=torch.int32, device=dev); dist = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(lib.proqa_kmeans_assign_hinted_device(handle, tx.data_ptr(), n, cen.data_ptr(), 1 if l2 else 0,
+                                                             hint.data_ptr() if hint is not None else None, lab.data_ptr(),
+                                                             dist.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            return lab, dist
+        h1, h2 = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.proqa_kmeans_create(128, n, k, ctypes.byref(h1)))
+        _lib.check(lib.proqa_kmeans_create(128, n, k, ctypes.byref(h2)))
+        lab, dist = assign(h1, tc)
+        x64, c64 = xs.astype(np.float64), centers.astype(np.float64)
+        sc = x64 @ c64.T - (0.5 * (c64 * c64).sum(1) if l2 else 0.0)
+        got = lab.cpu().numpy()
+        best = sc.max(1)
+        lost = best - sc[np.arange(n), got]
+        if (lost > 1e-3 * (1 + np.abs(best))).any():
+            print(f"FLOAT ASSIGN MISMATCH n={n} k={k} l2={l2} seed={seed} worst {lost.max()}")
+            sys.exit(1)
+        c1 = tc.clone(); cnt = torch.zeros(k, dtype=torch.int32, device=dev)
+        _lib.check(lib.proqa_kmeans_update_device(h1, tx.data_ptr(), n, lab.data_ptr(), c1.data_ptr(), cnt.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream))
+        a1, _ = assign(h1, c1, lab)
+        a2, _ = assign(h2, c1)
+        if not torch.equal(a1, a2):
+            print(f"HINTED ASSIGN MISMATCH n={n} k={k} l2={l2} seed={seed}: {(a1 != a2).sum().item()} labels differ")
+            sys.exit(1)
+        lib.proqa_kmeans_free(h1); lib.proqa_kmeans_free(h2)
     n_cases += 1
 print(f"kmeans fuzz ok: {n_cases} cases in {budget:.0f} s (seed {seed})")
