@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROQA_ABI_VERSION 4
+#define PROQA_ABI_VERSION 5
 
 /* element types of embedding matrices (the .npy index is '<f2' under --fp16, else '<f4':
  * retrieval/get_embed.py:139) */
@@ -423,6 +423,8 @@ int proqa_microbench_stream(void* buf_dev, size_t bytes, int kind, int reps, voi
 /* launches of about ms_target milliseconds; zero_operands != 0 feeds all-zero inputs (the sustained clock depends on
  * the operand bits).  Dense TFLOP/s. */
 int proqa_microbench_mfma(double ms_target, int zero_operands, void* stream, double* tflops);
+/* the same loop on v_mfma_i32_32x32x32_i8 (the nomination scan's instruction); dense TOP/s */
+int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, double* tops);
 
 #ifdef __cplusplus
 }

@@ -147,6 +147,7 @@ SIGNATURES = {
     "proqa_topk_merge_gathered_device": (c_int, [c_void_p, c_int, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "proqa_microbench_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "proqa_microbench_mfma": (c_int, [ctypes.c_double, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "proqa_microbench_mfma_i8": (c_int, [ctypes.c_double, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lock = threading.Lock()
@@ -207,7 +208,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.proqa_abi_version() != 4:
+        if lib.proqa_abi_version() != 5:
             raise RuntimeError("libproqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
         return lib

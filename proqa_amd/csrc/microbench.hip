@@ -71,6 +71,29 @@ __global__ __launch_bounds__(256) void mfma_loop(int iters, int zero, float* __r
   if (t == 1.2345e-30f) *sink = t;
 }
 
+// the same loop on the int8 matrix instruction (v_mfma_i32_32x32x32_i8: twice the k of the fp16 form per issue)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_loop_i8(int iters, int zero, int* __restrict__ sink) {
+  i32x4 a, b;
+  for (int e = 0; e < 4; ++e) {
+    const unsigned h = (threadIdx.x * 2654435761u + e * 40503u + blockIdx.x * 97u);
+    a[e] = zero ? 0 : (int)(h * 2246822519u);          // four random int8 per register
+    b[e] = zero ? 0 : (int)(h * 3266489917u + 12345u);
+  }
+  i32x16 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c3, 0, 0, 0);
+  }
+  const i32x16 s = c0 + c1 + c2 + c3;
+  int t = 0;
+  for (int e = 0; e < 16; ++e) t += s[e];
+  if (t == 0x12345678) *sink = t;
+}
+
 }  // namespace
 }  // namespace proqa
 
@@ -140,6 +163,36 @@ int proqa_microbench_mfma(double ms_target, int zero_operands, void* stream, dou
   (void)hipEventDestroy(e1);
   const double flops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*chains*/ * 2.0 * 32 * 32 * 16;
   *tflops = flops / (best * 1e-3) / 1e12;
+  return PROQA_OK;
+}
+
+// the int8 rate of the same kind of loop (the nomination scan's instruction).  Result in TOP/s (2 x MAC).
+int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, double* tops) {
+  if (!tops || !(ms_target > 0)) return fail(PROQA_EINVAL, "microbench_mfma_i8: bad argument");
+  hipStream_t st = as_stream(stream);
+  hipEvent_t e0, e1;
+  PROQA_HIP(hipEventCreate(&e0));
+  PROQA_HIP(hipEventCreate(&e1));
+  int* sink = nullptr;
+  PROQA_HIP(hipMalloc((void**)&sink, 4));
+  const unsigned grid = (unsigned)device_cu_count() * 2;
+  int iters = (int)(ms_target * 1e-3 * 2.4e9 / (4 * 2 * 32));
+  if (iters < 64) iters = 64;
+  float best = 1e30f;
+  for (int r = 0; r < 4; ++r) {
+    PROQA_HIP(hipEventRecord(e0, st));
+    hipLaunchKernelGGL(mfma_loop_i8, dim3(grid), dim3(256), 0, st, iters, zero_operands, sink);
+    PROQA_HIP(hipEventRecord(e1, st));
+    PROQA_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PROQA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  (void)hipFree(sink);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const double ops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*chains*/ * 2.0 * 32 * 32 * 32;
+  *tops = ops / (best * 1e-3) / 1e12;
   return PROQA_OK;
 }
 

@@ -109,7 +109,53 @@ struct MergeArgs {
   float* tau_filter;             // [nq_pad] threshold of the next filter launch
   unsigned long long* dbg;       // developer build (PROQA_MERGE_STAMPS): [nq_pad, 8] s_memtime stamps of the phases, or NULL
   int compact;                   // the launch logged compact lists (FilterArgs::compact)
+  // int8 nomination rounds (all NULL otherwise): the records hold int32 scores and the integer threshold they were tested
+  // against; every score above it names a row that is re-scored from xb16 against xq16 on the filter's MFMA sequence
+  const void* xq16;              // fp16 [nq_pad,128] padded queries
+  const char* xb16;              // fp16 corpus rows of this shard
+  unsigned long long* stat_nominated;  // [nq_pad] rows re-scored per query (statistics)
 };
+
+// ---- int8 nomination scan (the k <= kPageK rounds of an fp16 index; see "int8 nomination" in mips_kernels.hip) ----------
+// An int8 copy of the centred, per-dimension-scaled rows is scanned on v_mfma_i32_32x32x32_i8 (twice the fp16 rate, exact
+// i32 sums); a row is NOMINATED when its integer score exceeds the query's running threshold lowered by a rigorous bound on
+// the quantisation error; the merge re-scores the nominated rows from the fp16 rows with the filter's own MFMA sequence
+// (bit-identical scores) and keeps those that beat the exact threshold.
+constexpr int kStageBytesI8 = kStageRows * kDim;   // 16 KiB: a 128-row stage of int8 rows
+struct NominateParams {     // per query, written by prep_queries_i8
+  float off;                // q . mean (the centring constant of this query's scores)
+  float inv_unit;           // 1 / s_q: integer score units per score unit
+  float margin;             // bound on |exact score - off - s_q * integer score| in integer units, all slack included
+  float pad;
+};
+static_assert(sizeof(NominateParams) == 16, "one 16-byte load per lane");
+struct QuantStats {         // device words maintained by the quantisation passes (floats as bits: atomicMax on non-negatives)
+  unsigned max_resid;       // R  = max over rows of ||127 (x - mean) / c - xi||
+  unsigned max_inorm;       // Xn = max over rows of ||xi||
+  unsigned max_xnorm;       // Xf = max over rows of ||x|| (fp16 rows)
+  unsigned nonfinite;       // rows or statistics that are not finite: the scan is not used
+};
+struct FilterArgsI8 {
+  const signed char* xq8;   // int8 [nq_pad,128] queries (prep_queries_i8), zero rows beyond nq
+  const signed char* xb8;   // int8 corpus rows of this shard
+  long long slab_row0;
+  long long slab_row1;
+  int rows_per_chunk;       // multiple of kStageRows
+  const float* tau;         // exact running k-th best score per query (+inf: padding / exhausted, -inf: fewer than k rows yet)
+  const NominateParams* qp; // [nq_pad]
+  CandidateStore store;     // column records whose scores / threshold words are int32
+  unsigned* overflow;
+};
+hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st);
+// column statistics of fp16 rows [0, n): partial[g][0..127] sums, [g][128..255] minima, [g][256..383] maxima per workgroup g
+// (deterministic two-level reduction), then mean / scale per dimension: col[0..127] mean, col[128..255] 127 / c, col[256..383] c / 127
+constexpr int kColStatGroups = 1024;
+hipError_t launch_column_stats(const void* xb16, long long n, float* partial, float* col, QuantStats* stats, hipStream_t st);
+// xi = clamp(rint((x - mean) * 127 / c)), and the three maxima of QuantStats
+hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, QuantStats* stats, hipStream_t st);
+// int8 queries + NominateParams of every padded query (fp16 padded queries in, as the filter reads them)
+hipError_t launch_prep_queries_i8(const void* xq_pad16, long long nq_pad, const float* col, const QuantStats* stats,
+                                  signed char* xq8, NominateParams* qp, hipStream_t st);
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);
 #ifdef PROQA_FILTER_STAMPS
@@ -142,6 +188,7 @@ constexpr int kOverflowWords = 96;   // = kMaxRounds of mips_index.cpp
 struct SearchMirror {
   unsigned overflow[kOverflowWords];
   unsigned long long candidates;
+  unsigned long long nominated;   // rows the int8 rounds re-scored, summed over the queries (0 for an fp16 search)
 };
 // writes page results: D/I[q * out_stride + out_offset + j], j < page_k.  overflow: the kOverflowWords round words (device);
 // status (optional device word) = 1 if any is set, else 0; mirror (optional, pinned host memory) receives the words and the
@@ -149,7 +196,7 @@ struct SearchMirror {
 hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                            long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
                            const unsigned* overflow, unsigned* status, SearchMirror* mirror, const unsigned long long* stat,
-                           hipStream_t st);
+                           hipStream_t st, const unsigned long long* stat_nominated = nullptr);
 // part p's [nq, k] scores / ids start stride_d / stride_i ELEMENTS after part p-1's (nq*k for dense [n_parts, nq, k] arrays);
 // status_host (optional, pinned host memory, n_parts words) receives status_src[p * status_stride] of every part
 // (also when nq == 0).  parts_sorted: every part is a list as a search reports it (scores descending, ties by ascending id,
