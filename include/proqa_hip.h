@@ -139,6 +139,9 @@ typedef struct proqa_search_stats {
   float filter_ms;           /* HIP-event time of the mips_filter launches, summed over the
                                 rounds (0 unless profiling is enabled on the handle) */
   float total_ms;            /* HIP-event time of the whole search on the stream */
+  int64_t nominated;         /* rows the int8 nomination rounds handed to the exact re-scoring (0 for an fp16 scan) */
+  int32_t nomination;        /* 1 if the rounds of this search scanned the int8 copy of the rows, else 0 */
+  int32_t reserved;
 } proqa_search_stats;
 int proqa_index_last_stats(const proqa_index* idx, proqa_search_stats* out);
 /* bracket every mips_filter launch with HIP events on the search stream (bench.py roofline) */
@@ -150,6 +153,14 @@ int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth);
  * a multiple of 32 up to 8192, 0 disables it.  Used for k <= rows/4 (at most 256) on indexes of >= 4*rows rows;
  * the result never depends on it.  Default 4096. */
 int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
+/* The int8 nomination scan of the k <= 128 rounds (batches of more than 256 queries, fp16 indexes of >= 65536 rows): the
+ * rounds scan an int8 copy of the centred, per-dimension-scaled rows at twice the fp16 MFMA rate, nominate every row whose
+ * integer score exceeds the running threshold lowered by a rigorous bound on the quantisation error, and re-score the
+ * nominated rows from the fp16 rows -- the result is the fp16 scan's, bit for bit.  mode 0: never (fp16 scan);
+ * 1 (default): unless the first such search shows that the data does not quantise (then fp16 until the rows change);
+ * 2: always.  The copy (+128 B per row) is built by the first search that uses it.  Rows adopted with
+ * proqa_index_adopt_device must not be modified while the index holds them. */
+int proqa_index_configure_nomination(proqa_index* idx, int mode);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
  * (the layout an RCCL all-gather of per-rank [nq, k] produces); every list as a search reports it (scores descending,

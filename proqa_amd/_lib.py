@@ -33,7 +33,8 @@ class ProqaError(RuntimeError):
 
 class SearchStats(ctypes.Structure):
     _fields_ = [("rounds", ctypes.c_int32), ("fallback_rounds", ctypes.c_int32),
-                ("candidates", ctypes.c_int64), ("filter_ms", c_float), ("total_ms", c_float)]
+                ("candidates", ctypes.c_int64), ("filter_ms", c_float), ("total_ms", c_float),
+                ("nominated", ctypes.c_int64), ("nomination", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class BertLayer(ctypes.Structure):
@@ -87,6 +88,7 @@ SIGNATURES = {
     "proqa_index_last_stats": (c_int, [c_void_p, ctypes.POINTER(SearchStats)]),
     "proqa_index_set_profiling": (c_int, [c_void_p, c_int]),
     "proqa_index_configure": (c_int, [c_void_p, c_int, c_int]),
+    "proqa_index_configure_nomination": (c_int, [c_void_p, c_int]),
     "proqa_index_configure_bootstrap": (c_int, [c_void_p, c_int]),
     "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p]),

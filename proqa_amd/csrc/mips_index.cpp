@@ -89,6 +89,22 @@ struct proqa_index {
   size_t boot_floats = 0;
   int bootstrap_rows = 4096;               // 0 disables it
   bool bootstrap_auto = true;              // not configured by the caller: 8192 rows where that saves candidates (page_enqueue)
+  // int8 nomination scan (mips_kernels.hip): an int8 copy of the centred, per-dimension-scaled rows, built lazily by the first
+  // search that can use it and rebuilt when the rows changed (rows_epoch); the fp16 rows stay the data every score comes from
+  signed char* xb8 = nullptr;
+  int64_t capacity8 = 0;
+  float* col = nullptr;                    // device [3][128]: mean, 127 / c, c / 127
+  float* col_partial = nullptr;            // device [kColStatGroups][3][128]
+  proqa::QuantStats* qstats = nullptr;     // device
+  uint64_t rows_epoch = 1;                 // bumped by every change of the rows
+  uint64_t q8_epoch = 0;                   // rows_epoch the int8 copy was built for (0: never)
+  bool q8_usable = false;                  // that copy can be scanned (finite statistics)
+  bool q8_unprofitable = false;            // a search on this copy nominated far too many rows: fp16 scan until the rows change
+  int nominate_mode = 1;                   // 0 off, 1 automatic, 2 always (no profitability check); proqa_index_configure_nomination
+  bool q8_active = false;                  // the search being enqueued runs its rounds on the int8 copy
+  signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
+  proqa::NominateParams* qparams = nullptr;   // workspace [ws_nq_pad]
+  unsigned long long* stat_nom = nullptr;  // workspace [ws_nq_pad] rows re-scored per query
   // tuning
   int first_slab_rows = 256;
   int growth = 0;                          // 0 = automatic (see growth_for)
@@ -211,6 +227,43 @@ int ensure_stage(proqa_index* idx, size_t bytes) {
   return PROQA_OK;
 }
 
+// The int8 copy of the rows for the nomination scan, (re)built when the rows changed since it was made: column statistics
+// (two launches), the quantisation pass, one host read of the statistics word.  18M rows: ~3 passes over 4.6 GB.
+constexpr int64_t kNominateMinRows = 65536;   // smaller shards are launch-bound either way
+constexpr int kNominateMaxK = 128;            // nominations of a round (~3 x its candidates) must fit one merge
+constexpr unsigned kNominateLaneCap = 32;     // records per lane list of an int8 round (no spill log: a full list re-scans the round)
+int ensure_q8(proqa_index* idx, hipStream_t st) {
+  if (idx->q8_epoch == idx->rows_epoch) return PROQA_OK;
+  idx->q8_usable = false;
+  idx->q8_unprofitable = false;
+  if (!idx->col) {
+    PROQA_HIP(hipMalloc((void**)&idx->col, 3 * kDim * sizeof(float)));
+    PROQA_HIP(hipMalloc((void**)&idx->col_partial, (size_t)kColStatGroups * 3 * kDim * sizeof(float)));
+    PROQA_HIP(hipMalloc((void**)&idx->qstats, sizeof(QuantStats)));
+  }
+  if (idx->n > idx->capacity8) {
+    PROQA_HIP(hipStreamSynchronize(st));
+    if (idx->xb8) PROQA_HIP(hipFree(idx->xb8));
+    idx->xb8 = nullptr;
+    idx->capacity8 = 0;
+    const int64_t cap = round_up<int64_t>(std::max(idx->n, idx->capacity), kStageRows);
+    if (try_malloc((void**)&idx->xb8, (size_t)cap * kDim) != hipSuccess) {
+      idx->q8_epoch = idx->rows_epoch;   // no room for the copy: this index is searched on its fp16 rows
+      return PROQA_OK;
+    }
+    idx->capacity8 = cap;
+  }
+  PROQA_HIP(hipMemsetAsync(idx->qstats, 0, sizeof(QuantStats), st));
+  PROQA_HIP(launch_column_stats(idx->xb, idx->n, idx->col_partial, idx->col, idx->qstats, st));
+  PROQA_HIP(launch_quantise_rows_i8(idx->xb, idx->n, idx->col, idx->xb8, idx->qstats, st));
+  QuantStats h;
+  PROQA_HIP(hipMemcpyAsync(&h, idx->qstats, sizeof h, hipMemcpyDeviceToHost, st));
+  PROQA_HIP(hipStreamSynchronize(st));
+  idx->q8_epoch = idx->rows_epoch;
+  idx->q8_usable = h.nonfinite == 0u && h.max_inorm != 0u;   // (all rows equal to the mean: nothing to scan for)
+  return PROQA_OK;
+}
+
 constexpr int64_t kAddPieceRows = 1 << 20;   // rows per upload piece of proqa_index_add (256 MiB of fp16 rows)
 constexpr int kLoaderSlots = 4;               // pinned pieces of proqa_index_add_npy: two being read, two on their way up
 // pieces of 4 .. 64 MiB and 2 .. 8 readers all reach 31-34 GB/s from a warm page cache (profiles/r04_loader_timing.txt)
@@ -290,7 +343,10 @@ void free_store(proqa_index* idx) {
 
 void free_workspace(proqa_index* idx) {
   void* ptrs[] = {idx->xq_pad, idx->tau, idx->run_n, idx->run_keys, idx->stat_dev, idx->bound_keys, idx->ub, idx->done,
-                  idx->xq32, idx->margin, idx->tau_filter, idx->ub_filter};
+                  idx->xq32, idx->margin, idx->tau_filter, idx->ub_filter, idx->xq8, idx->qparams, idx->stat_nom};
+  idx->xq8 = nullptr;
+  idx->qparams = nullptr;
+  idx->stat_nom = nullptr;
   idx->xq32 = nullptr;
   idx->margin = nullptr;
   idx->tau_filter = nullptr;
@@ -327,6 +383,9 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
   PROQA_HIP(hipMalloc((void**)&idx->margin, (size_t)q * sizeof(float)));
   PROQA_HIP(hipMalloc((void**)&idx->tau_filter, (size_t)q * sizeof(float)));
   PROQA_HIP(hipMalloc((void**)&idx->ub_filter, (size_t)q * sizeof(float)));
+  PROQA_HIP(hipMalloc((void**)&idx->xq8, (size_t)q * kDim));
+  PROQA_HIP(hipMalloc((void**)&idx->qparams, (size_t)q * sizeof(NominateParams)));
+  PROQA_HIP(hipMalloc((void**)&idx->stat_nom, (size_t)q * sizeof(unsigned long long)));
   idx->ws_nq_pad = q;
   idx->ws_k = kk;
   return PROQA_OK;
@@ -484,6 +543,66 @@ struct RoundShape {
 int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
               bool inclusive, bool dense, bool bounded, unsigned* overflow_word, hipStream_t st, hipEvent_t f0,
               hipEvent_t f1, const RoundShape& shape = RoundShape()) {
+  // rounds of the plain search (strict threshold, first page, not dense, no shape of its own) scan the int8 copy when the
+  // search was set up for it: two workgroups per CU, deep lane lists instead of a spill log
+  const bool nominate = idx->q8_active && !inclusive && !dense && !bounded && !shape.want_chunks && !shape.compact;
+  if (nominate) {
+    const unsigned want = std::max<unsigned>(64u, (unsigned)(2 * device_cu_count() / (int)n_qtiles) / 8 * 8);
+    const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, false, k, want);
+    if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, kNominateLaneCap)) return rc;
+    FilterArgsI8 fa;
+    fa.xq8 = idx->xq8;
+    fa.xb8 = idx->xb8;
+    fa.slab_row0 = slab.r0;
+    fa.slab_row1 = slab.r1;
+    fa.rows_per_chunk = g.rows_per_chunk;
+    fa.tau = idx->tau;
+    fa.qp = idx->qparams;
+    fa.store = store_of(idx, nq_pad, n_qtiles, kNominateLaneCap, round_up<unsigned>(g.chunks, 8));
+    fa.overflow = overflow_word;
+    if (f0) PROQA_HIP(hipEventRecord(f0, st));
+    PROQA_HIP(launch_filter_i8(fa, qw, g.grid, st));
+    if (f1) PROQA_HIP(hipEventRecord(f1, st));
+    MergeArgs ma = {};
+    ma.store = fa.store;
+    ma.n_chunks = g.chunks;
+    ma.qw = (unsigned)qw;
+    ma.run_keys = idx->run_keys;
+    ma.run_n = idx->run_n;
+    ma.tau = idx->tau;
+    ma.k = k;
+    ma.sort_cap = sort_capacity(k);
+    ma.stat_candidates = idx->stat_dev;
+    ma.overflow = overflow_word;
+    ma.xq16 = idx->xq_pad;
+    ma.xb16 = idx->xb;
+    ma.stat_nominated = idx->stat_nom;
+    PROQA_HIP(launch_merge(ma, nq_pad, st));
+    if (kDebugCand) {   // developer: records the scan logged / rows the merges re-scored so far / candidates so far
+      (void)hipStreamSynchronize(st);
+      const size_t n_cnt = (size_t)nq_pad * fa.store.n_chunks * 2;
+      std::vector<unsigned> cnt(n_cnt);
+      (void)hipMemcpy(cnt.data(), idx->lane_cnt, n_cnt * sizeof(unsigned), hipMemcpyDeviceToHost);
+      unsigned long long recs = 0, fullest = 0;
+      for (unsigned v : cnt) {
+        recs += v;
+        fullest = std::max<unsigned long long>(fullest, v);
+      }
+      std::vector<unsigned long long> nomv(nq_pad), candv(nq_pad);
+      (void)hipMemcpy(nomv.data(), idx->stat_nom, nq_pad * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(candv.data(), idx->stat_dev, nq_pad * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+      unsigned long long nom = 0, cand = 0;
+      for (unsigned q = 0; q < nq_pad; ++q) {
+        nom += nomv[q];
+        cand += candv[q];
+      }
+      fprintf(stderr, "int8 round rows [%lld, %lld): %u chunks x %d rows, %llu records logged (fullest list %llu of %u), cumulative nominated %llu, "
+              "cumulative candidates %llu; nominated q0..7:", slab.r0, slab.r1, g.chunks, g.rows_per_chunk, recs, fullest, kNominateLaneCap, nom, cand);
+      for (unsigned q = 0; q < 8 && q < nq_pad; ++q) fprintf(stderr, " %llu", nomv[q]);
+      fprintf(stderr, "\n");
+    }
+    return PROQA_OK;
+  }
   const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, dense, k, shape.want_chunks);
   const unsigned lane_cap = shape.lane_cap ? shape.lane_cap : lane_capacity(k);
   if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, lane_cap)) return rc;
@@ -523,6 +642,9 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.tau_filter = idx->exact ? idx->tau_filter : nullptr;
   ma.dbg = nullptr;
   ma.compact = shape.compact ? 1 : 0;
+  ma.xq16 = nullptr;
+  ma.xb16 = nullptr;
+  ma.stat_nominated = nullptr;
 #ifdef PROQA_MERGE_STAMPS
   {
     static unsigned long long* dbg_buf = nullptr;
@@ -645,7 +767,8 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
   // (the finalize kernel also writes the overflow words and the candidate count into the pinned mirror and the status
   // word: no copy command between the search and what the caller enqueues behind it)
   PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, out.idx_offset, out.D, out.I, out.out_stride,
-                            out.out_offset, idx->overflow, status_dev, idx->mirror, idx->stat_dev, st));
+                            out.out_offset, idx->overflow, status_dev, idx->mirror, idx->stat_dev, st,
+                            idx->q8_active ? idx->stat_nom : nullptr));
   PROQA_HIP(hipEventRecord(idx->ev[1], st));
   return PROQA_OK;
 }
@@ -696,7 +819,8 @@ int page_complete(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64
   }
   if (*fallback_out != fallback_before) {
     PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, page_k, out.idx_offset, out.D, out.I, out.out_stride,
-                              out.out_offset, idx->overflow, nullptr, idx->mirror, idx->stat_dev, st));
+                              out.out_offset, idx->overflow, nullptr, idx->mirror, idx->stat_dev, st,
+                              idx->q8_active ? idx->stat_nom : nullptr));
     PROQA_HIP(hipEventRecord(idx->ev[1], st));
     PROQA_HIP(hipStreamSynchronize(st));
   }
@@ -945,6 +1069,18 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   return one_pass_big_launch(idx, pl, shape, qw, n_qtiles, nq, nq_pad, k, out, st, (int)slabs.size(), done);
 }
 
+// after the host sync of a search whose rounds ran on the int8 copy: statistics, and the profitability check -- a corpus
+// whose scores the eight bits cannot separate (nominations per query and row far above what pays for the halved scan) goes
+// back to the fp16 scan until its rows change.  Exactness never depends on this: every nominated row is re-scored.
+void note_nomination(proqa_index* idx, int64_t nq) {
+  if (!idx->q8_active) return;
+  idx->q8_active = false;
+  idx->stats.nomination = 1;
+  idx->stats.nominated = (int64_t)idx->mirror->nominated;
+  const double per_query = (double)idx->stats.nominated / (double)std::max<int64_t>(nq, 1);
+  if (per_query > std::max(4096.0, (double)idx->n / 2048.0) || idx->stats.fallback_rounds > 0) idx->q8_unprofitable = true;
+}
+
 int finish_pending(proqa_index* idx, int* rewritten);
 int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset, float* D_dev,
                        int64_t* I_dev, hipStream_t st, bool defer, uint32_t* status_dev);
@@ -978,6 +1114,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "search: bad dtype %d", dtype);
   if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
   idx->stats = {};
+  idx->q8_active = false;
   if (nq == 0) return PROQA_OK;
   PROQA_ON_DEVICE(idx->device);
 
@@ -1028,6 +1165,17 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
     }
     return PROQA_OK;
   };
+  // The rounds of a one-page search of an fp16 index scan the int8 copy of the rows (nomination + exact re-scoring, see
+  // mips_kernels.hip) when the batch is MFMA-bound, k small enough for a round's nominations to fit its merge and the
+  // shard large enough to matter.  Called after prep_first (it reads the padded fp16 queries).
+  auto setup_nominate = [&]() -> int {
+    if (idx->nominate_mode == 0 || idx->exact || k > kNominateMaxK || qw != 2 || idx->n < kNominateMinRows) return PROQA_OK;
+    if (int rc = ensure_q8(idx, st)) return rc;
+    if (!idx->q8_usable || (idx->q8_unprofitable && idx->nominate_mode != 2)) return PROQA_OK;
+    PROQA_HIP(launch_prep_queries_i8(idx->xq_pad, idx->ws_nq_pad, idx->col, idx->qstats, idx->xq8, idx->qparams, idx->stat_nom, st));
+    idx->q8_active = true;
+    return PROQA_OK;
+  };
   // ~670 <= k <= ~11700 on a shard much larger than k: one pass against sampled thresholds (search_one_pass)
   if (one_pass.use) {
     if (int rc = prep_first()) return rc;
@@ -1052,6 +1200,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
     if (idx->exact)
       PROQA_HIP(launch_query_margins(xq_dev, dtype, nq, idx->ws_nq_pad, idx->norm_stats, idx->xq32, idx->margin,
                                      idx->tau, idx->tau_filter, st));
+    if (int rc = setup_nominate()) return rc;
     PagePlan plan;
     if (int rc = page_enqueue(idx, qw, n_qtiles, nq, nq_pad, k, false, PageOut{D_dev, (long long*)I_dev, idx_offset, k, 0}, st, true,
                               &plan, status_dev))
@@ -1078,6 +1227,8 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
     const int page_k = std::min(page_size, k - p * page_size);
     if (p == 0) {
       if (int rc = prep_first()) return rc;
+      if (n_pages == 1 && !fallback)
+        if (int rc = setup_nominate()) return rc;
     } else {
       PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
                                     idx->done, false, nullptr, idx->overflow, st));
@@ -1105,6 +1256,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   idx->stats.fallback_rounds = fallback;
   idx->stats.candidates += (int64_t)idx->mirror->candidates;
   (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
+  note_nomination(idx, nq);
   return PROQA_OK;
 }
 
@@ -1134,6 +1286,7 @@ int finish_pending(proqa_index* idx, int* rewritten) {
   idx->stats.fallback_rounds = fallback;
   idx->stats.candidates += (int64_t)idx->mirror->candidates;
   (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
+  note_nomination(idx, pe.nq);
   if (rewritten) *rewritten = fallback != 0;
   return PROQA_OK;
 }
@@ -1193,6 +1346,10 @@ int proqa_index_free(proqa_index* idx) {
   if (idx->mirror) (void)hipHostFree(idx->mirror);
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
   if (idx->boot_scores) (void)hipFree(idx->boot_scores);
+  if (idx->xb8) (void)hipFree(idx->xb8);
+  if (idx->col) (void)hipFree(idx->col);
+  if (idx->col_partial) (void)hipFree(idx->col_partial);
+  if (idx->qstats) (void)hipFree(idx->qstats);
   if (idx->stage_pinned) (void)hipHostFree(idx->stage_pinned);
   if (idx->io_stream) (void)hipStreamDestroy(idx->io_stream);
   for (auto& e : idx->ev)
@@ -1211,6 +1368,7 @@ int proqa_index_reset(proqa_index* idx) {
     idx->owns_xb = true;
   }
   idx->n = 0;
+  ++idx->rows_epoch;
   idx->exact = false;   // the float32 buffer stays allocated for the next use
   return PROQA_OK;
 }
@@ -1236,6 +1394,13 @@ int proqa_index_configure_bootstrap(proqa_index* idx, int rows) {
                 kBootstrapMaxRows);
   idx->bootstrap_rows = rows;
   idx->bootstrap_auto = false;
+  return PROQA_OK;
+}
+
+int proqa_index_configure_nomination(proqa_index* idx, int mode) {
+  if (!idx) return fail(PROQA_EINVAL, "index_configure_nomination: NULL handle");
+  if (mode < 0 || mode > 2) return fail(PROQA_EINVAL, "index_configure_nomination: mode=%d (0 off, 1 automatic, 2 always)", mode);
+  idx->nominate_mode = mode;
   return PROQA_OK;
 }
 
@@ -1287,6 +1452,7 @@ int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int 
   if (int rc = finish_rows_exact(idx, idx->n, n, dtype == PROQA_F32 ? (const float*)xb_dev : nullptr, st)) return rc;
   PROQA_HIP(hipStreamSynchronize(st));
   idx->n += n;
+  ++idx->rows_epoch;
   return PROQA_OK;
 }
 
@@ -1299,6 +1465,7 @@ int proqa_index_adopt_device(proqa_index* idx, const void* xb_dev_f16, int64_t n
   idx->n = n;
   idx->capacity = n;
   idx->exact = false;
+  ++idx->rows_epoch;
   return PROQA_OK;
 }
 
@@ -1321,6 +1488,7 @@ int proqa_index_add(proqa_index* idx, const void* xb, int64_t n, int dtype) {
     }
   }
   idx->n += n;
+  ++idx->rows_epoch;
   return PROQA_OK;
 }
 
@@ -1450,6 +1618,7 @@ int proqa_index_add_npy(proqa_index* idx, const char* path, int64_t row0, int64_
   }
   PROQA_HIP(hipStreamSynchronize(st));
   idx->n += n;
+  ++idx->rows_epoch;
   return PROQA_OK;
 }
 

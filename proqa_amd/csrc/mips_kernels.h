@@ -154,8 +154,9 @@ hipError_t launch_column_stats(const void* xb16, long long n, float* partial, fl
 // xi = clamp(rint((x - mean) * 127 / c)), and the three maxima of QuantStats
 hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, QuantStats* stats, hipStream_t st);
 // int8 queries + NominateParams of every padded query (fp16 padded queries in, as the filter reads them)
+// (also zeroes stat_nom[0, nq_pad))
 hipError_t launch_prep_queries_i8(const void* xq_pad16, long long nq_pad, const float* col, const QuantStats* stats,
-                                  signed char* xq8, NominateParams* qp, hipStream_t st);
+                                  signed char* xq8, NominateParams* qp, unsigned long long* stat_nom, hipStream_t st);
 
 hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned grid, hipStream_t st);
 #ifdef PROQA_FILTER_STAMPS

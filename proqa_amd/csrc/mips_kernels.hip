@@ -478,6 +478,385 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// int8 nomination scan
+// ---------------------------------------------------------------------------------------
+// The fp16 scan above is bound by the matrix pipe (MFMA-bound from ~300 queries per corpus pass on); v_mfma_i32_32x32x32_i8
+// does the same 128-long dot products at twice the rate, exactly (i32 sums).  The rounds of a k <= kPageK search on an fp16
+// index therefore scan an int8 copy of the rows:
+//     x_d  ~ mean_d + (c_d / 127) xi_d        xi = clamp(rint(127 (x - mean) / c)),  c_d = max |x_d - mean_d| over the shard
+//     q.x  = q.mean + sum_d w_d (xi_d + r_d)  w_d = q_d c_d / 127,   r = 127 (x - mean) / c - xi        (|r_d| <= 1/2)
+//          = q.mean + s_q sum_d (qi_d + e_d) xi_d + sum_d w_d r_d     qi = rint(w / s_q), s_q = max |w| / 127, e = w / s_q - qi
+//     |q.x - q.mean - s_q acc| <= s_q (||w / s_q|| R + ||e|| Xn)       acc = sum_d qi_d xi_d (the MFMA result),
+//                                                                      R = max ||r||, Xn = max ||xi|| over the rows (Cauchy-Schwarz)
+// Centring matters: q.mean is a per-query constant that does not change the ranking, and embeddings with a large common
+// component would otherwise spend the eight bits on it (scripts/dev_int8_margin.py: 256 x k nominations uncentred, 2 x k centred
+// on the end-to-end test's corpus).  A row whose exact score (the fp16 filter's MFMA sum) beats the running threshold tau has
+// acc > (tau - q.mean) / s_q - margin, so the scan NOMINATES every row above the integer threshold T = floor(that) - 1 and
+// can miss none; the merge re-scores the nominated rows from the fp16 rows with the fp16 filter's own MFMA sequence -- the
+// same bits as the fp16 scan produces -- and everything downstream (running lists, thresholds, ties, overflow-safe path,
+// shards) works on exact scores.  Nothing here depends on the accuracy of mean / c: the residual norms are measured.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+constexpr int kRowBytesI8 = kDim;                        // 128 B per int8 corpus row
+constexpr int kSubBytesI8 = kSubRows * kRowBytesI8;      // 4 KiB: one 32-row MFMA M-tile
+
+// Plain C++ on purpose (hipcc folds it into v_max3_i32): the maximum is taken of accumulators an MFMA has just written, and
+// the wait states between a matrix instruction and a VALU read of its result are the compiler's to insert -- it does not
+// look into an inline-asm string (the asm max tree of the fp16 scan reads the PREVIOUS unit's accumulators; a first version
+// of this kernel with that tree on the fresh ones read registers the MFMA had not written yet and lost 40 % of its hits).
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int max16_i32(const i32x16& v) {
+  int m = imax(imax(v[0], v[1]), v[2]);
+#pragma unroll
+  for (int r = 3; r + 1 < 16; r += 2) m = imax(imax(m, v[r]), v[r + 1]);
+  return imax(m, v[15]);
+}
+
+// the integer threshold of a query whose exact threshold is tau: every row with exact score > tau has acc > T
+__device__ __forceinline__ int nominate_threshold(float tau, const NominateParams& p) {
+  if (!(tau > -__builtin_inff())) return (int)0x80000000;                 // fewer than k rows yet: every row is a candidate
+  if (tau == __builtin_inff()) return 0x7fffffff;                         // padding / exhausted query: never
+  float t = (tau - p.off) * p.inv_unit - p.margin;
+  t = __builtin_floorf(t - __builtin_fabsf(t) * 0x1p-20f - 1.0f);         // the roundings of this line itself
+  if (!(t > -2147483000.f)) return (int)0x80000000;                       // (also a NaN from non-finite parameters: nominate everything)
+  if (t > 2147483000.f) return 0x7ffffffe;
+  return (int)t;
+}
+
+__device__ __forceinline__ void write_record_i32(WaveRecord* dst, const i32x16& acc, unsigned q, unsigned row0, int rows_left, int thr) {
+  uint4* d = (uint4*)dst;
+  d[0] = make_uint4(q, row0, (unsigned)rows_left, (unsigned)thr);
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    d[1 + g] = make_uint4((unsigned)acc[4 * g], (unsigned)acc[4 * g + 1], (unsigned)acc[4 * g + 2], (unsigned)acc[4 * g + 3]);
+}
+
+// Same tiling as mips_filter_f16 -- 8 waves, wave w keeps its QW x 32 queries as MFMA B fragments for its lifetime, the
+// workgroup streams a contiguous chunk of rows through a four-stage LDS ring filled by LDS-DMA, each lane owns one query
+// column of the 32x32 accumulator so the test is lane-local -- with what the half-size operands change:
+//   * a stage of 128 rows is 16 KiB, the ring 64 KiB: TWO workgroups per CU, i.e. four waves per SIMD.  The matrix pipe is
+//     kept busy by the other waves of the SIMD while one wave examines its accumulators or logs a column, so the loop needs no
+//     software pipeline across units (no second accumulator set: <= 128 VGPRs);
+//   * a unit (32 rows x QW x 32 queries) is 4 QW MFMAs of 32 cycles instead of 8 QW;
+//   * rows are 128 B = 8 pieces of 16 B; piece p of row r sits at slot p ^ ((r >> 1) & 7) of its LDS row (XOR on the DMA
+//     SOURCE address, the LDS image stays lane-linear), which keeps the four lane groups of ds_read_b128 on 16 distinct
+//     16-byte bank slots each (MI355X_MICROARCH.md, LDS table);
+//   * the MFMA k-order is permuted identically on both operands (piece 2j + half at k-step j); integer sums do not depend on it.
+// A lane whose column maximum exceeds its integer threshold logs the 16 int32 scores as one 80-byte record (the format of
+// the fp16 scan, threshold word = T); a full list is reported through `overflow` (the round is then re-scanned by the fp16
+// overflow-safe path): no spill log, no capacity branch in the hit path.
+template <int QW>
+__global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8 a) {
+  static_assert(QW == 1 || QW == 2, "8 waves x 32 / 64 queries");
+  __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytesI8];
+  constexpr int NW = kFilterWaves;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31;
+  const int half = lane >> 5;
+
+  const unsigned b = blockIdx.x;
+  const unsigned xcd = b & 7u;
+  const unsigned rest = b >> 3;
+  const unsigned qt = rest % a.store.n_qtiles;
+  const unsigned grp = rest / a.store.n_qtiles;
+  const unsigned chunk = grp * 8 + xcd;
+  const long long row_begin = a.slab_row0 + (long long)chunk * a.rows_per_chunk;
+  if (row_begin >= a.slab_row1) return;
+  long long row_end = row_begin + a.rows_per_chunk;
+  if (row_end > a.slab_row1) row_end = a.slab_row1;
+  const int n_rows = (int)(row_end - row_begin);
+  const int nstages = (n_rows + kStageRows - 1) / kStageRows;
+  const unsigned row_begin32 = (unsigned)row_begin;
+  const signed char* chunk_base = a.xb8 + row_begin * kRowBytesI8;
+
+  const unsigned q0 = qt * (NW * QW * 32) + wave * (QW * 32);
+  i32x4 qf[QW][4];
+  int thr[QW];
+  WaveRecord* lane_list[QW];
+  unsigned lane_n[QW];
+  bool wave_live = false;
+#pragma unroll
+  for (int blk = 0; blk < QW; ++blk) {
+    const unsigned q = q0 + blk * 32 + li;
+    const signed char* qrow = a.xq8 + (size_t)q * kRowBytesI8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[blk][j] = *(const i32x4*)(qrow + (2 * j + half) * 16);
+    thr[blk] = nominate_threshold(a.tau[q], a.qp[q]);
+    wave_live = wave_live || thr[blk] != 0x7fffffff;
+    lane_n[blk] = 0u;
+    lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
+  }
+  wave_live = __any(wave_live);
+  const unsigned lane_cap = a.store.lane_cap;
+
+  unsigned rd_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rd_off[j] = li * kRowBytesI8 + (((2 * j + half) ^ ((li >> 1) & 7)) << 4);
+
+  // LDS-DMA: 1 KiB per wave-instruction = 8 rows; lane t lands at (row t >> 3, slot t & 7) and fetches piece slot ^ ((row >> 1) & 7)
+  constexpr int kDmaPerWave = (kStageBytesI8 / 1024) / NW;   // 2
+  static_assert(kDmaPerWave == 2, "counted vmcnt below");
+  int dma_rel[kDmaPerWave];
+  int dma_piece_off[kDmaPerWave];
+#pragma unroll
+  for (int e = 0; e < kDmaPerWave; ++e) {
+    dma_rel[e] = (wave * kDmaPerWave + e) * 8 + (lane >> 3);
+    dma_piece_off[e] = ((lane & 7) ^ ((dma_rel[e] >> 1) & 7)) * 16;
+  }
+  auto issue_stage = [&](int s, int buf_off) {
+#pragma unroll
+    for (int e = 0; e < kDmaPerWave; ++e) {
+      int rel = s * kStageRows + dma_rel[e];
+      rel = rel < n_rows ? rel : n_rows - 1;
+      const signed char* src = chunk_base + (long long)rel * kRowBytesI8 + dma_piece_off[e];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + buf_off + (wave * kDmaPerWave + e) * 1024),
+                                       16, 0, QW == 1 ? kDmaAux : 0);
+    }
+  };
+  // see mips_filter_f16: loads retire in order, so "at most the kDmaPerWave youngest outstanding" = the stage before has landed
+  auto publish = [&](bool younger_stage_in_flight) {
+    if (younger_stage_in_flight) {
+      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      dma_wait_barrier();
+    }
+  };
+  int off0 = 0, off1 = kStageBytesI8, off2 = 2 * kStageBytesI8, off3 = 3 * kStageBytesI8;
+  issue_stage(0, off0);
+  if (nstages > 1) issue_stage(1, off1);
+  if (nstages > 2) issue_stage(2, off2);
+  publish(nstages > 2);
+
+  if (!wave_live) {   // padding / exhausted queries only: the wave helps streaming and meets the barriers
+    for (int s = 0; s < nstages; ++s) {
+      publish(s + 2 < nstages);
+      if (s + 3 < nstages) issue_stage(s + 3, off3);
+      const int t = off0;
+      off0 = off1;
+      off1 = off2;
+      off2 = off3;
+      off3 = t;
+    }
+#pragma unroll
+    for (int blk = 0; blk < QW; ++blk)
+      a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
+    return;
+  }
+
+  i32x4 af[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(lds + off0 + rd_off[j]);
+  constexpr int kSubs = kStageRows / kSubRows;
+  for (int s = 0; s < nstages; ++s) {
+#pragma unroll
+    for (int u = 0; u < kSubs; ++u) {
+      if (u == 2) {
+        publish(s + 2 < nstages);
+        if (s + 3 < nstages) issue_stage(s + 3, off3);
+      }
+      const char* nxt = (u + 1 < kSubs) ? lds + off0 + (u + 1) * kSubBytesI8 : lds + off1;
+      i32x16 acc[QW];
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk) acc[blk] = i32x16{0};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk)
+          acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j], qf[blk][j], acc[blk], 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
+
+      bool hit[QW];
+      bool any_hit = false;
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk) {
+        hit[blk] = max16_i32(acc[blk]) > thr[blk];
+        any_hit = any_hit || hit[blk];
+      }
+      if (__builtin_expect(__any(any_hit), 0)) {
+        int rel0 = s * kStageRows + u * kSubRows;
+        asm volatile("" : "+v"(rel0));
+        const int rel = rel0 + 4 * half;
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk) {
+          if (hit[blk]) {
+            const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
+            write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, thr[blk]);
+            ++lane_n[blk];
+          }
+        }
+      }
+    }
+    const int t = off0;
+    off0 = off1;
+    off1 = off2;
+    off2 = off3;
+    off3 = t;
+  }
+#pragma unroll
+  for (int blk = 0; blk < QW; ++blk) {
+    if (lane_n[blk] > lane_cap) {
+      *a.overflow = 1u;
+      lane_n[blk] = lane_cap;
+    }
+    a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
+  }
+}
+
+// ---- quantisation of the rows ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// per-dimension sum / minimum / maximum of the fp16 rows, one partial per workgroup (a deterministic two-level reduction)
+__global__ __launch_bounds__(256) void column_stats_partial(const _Float16* __restrict__ xb, long long n, float* __restrict__ partial,
+                                                            QuantStats* __restrict__ stats) {
+  __shared__ float red[3][4][kDim];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, lo0 = __builtin_inff(), lo1 = __builtin_inff(), hi0 = -__builtin_inff(), hi1 = -__builtin_inff();
+  bool bad = false;
+  for (long long r = (long long)blockIdx.x * 4 + w; r < n; r += (long long)gridDim.x * 4) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 v = *(const f16x2*)(xb + r * kDim + 2 * lane);
+    const float x0 = (float)v[0], x1 = (float)v[1];
+    bad = bad || !(__builtin_fabsf(x0) < __builtin_inff()) || !(__builtin_fabsf(x1) < __builtin_inff());
+    s0 += x0;
+    s1 += x1;
+    lo0 = __builtin_fminf(lo0, x0);
+    lo1 = __builtin_fminf(lo1, x1);
+    hi0 = __builtin_fmaxf(hi0, x0);
+    hi1 = __builtin_fmaxf(hi1, x1);
+  }
+  if (bad) atomicOr(&stats->nonfinite, 1u);
+  red[0][w][2 * lane] = s0;
+  red[0][w][2 * lane + 1] = s1;
+  red[1][w][2 * lane] = lo0;
+  red[1][w][2 * lane + 1] = lo1;
+  red[2][w][2 * lane] = hi0;
+  red[2][w][2 * lane + 1] = hi1;
+  __syncthreads();
+  if (threadIdx.x < kDim) {
+    const int d = threadIdx.x;
+    float* out = partial + (size_t)blockIdx.x * 3 * kDim;
+    out[d] = (red[0][0][d] + red[0][1][d]) + (red[0][2][d] + red[0][3][d]);
+    out[kDim + d] = __builtin_fminf(__builtin_fminf(red[1][0][d], red[1][1][d]), __builtin_fminf(red[1][2][d], red[1][3][d]));
+    out[2 * kDim + d] = __builtin_fmaxf(__builtin_fmaxf(red[2][0][d], red[2][1][d]), __builtin_fmaxf(red[2][2][d], red[2][3][d]));
+  }
+}
+
+// col[0..127] = mean, col[128..255] = 127 / c, col[256..383] = c / 127, with c = max |x - mean| as the quantiser computes it
+__global__ __launch_bounds__(kDim) void column_stats_finish(const float* __restrict__ partial, int groups, long long n, float* __restrict__ col,
+                                                            QuantStats* __restrict__ stats) {
+  const int d = threadIdx.x;
+  double sum = 0.0;
+  float lo = __builtin_inff(), hi = -__builtin_inff();
+  for (int g = 0; g < groups; ++g) {
+    const float* p = partial + (size_t)g * 3 * kDim;
+    sum += (double)p[d];
+    lo = __builtin_fminf(lo, p[kDim + d]);
+    hi = __builtin_fmaxf(hi, p[2 * kDim + d]);
+  }
+  const float mean = (float)(sum / (double)(n > 0 ? n : 1));
+  const float c = __builtin_fmaxf(hi - mean, mean - lo);   // rounding is monotone: = max over the rows of |fl(x - mean)|
+  const bool ok = c > 0.f && c < __builtin_inff() && mean == mean;
+  if (!(c >= 0.f && c < __builtin_inff() && mean == mean)) atomicOr(&stats->nonfinite, 1u);
+  col[d] = ok ? mean : 0.f;
+  col[kDim + d] = ok ? 127.0f / c : 0.f;   // a constant dimension quantises to 0 (its residual is 0 too)
+  col[2 * kDim + d] = ok ? c / 127.0f : 0.f;
+}
+
+// one wave per row: xi = clamp(rint((x - mean) 127 / c)); R, Xn, Xf of QuantStats (rounded up a little, as non-negative float bits)
+__global__ __launch_bounds__(256) void quantise_rows_i8(const _Float16* __restrict__ xb, long long n, const float* __restrict__ col,
+                                                        signed char* __restrict__ xb8, QuantStats* __restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const float mu0 = col[2 * lane], mu1 = col[2 * lane + 1];
+  const float inv0 = col[kDim + 2 * lane], inv1 = col[kDim + 2 * lane + 1];
+  float max_r = 0.f, max_i = 0.f, max_x = 0.f;
+  for (long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4, e = 0; e < 4 && row < n; ++e, ++row) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 v = *(const f16x2*)(xb + row * kDim + 2 * lane);
+    const float x0 = (float)v[0], x1 = (float)v[1];
+    const float v0 = (x0 - mu0) * inv0, v1 = (x1 - mu1) * inv1;
+    const float i0 = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(v0)));
+    const float i1 = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(v1)));
+    const float r0 = v0 - i0, r1 = v1 - i1;
+    typedef signed char i8x2 __attribute__((ext_vector_type(2)));
+    const i8x2 o = {(signed char)(int)i0, (signed char)(int)i1};
+    *(i8x2*)(xb8 + row * kDim + 2 * lane) = o;
+    max_r = __builtin_fmaxf(max_r, wave_sum_f(r0 * r0 + r1 * r1));
+    max_i = __builtin_fmaxf(max_i, wave_sum_f(i0 * i0 + i1 * i1));
+    max_x = __builtin_fmaxf(max_x, wave_sum_f(x0 * x0 + x1 * x1));
+  }
+  if (lane == 0) {
+    // a NaN (non-finite rows: flagged by column_stats) compares false everywhere and leaves the maxima alone
+    const float r = __builtin_sqrtf(max_r) * (1.0f + 0x1p-10f), i = __builtin_sqrtf(max_i) * (1.0f + 0x1p-10f),
+                x = __builtin_sqrtf(max_x) * (1.0f + 0x1p-10f);
+    if (r > 0.f) atomicMax(&stats->max_resid, __float_as_uint(r));
+    if (i > 0.f) atomicMax(&stats->max_inorm, __float_as_uint(i));
+    if (x > 0.f) atomicMax(&stats->max_xnorm, __float_as_uint(x));
+  }
+}
+
+// one wave per (padded) query: int8 query and its NominateParams (see the derivation at the top of this section)
+__global__ __launch_bounds__(256) void prep_queries_i8(const _Float16* __restrict__ xq, long long nq_pad, const float* __restrict__ col,
+                                                       const QuantStats* __restrict__ stats, signed char* __restrict__ xq8,
+                                                       NominateParams* __restrict__ qp, unsigned long long* __restrict__ stat_nom) {
+  const int lane = threadIdx.x & 63;
+  const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= nq_pad) return;
+  const float q0 = (float)xq[q * kDim + 2 * lane], q1 = (float)xq[q * kDim + 2 * lane + 1];
+  const float mu0 = col[2 * lane], mu1 = col[2 * lane + 1];
+  const float w0 = q0 * col[2 * kDim + 2 * lane], w1 = q1 * col[2 * kDim + 2 * lane + 1];
+  const float wmax = wave_max_f(__builtin_fmaxf(__builtin_fabsf(w0), __builtin_fabsf(w1)));
+  const float s_q = wmax / 127.0f;
+  const bool ok = s_q > 0.f && s_q < __builtin_inff();
+  const float inv = ok ? 1.0f / s_q : 0.f;
+  const float u0 = w0 * inv, u1 = w1 * inv;
+  const float i0 = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(u0)));
+  const float i1 = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(u1)));
+  typedef signed char i8x2 __attribute__((ext_vector_type(2)));
+  const i8x2 o = {(signed char)(int)i0, (signed char)(int)i1};
+  *(i8x2*)(xq8 + q * kDim + 2 * lane) = o;
+  const float e0 = u0 - i0, e1 = u1 - i1;
+  const float n_u = __builtin_sqrtf(wave_sum_f(u0 * u0 + u1 * u1)) * (1.0f + 0x1p-10f);
+  const float n_e = __builtin_sqrtf(wave_sum_f(e0 * e0 + e1 * e1)) * (1.0f + 0x1p-10f) + 0x1p-10f;
+  const float n_q = __builtin_sqrtf(wave_sum_f(q0 * q0 + q1 * q1)) * (1.0f + 0x1p-10f);
+  const float abs_off = wave_sum_f(__builtin_fabsf(q0 * mu0) + __builtin_fabsf(q1 * mu1));
+  double off = (double)q0 * (double)mu0 + (double)q1 * (double)mu1;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) off += __shfl_xor(off, d, 64);
+  if (lane == 0) {
+    const float R = __uint_as_float(stats->max_resid) + 0x1p-10f, Xn = __uint_as_float(stats->max_inorm),
+                Xf = __uint_as_float(stats->max_xnorm);
+    // score units: the fp32 accumulation of the exact score's MFMA sums, fp16 subnormal operands should the matrix cores flush
+    // them (see query_margins), the rounding of `off` itself
+    const float delta = 0x1p-16f * n_q * Xf + 11.32f * 0x1p-14f * (n_q + Xf) + 0x1p-20f * abs_off;
+    NominateParams p;
+    p.off = (float)off;
+    p.inv_unit = inv;
+    p.margin = ok ? ((n_u * R + n_e * Xn) + delta * inv) * (1.0f + 0x1p-10f) + 1.0f : 1.0f;   // !ok: a zero query -- acc = 0 > -2 always
+    if (!(stats->nonfinite == 0u)) p.margin = __builtin_nanf("");   // never used on such an index; a NaN nominates everything
+    p.pad = 0.f;
+    qp[q] = p;
+    stat_nom[q] = 0ull;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // merge kernel: one workgroup per query
 // ---------------------------------------------------------------------------------------
 // keys[] collects {survivors of this round} then {running list}; the workgroup sorts them in registers
@@ -498,6 +877,8 @@ struct ExactCtx {
   unsigned* n_nom;
 };
 
+// INT_SCORES: records of the int8 nomination scan (int32 scores against an int32 threshold word, strict)
+template <bool INT_SCORES = false>
 __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned q, bool inclusive,
                                                  unsigned long long bound, const ExactCtx& ex,
                                                  unsigned long long* keys, unsigned* n_keys, unsigned cap) {
@@ -509,9 +890,11 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
   for (int g = 0; g < 4; ++g) {
     const uint4 v = src[1 + g];
     const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    const unsigned raw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      if ((inclusive ? (sc[e] >= tau) : (sc[e] > tau)) && (e + 8 * g) < rows_left) {
+      const bool pass = INT_SCORES ? ((int)raw[e] > (int)h.w) : (inclusive ? (sc[e] >= tau) : (sc[e] > tau));
+      if (pass && (e + 8 * g) < rows_left) {
         const unsigned row = h.y + (unsigned)(e + 8 * g);
         if (ex.nom) {  // the fp16 score only nominates the row
           const unsigned pos = atomicAdd(ex.n_nom, 1u);  // LDS
@@ -528,13 +911,14 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
   }
 }
 
+template <bool INT_SCORES = false>
 __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
                                             unsigned long long bound, const ExactCtx& ex, unsigned long long* keys,
                                             unsigned* n_keys, unsigned cap) {
   uint4 buf[5];
 #pragma unroll
   for (int g = 0; g < 5; ++g) buf[g] = ((const uint4*)rec)[g];
-  keep_scores_regs(buf, q, inclusive, bound, ex, keys, n_keys, cap);
+  keep_scores_regs<INT_SCORES>(buf, q, inclusive, bound, ex, keys, n_keys, cap);
 }
 
 // Append the lanes' items (pred lanes only) to an LDS array: one LDS atomic per wave, ranks by mbcnt.
@@ -701,12 +1085,17 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
 #else
 #define PROQA_STAMP(i) do {} while (0)
 #endif
-// EXACT = exact-float32 mode (own instantiation: its LDS list and registers stay out of the fp16 kernel)
+// MODE = kMergeF16, kMergeExactF32 (exact-float32 mode) or kMergeNominatedI8 (rounds of the int8 nomination scan): the two
+//        re-scoring modes are instantiations of their own -- their LDS lists and registers stay out of the fp16 kernel
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
 // T = threads: 256, or 512 for the largest CAP (one workgroup per CU there: the second wave per SIMD hides the latencies)
-template <bool EXACT, int CAP, int T = kMergeThreads>
-__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (EXACT ? 1 : 2) : (CAP > kMaxSortKeys || EXACT ? 4 : 8)))
+constexpr int kMergeF16 = 0, kMergeExactF32 = 1, kMergeNominatedI8 = 2;
+template <int MODE, int CAP, int T = kMergeThreads>
+__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE ? 4 : 8)))
 void topk_merge(MergeArgs a) {
+  constexpr bool EXACT = MODE == kMergeExactF32;   // nominated rows are re-scored from the float32 rows in double
+  constexpr bool NOM = MODE == kMergeNominatedI8;  // ... from the fp16 rows on the fp16 filter's MFMA sequence
+  constexpr bool RESCORE = EXACT || NOM;
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
@@ -714,7 +1103,8 @@ void topk_merge(MergeArgs a) {
   // 12288 -- with 8192 four queries in ten overflowed it by a hundred records or two, 5.5 vs 5.2 ms; big pages and
   // the one-pass search's sample round put ~2 k records of a query into one pass: 4096 -- with 1024, half of them took the
   // one-at-a-time path and the sample merge of 6980 queries 1.4-1.5 ms instead of 1.1)
-  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 12288 : (CAP > kMidSortKeys ? 4096 : (CAP > kMaxSortKeys ? 3072 : 1024));
+  // (int8 nomination rounds log ~3 x the records of an fp16 round: 2048)
+  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 12288 : (CAP > kMidSortKeys ? 4096 : (CAP > kMaxSortKeys ? 3072 : (MODE == 2 ? 2048 : 1024)));
   __shared__ unsigned short s_work[kWorkCap];
   __shared__ unsigned s_n_keys, s_n_work;
   __shared__ unsigned long long s_dummy;   // target of the stores of lanes that have nothing to append
@@ -740,6 +1130,13 @@ void topk_merge(MergeArgs a) {
     ex.n_nom = &s_n_nom;
     xq32_lds = s_xq32;
   }
+  if constexpr (NOM) {
+    __shared__ unsigned s_nom[CAP];
+    __shared__ unsigned s_n_nom;
+    if (tid == 0) s_n_nom = 0;   // visible after the first barrier below
+    ex.nom = s_nom;
+    ex.n_nom = &s_n_nom;
+  }
   const unsigned n_lists = 2 * a.n_chunks;
   const bool inclusive = a.inclusive != 0;
   const unsigned long long bound = a.bound_keys ? a.bound_keys[q] : ~0ull;
@@ -764,13 +1161,14 @@ void topk_merge(MergeArgs a) {
       const unsigned t = (unsigned)tid + e * T;
       cnt_first[e] = t < n_here ? st.lane_cnt[lane_cnt_index(st, t >> 1, q, (int)(t & 1))] : 0u;
     }
-    n_spill_first = (unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_cnt_index(st, (unsigned)tid, qt, wave)] : 0u;
+    // (the int8 nomination scan has no spill log: its counters are not written)
+    n_spill_first = !NOM && (unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_cnt_index(st, (unsigned)tid, qt, wave)] : 0u;
   }
   run_pref = (unsigned)tid < nrun ? run_pref : 0ull;
 
   if (tid == 0) s_n_keys = 0;
 
-  if (!EXACT && a.compact) {
+  if (!RESCORE && a.compact) {
     // Compact lists (see mips_filter_f16<COMPACT>): every entry is a key that passed its threshold.  Per sweep of up to
     // kSweep lists: one thread per list reads its length and reserves the slots (LDS atomic; the order of the keys does
     // not matter, they are sorted below); then a wave per list copies it, eight lists in flight per wave.
@@ -830,7 +1228,7 @@ void topk_merge(MergeArgs a) {
     }
     const unsigned spill_slot0 = ((base >> 1) * st.n_qtiles + qt) * kFilterWaves + wave;   // chunk base/2
     const unsigned n_spill = base == 0 ? n_spill_first
-                                       : ((unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_cnt_index(st, (base >> 1) + (unsigned)tid, qt, wave)] : 0u);
+                                       : (!NOM && (unsigned)tid < (n_here >> 1) ? st.spill_cnt[spill_cnt_index(st, (base >> 1) + (unsigned)tid, qt, wave)] : 0u);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       if (cnt[e]) {
@@ -840,7 +1238,7 @@ void topk_merge(MergeArgs a) {
           if (pos + s < kWorkCap)
             s_work[pos + s] = (unsigned short)((t << kSlotBits) | s);
           else
-            keep_scores(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+            keep_scores<NOM>(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
         }
       }
     }
@@ -854,7 +1252,7 @@ void topk_merge(MergeArgs a) {
         const unsigned n_s = (unsigned)__shfl((int)n_spill, src, 64);
         const size_t slot_s = spill_slot0 + (size_t)((tid & ~63) + src) * spill_stride;
         for (unsigned i = lane; i < n_s; i += 64)
-          keep_scores(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+          keep_scores<NOM>(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
       }
     }
     __syncthreads();
@@ -877,8 +1275,8 @@ void topk_merge(MergeArgs a) {
         for (int g = 0; g < 5; ++g) b0[g] = r0[g];
 #pragma unroll
         for (int g = 0; g < 5; ++g) b1[g] = r1[g];
-        keep_scores_regs(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
-        if (two) keep_scores_regs(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+        keep_scores_regs<NOM>(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+        if (two) keep_scores_regs<NOM>(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
       }
     } else
     // FIVE lanes per record, one 16-byte piece each (12 records per wave and load instruction, two instructions in
@@ -913,6 +1311,29 @@ void topk_merge(MergeArgs a) {
               const unsigned pos = atomicAdd(ex.n_nom, 1u);  // LDS
               if (pos < (unsigned)CAP) ex.nom[pos] = row0 + (unsigned)(e + 8 * g);
             }
+          }
+        } else if constexpr (NOM) {   // int8 nomination: int32 scores above the integer threshold name the rows to re-score
+          const int thr = __shfl((int)v.w, head, 64);
+          const int raw[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+          bool p[4];
+          unsigned long long m[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            p[e] = live && piece != 0 && raw[e] > thr && (e + 8 * g) < rows_left;
+            m[e] = __ballot(p[e]);
+          }
+          const unsigned n0 = (unsigned)__builtin_popcountll(m[0]), n1 = (unsigned)__builtin_popcountll(m[1]),
+                         n2 = (unsigned)__builtin_popcountll(m[2]), n3 = (unsigned)__builtin_popcountll(m[3]);
+          const unsigned total = n0 + n1 + n2 + n3;
+          if (total == 0) return;   // wave-uniform
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(ex.n_nom, total);   // LDS
+          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+          const unsigned off[4] = {base, base + n0, base + n0 + n1, base + n0 + n1 + n2};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned pos = off[e] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[e], 0u));
+            if (p[e] && pos < (unsigned)CAP) ex.nom[pos] = row0 + (unsigned)(e + 8 * g);
           }
         } else {
           // Branch-free per lane: the four scores of a piece are tested, the survivors of the WAVE are counted by ballot
@@ -1001,6 +1422,47 @@ void topk_merge(MergeArgs a) {
             if (pos < (unsigned)CAP) keys[pos] = key;
           }
         }
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (NOM) {
+    // Re-score the nominated rows from the fp16 rows: a wave takes 32 of them as the A operand of the fp16 filter's own MFMA
+    // sequence (rows = A, piece 2j + half at k-step j, the query in every B column), so a row's score has the bits the fp16
+    // scan gives it.  Lane (li, half) ends up with the scores of rows (r & 3) + 8 (r >> 2) + 4 half of the batch in every
+    // column; column 0 hands them to lanes 0..31 through LDS, which test and append them.
+    __shared__ float s_sc[T / 64][32];
+    unsigned n_nom = *ex.n_nom;
+    if (n_nom > (unsigned)CAP) {  // more nominations than the list holds: overflow-safe path
+      if (tid == 0) *a.overflow = 1u;
+      n_nom = CAP;
+    }
+    if (tid == 0) a.stat_nominated[q] += n_nom;
+    const float tau_exact = a.tau[q];
+    const int lane = tid & 63, w = tid >> 6, li = lane & 31, half = lane >> 5;
+    if (n_nom) {   // workgroup-uniform
+      f16x8 qf[8];
+      const char* qrow = (const char*)a.xq16 + (size_t)q * kRowBytes;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[j] = *(const f16x8*)(qrow + (2 * j + half) * 16);
+      for (unsigned c0 = (unsigned)w * 32; c0 < n_nom; c0 += (T / 64) * 32) {   // wave-uniform trip count
+        const unsigned mine = c0 + (unsigned)li < n_nom ? c0 + (unsigned)li : c0;
+        const unsigned row = ex.nom[mine];
+        const char* ap = a.xb16 + (size_t)row * kRowBytes;
+        f16x8 af[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(ap + (2 * j + half) * 16);
+        f32x16 acc = {0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[j], acc, 0, 0, 0);
+        if (li == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_sc[w][(r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
+        }
+        // (LDS operations of one wave execute in program order: the reads below see the writes of lanes 0 and 32)
+        const float score = s_sc[w][li];
+        const bool keep = half == 0 && c0 + (unsigned)li < n_nom && score > tau_exact;
+        wave_append(keep, pack_key(score, row), keys, &s_n_keys, (unsigned)CAP);
       }
     }
     __syncthreads();
@@ -1331,9 +1793,10 @@ __global__ void prep_queries(const void* xq, int dtype, long long nq, long long 
 __global__ __launch_bounds__(256) void finalize_topk(const unsigned long long* run_keys, const unsigned* run_n, long long nq,
                                                      int k, long long idx_offset, float* D, long long* I, int out_stride,
                                                      int out_offset, const unsigned* overflow, unsigned* status,
-                                                     SearchMirror* mirror, const unsigned long long* stat) {
+                                                     SearchMirror* mirror, const unsigned long long* stat,
+                                                     const unsigned long long* stat_nominated) {
   if (blockIdx.x == 0 && (status || mirror)) {
-    __shared__ unsigned long long s_part[4];
+    __shared__ unsigned long long s_part[8];
     bool any = false;
     for (int w = threadIdx.x; w < kOverflowWords; w += 256) {
       const unsigned v = overflow[w];
@@ -1343,14 +1806,24 @@ __global__ __launch_bounds__(256) void finalize_topk(const unsigned long long* r
     const int any_all = __syncthreads_or(any ? 1 : 0);
     if (threadIdx.x == 0 && status) *status = any_all ? 1u : 0u;
     if (mirror) {
-      unsigned long long c = 0;
-      for (long long i = threadIdx.x; i < nq; i += 256) c += stat[i];
+      unsigned long long c = 0, m = 0;
+      for (long long i = threadIdx.x; i < nq; i += 256) {
+        c += stat[i];
+        if (stat_nominated) m += stat_nominated[i];
+      }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-      if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+      for (int off = 32; off > 0; off >>= 1) {
+        c += __shfl_xor(c, off, 64);
+        m += __shfl_xor(m, off, 64);
+      }
+      if ((threadIdx.x & 63) == 0) {
+        s_part[threadIdx.x >> 6] = c;
+        s_part[4 + (threadIdx.x >> 6)] = m;
+      }
       __syncthreads();
       if (threadIdx.x == 0) {
         mirror->candidates = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        mirror->nominated = s_part[4] + s_part[5] + s_part[6] + s_part[7];
         __threadfence_system();
       }
     }
@@ -1724,6 +2197,36 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
   return hipGetLastError();
 }
 
+hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st) {
+  if (qw == 2)
+    hipLaunchKernelGGL((mips_filter_i8<2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+  else if (qw == 1)
+    hipLaunchKernelGGL((mips_filter_i8<1>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t launch_column_stats(const void* xb16, long long n, float* partial, float* col, QuantStats* stats, hipStream_t st) {
+  hipLaunchKernelGGL(column_stats_partial, dim3(kColStatGroups), dim3(256), 0, st, (const _Float16*)xb16, n, partial, stats);
+  hipLaunchKernelGGL(column_stats_finish, dim3(1), dim3(kDim), 0, st, partial, kColStatGroups, n, col, stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, QuantStats* stats, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(quantise_rows_i8, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const _Float16*)xb16, n, col, xb8, stats);
+  return hipGetLastError();
+}
+
+hipError_t launch_prep_queries_i8(const void* xq_pad16, long long nq_pad, const float* col, const QuantStats* stats,
+                                  signed char* xq8, NominateParams* qp, unsigned long long* stat_nom, hipStream_t st) {
+  if (nq_pad == 0) return hipSuccess;
+  hipLaunchKernelGGL(prep_queries_i8, dim3((unsigned)((nq_pad + 3) / 4)), dim3(256), 0, st, (const _Float16*)xq_pad16, nq_pad, col,
+                     stats, xq8, qp, stat_nom);
+  return hipGetLastError();
+}
+
 #ifdef PROQA_FILTER_STAMPS
 void read_filter_stamps(unsigned long long* out5) {
   (void)hipDeviceSynchronize();
@@ -1806,20 +2309,23 @@ hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned
 
 hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   const bool big = a.sort_cap > kMaxSortKeys;
-  if (a.xq32) {
+  if (a.xb16) {   // records of the int8 nomination scan
+    if (big || a.xq32 || a.compact || a.inclusive || a.bound_keys) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+  } else if (a.xq32) {
     if (big)
-      hipLaunchKernelGGL((topk_merge<true, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+      hipLaunchKernelGGL((topk_merge<kMergeExactF32, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
     else
-      hipLaunchKernelGGL((topk_merge<true, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+      hipLaunchKernelGGL((topk_merge<kMergeExactF32, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   } else {
     if (a.sort_cap > kBigSortKeys)
-      hipLaunchKernelGGL((topk_merge<false, kOnePassSortKeys, kOnePassMergeThreads>), dim3(nq_pad), dim3(kOnePassMergeThreads), 0, st, a);
+      hipLaunchKernelGGL((topk_merge<kMergeF16, kOnePassSortKeys, kOnePassMergeThreads>), dim3(nq_pad), dim3(kOnePassMergeThreads), 0, st, a);
     else if (a.sort_cap > kMidSortKeys)
-      hipLaunchKernelGGL((topk_merge<false, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+      hipLaunchKernelGGL((topk_merge<kMergeF16, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
     else if (big)
-      hipLaunchKernelGGL((topk_merge<false, kMidSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+      hipLaunchKernelGGL((topk_merge<kMergeF16, kMidSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
     else
-      hipLaunchKernelGGL((topk_merge<false, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+      hipLaunchKernelGGL((topk_merge<kMergeF16, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   }
   return hipGetLastError();
 }
@@ -1841,11 +2347,11 @@ hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long lon
 hipError_t launch_finalize(const unsigned long long* run_keys, const unsigned* run_n, long long nq, int page_k,
                            long long idx_offset, float* D, long long* I, int out_stride, int out_offset,
                            const unsigned* overflow, unsigned* status, SearchMirror* mirror, const unsigned long long* stat,
-                           hipStream_t st) {
+                           hipStream_t st, const unsigned long long* stat_nominated) {
   const long long n = nq * page_k;
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(finalize_topk, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, run_keys, run_n,
-                     nq, page_k, idx_offset, D, I, out_stride, out_offset, overflow, status, mirror, stat);
+                     nq, page_k, idx_offset, D, I, out_stride, out_offset, overflow, status, mirror, stat, stat_nominated);
   return hipGetLastError();
 }
 

@@ -164,7 +164,8 @@ class IndexFlatIP:
         st = _lib.SearchStats()
         _lib.check(self._lib.proqa_index_last_stats(self._h, ctypes.byref(st)))
         return {"rounds": st.rounds, "fallback_rounds": st.fallback_rounds, "candidates": st.candidates,
-                "filter_ms": st.filter_ms, "total_ms": st.total_ms}
+                "filter_ms": st.filter_ms, "total_ms": st.total_ms, "nominated": st.nominated,
+                "nomination": bool(st.nomination)}
 
     def set_profiling(self, enable=True):
         _lib.check(self._lib.proqa_index_set_profiling(self._h, 1 if enable else 0))
@@ -190,6 +191,12 @@ class IndexFlatIP:
     def configure_bootstrap(self, rows):
         """Rows covered by the dense bootstrap (exact top-k of the first rows from a score matrix); 0 disables it."""
         _lib.check(self._lib.proqa_index_configure_bootstrap(self._h, int(rows)))
+
+    def configure_nomination(self, mode):
+        """The int8 nomination scan of the k <= 128 rounds (see proqa_hip.h): 0 / "off" = fp16 scan only, 1 / "auto"
+        (default), 2 / "always".  The result is the fp16 scan's either way."""
+        mode = {"off": 0, "auto": 1, "always": 2}.get(mode, mode)
+        _lib.check(self._lib.proqa_index_configure_nomination(self._h, int(mode)))
 
     def close(self):
         if getattr(self, "_h", None):
