@@ -560,6 +560,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     fa.qp = idx->qparams;
     fa.store = store_of(idx, nq_pad, n_qtiles, kNominateLaneCap, round_up<unsigned>(g.chunks, 8));
     fa.overflow = overflow_word;
+    fa.flags = kFilterFlags;
     if (f0) PROQA_HIP(hipEventRecord(f0, st));
     PROQA_HIP(launch_filter_i8(fa, qw, g.grid, st));
     if (f1) PROQA_HIP(hipEventRecord(f1, st));
@@ -718,6 +719,8 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
   // Bootstrap: exact top-k of the first rows in two launches instead of the first three or four (dense) rounds.
   // Not for pages after the first (bounded), exact-float32 mode (its scores are re-computed from float32 rows),
   // k beyond the select kernel's bound, or an index too small to need it.
+  // (rounds on the int8 copy nominate ~3 x the candidates of an fp16 round: never the growth 8 of the small batches)
+  const int gqw = idx->q8_active ? 2 : qw;
   long long boot = 0;
   if (use_bootstrap && idx->bootstrap_rows > 0 && !bounded && !idx->exact && page_k <= kBootstrapMaxK &&
       page_k <= idx->bootstrap_rows / 4 && idx->n >= 4ll * idx->bootstrap_rows) {
@@ -727,7 +730,7 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
     // 1324 candidates per query, -40 us; where it would save a round instead -- 4.5M, 18M rows -- the larger bootstrap
     // costs what the round did)
     if (idx->bootstrap_auto && kEqualGrowth && boot * 2 <= kBootstrapMaxRows && idx->n >= 8 * boot) {
-      const double cap = std::log(1.0 + growth_for(page_k, idx->growth, qw));
+      const double cap = std::log(1.0 + growth_for(page_k, idx->growth, gqw));
       const int r1 = (int)std::ceil(std::log((double)idx->n / (double)boot) / cap - 1e-9);
       const int r2 = (int)std::ceil(std::log((double)idx->n / (double)(2 * boot)) / cap - 1e-9);
       if (r1 == r2) boot *= 2;
@@ -737,8 +740,8 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
   // (big pages: as many rows as the merge holds -- their growth per round is small, so the rounds should start high)
   const int first_cap = (sort_capacity(page_k) - page_k) / kStageRows * kStageRows;
   const int first = page_k > kPageK ? first_cap : std::min<int>(idx->first_slab_rows, first_cap);
-  plan->slabs = boot && kEqualGrowth && kGrowthList.empty() ? plan_slabs_equal(idx->n, boot, growth_for(page_k, idx->growth, qw))
-                                                          : plan_slabs(idx->n, first, growth_for(page_k, idx->growth, qw), boot);
+  plan->slabs = boot && kEqualGrowth && kGrowthList.empty() ? plan_slabs_equal(idx->n, boot, growth_for(page_k, idx->growth, gqw))
+                                                          : plan_slabs(idx->n, first, growth_for(page_k, idx->growth, gqw), boot);
   plan->boot = boot;
   const std::vector<Slab>& slabs = plan->slabs;
   if ((int)slabs.size() + 2 > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
@@ -1169,7 +1172,11 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   // mips_kernels.hip) when the batch is MFMA-bound, k small enough for a round's nominations to fit its merge and the
   // shard large enough to matter.  Called after prep_first (it reads the padded fp16 queries).
   auto setup_nominate = [&]() -> int {
-    if (idx->nominate_mode == 0 || idx->exact || k > kNominateMaxK || qw != 2 || idx->n < kNominateMinRows) return PROQA_OK;
+    // (mode 2, "always", also takes small batches and small shards: tests and experiments)
+    const bool always = idx->nominate_mode == 2;
+    if (idx->nominate_mode == 0 || idx->exact || k > kNominateMaxK || (qw != 2 && !always) ||
+        idx->n < (always ? 4 * kStageRows : kNominateMinRows))
+      return PROQA_OK;
     if (int rc = ensure_q8(idx, st)) return rc;
     if (!idx->q8_usable || (idx->q8_unprofitable && idx->nominate_mode != 2)) return PROQA_OK;
     PROQA_HIP(launch_prep_queries_i8(idx->xq_pad, idx->ws_nq_pad, idx->col, idx->qstats, idx->xq8, idx->qparams, idx->stat_nom, st));

@@ -145,6 +145,7 @@ struct FilterArgsI8 {
   const NominateParams* qp; // [nq_pad]
   CandidateStore store;     // column records whose scores / threshold words are int32
   unsigned* overflow;
+  unsigned flags;           // developer cut experiments (PROQA_FILTER_FLAGS; wrong results), 0 in production
 };
 hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st);
 // column statistics of fp16 rows [0, n): partial[g][0..127] sums, [g][128..255] minima, [g][256..383] maxima per workgroup g

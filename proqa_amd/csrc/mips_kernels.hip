@@ -506,10 +506,11 @@ constexpr int kSubBytesI8 = kSubRows * kRowBytesI8;      // 4 KiB: one 32-row MF
 // of this kernel with that tree on the fresh ones read registers the MFMA had not written yet and lost 40 % of its hits).
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int max16_i32(const i32x16& v) {
-  int m = imax(imax(v[0], v[1]), v[2]);
-#pragma unroll
-  for (int r = 3; r + 1 < 16; r += 2) m = imax(imax(m, v[r]), v[r + 1]);
-  return imax(m, v[15]);
+  // a tree of depth three (five independent v_max3 first), not a chain of eight dependent ones: the two query blocks' trees
+  // interleave and the wave is back at its MFMAs sooner
+  const int m0 = imax(imax(v[0], v[1]), v[2]), m1 = imax(imax(v[3], v[4]), v[5]), m2 = imax(imax(v[6], v[7]), v[8]),
+            m3 = imax(imax(v[9], v[10]), v[11]), m4 = imax(imax(v[12], v[13]), v[14]);
+  return imax(imax(imax(m0, m1), m2), imax(imax(m3, m4), v[15]));
 }
 
 // the integer threshold of a query whose exact threshold is tau: every row with exact score > tau has acc > T
@@ -617,15 +618,43 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
                                        16, 0, QW == 1 ? kDmaAux : 0);
     }
   };
-  // see mips_filter_f16: loads retire in order, so "at most the kDmaPerWave youngest outstanding" = the stage before has landed
+  // The barrier that publishes stage s+1 must know that this wave's DMA pieces of that stage have landed.  Vector memory
+  // operations of a wave complete in issue order on gfx9 (one counter for loads, LDS-DMA and stores; hipcc's own counted
+  // waits rely on it), so "at most the operations issued AFTER those pieces outstanding" is exact: the kDmaPerWave pieces of
+  // the younger stage plus the record stores of the two windows since -- counted per wave.  Waiting for the stores as
+  // well (`vmcnt(2)`, the fp16 scan's form: never wrong, only longer) makes every stage barrier wait for the write
+  // acknowledgement of whatever column was logged just before it: 0.5 of 4.1 ms at 2032 x 18M (cut experiments, ABLATIONS R5.2).
+  int st_prev = 0, st_cur = 0;   // record-store instructions of this wave: between the last two barriers / since the last one
   auto publish = [&](bool younger_stage_in_flight) {
     if (younger_stage_in_flight) {
-      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      const int allowed = __builtin_amdgcn_readfirstlane(2 + st_prev + st_cur);
+      if (a.flags & 2u) {   // experiment switch: the conservative form
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else if (allowed >= 37) {
+        asm volatile("s_waitcnt vmcnt(37)" ::: "memory");
+      } else if (allowed >= 32) {
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+      } else if (allowed >= 27) {
+        asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+      } else if (allowed >= 22) {
+        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+      } else if (allowed >= 17) {
+        asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+      } else if (allowed >= 12) {
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else if (allowed >= 7) {
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     } else {
       dma_wait_barrier();
     }
+    st_prev = st_cur;
+    st_cur = 0;
   };
   int off0 = 0, off1 = kStageBytesI8, off2 = 2 * kStageBytesI8, off3 = 3 * kStageBytesI8;
   issue_stage(0, off0);
@@ -656,7 +685,7 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
   for (int s = 0; s < nstages; ++s) {
 #pragma unroll
     for (int u = 0; u < kSubs; ++u) {
-      if (u == 2) {
+      if (u == 2 && !(a.flags & 16u)) {   // (flag 16, cut experiment: no barrier, no DMA after the prologue -- stale stages)
         publish(s + 2 < nstages);
         if (s + 3 < nstages) issue_stage(s + 3, off3);
       }
@@ -664,32 +693,44 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
       i32x16 acc[QW];
 #pragma unroll
       for (int blk = 0; blk < QW; ++blk) acc[blk] = i32x16{0};
+      if (a.flags & 1u) __builtin_amdgcn_s_setprio(3);   // experiment: the wave that has MFMAs to issue goes first
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int blk = 0; blk < QW; ++blk)
           acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j], qf[blk][j], acc[blk], 0, 0, 0);
       }
+      if (a.flags & 1u) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
 
       bool hit[QW];
       bool any_hit = false;
+      if (!(a.flags & 8u)) {   // (flag 8, cut experiment: the accumulators are not examined at all)
 #pragma unroll
-      for (int blk = 0; blk < QW; ++blk) {
-        hit[blk] = max16_i32(acc[blk]) > thr[blk];
-        any_hit = any_hit || hit[blk];
+        for (int blk = 0; blk < QW; ++blk) {
+          hit[blk] = max16_i32(acc[blk]) > thr[blk];
+          any_hit = any_hit || hit[blk];
+        }
+      } else {
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk) hit[blk] = false;
+        asm volatile("" :: "v"(acc[0][0]), "v"(acc[QW - 1][15]));   // keeps the MFMAs
       }
+      if (a.flags & 32u) any_hit = false;   // cut experiment: examined, never logged
       if (__builtin_expect(__any(any_hit), 0)) {
         int rel0 = s * kStageRows + u * kSubRows;
         asm volatile("" : "+v"(rel0));
         const int rel = rel0 + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < QW; ++blk) {
-          if (hit[blk]) {
-            const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
-            write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, thr[blk]);
-            ++lane_n[blk];
+          if (__any(hit[blk])) {   // (wave-uniform: exactly the regions whose five stores are issued are counted)
+            st_cur += 5;
+            if (hit[blk]) {
+              const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
+              write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, thr[blk]);
+              ++lane_n[blk];
+            }
           }
         }
       }
@@ -722,39 +763,53 @@ __device__ __forceinline__ float wave_max_f(float v) {
   return v;
 }
 
-// per-dimension sum / minimum / maximum of the fp16 rows, one partial per workgroup (a deterministic two-level reduction)
+// per-dimension sum / minimum / maximum of the fp16 rows, one partial per workgroup (a deterministic two-level reduction).
+// 16 lanes per row (16 bytes = 8 dimensions each), four rows per wave and trip.
 __global__ __launch_bounds__(256) void column_stats_partial(const _Float16* __restrict__ xb, long long n, float* __restrict__ partial,
                                                             QuantStats* __restrict__ stats) {
-  __shared__ float red[3][4][kDim];
+  __shared__ float red[3][16][kDim];   // [statistic][row slot of the workgroup][dimension]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float s0 = 0.f, s1 = 0.f, lo0 = __builtin_inff(), lo1 = __builtin_inff(), hi0 = -__builtin_inff(), hi1 = -__builtin_inff();
+  const int sub = lane & 15, slot = w * 4 + (lane >> 4);
+  float sum[8], lo[8], hi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sum[e] = 0.f;
+    lo[e] = __builtin_inff();
+    hi[e] = -__builtin_inff();
+  }
   bool bad = false;
-  for (long long r = (long long)blockIdx.x * 4 + w; r < n; r += (long long)gridDim.x * 4) {
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    const f16x2 v = *(const f16x2*)(xb + r * kDim + 2 * lane);
-    const float x0 = (float)v[0], x1 = (float)v[1];
-    bad = bad || !(__builtin_fabsf(x0) < __builtin_inff()) || !(__builtin_fabsf(x1) < __builtin_inff());
-    s0 += x0;
-    s1 += x1;
-    lo0 = __builtin_fminf(lo0, x0);
-    lo1 = __builtin_fminf(lo1, x1);
-    hi0 = __builtin_fmaxf(hi0, x0);
-    hi1 = __builtin_fmaxf(hi1, x1);
+  for (long long r = (long long)blockIdx.x * 16 + slot; r < n; r += (long long)gridDim.x * 16) {
+    const f16x8 v = *(const f16x8*)(xb + r * kDim + sub * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (float)v[e];
+      bad = bad || !(__builtin_fabsf(x) < __builtin_inff());
+      sum[e] += x;
+      lo[e] = __builtin_fminf(lo[e], x);
+      hi[e] = __builtin_fmaxf(hi[e], x);
+    }
   }
   if (bad) atomicOr(&stats->nonfinite, 1u);
-  red[0][w][2 * lane] = s0;
-  red[0][w][2 * lane + 1] = s1;
-  red[1][w][2 * lane] = lo0;
-  red[1][w][2 * lane + 1] = lo1;
-  red[2][w][2 * lane] = hi0;
-  red[2][w][2 * lane + 1] = hi1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[0][slot][sub * 8 + e] = sum[e];
+    red[1][slot][sub * 8 + e] = lo[e];
+    red[2][slot][sub * 8 + e] = hi[e];
+  }
   __syncthreads();
   if (threadIdx.x < kDim) {
     const int d = threadIdx.x;
+    float s_ = 0.f, l_ = __builtin_inff(), h_ = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {   // fixed order: deterministic
+      s_ += red[0][t][d];
+      l_ = __builtin_fminf(l_, red[1][t][d]);
+      h_ = __builtin_fmaxf(h_, red[2][t][d]);
+    }
     float* out = partial + (size_t)blockIdx.x * 3 * kDim;
-    out[d] = (red[0][0][d] + red[0][1][d]) + (red[0][2][d] + red[0][3][d]);
-    out[kDim + d] = __builtin_fminf(__builtin_fminf(red[1][0][d], red[1][1][d]), __builtin_fminf(red[1][2][d], red[1][3][d]));
-    out[2 * kDim + d] = __builtin_fmaxf(__builtin_fmaxf(red[2][0][d], red[2][1][d]), __builtin_fmaxf(red[2][2][d], red[2][3][d]));
+    out[d] = s_;
+    out[kDim + d] = l_;
+    out[2 * kDim + d] = h_;
   }
 }
 
@@ -772,37 +827,63 @@ __global__ __launch_bounds__(kDim) void column_stats_finish(const float* __restr
   }
   const float mean = (float)(sum / (double)(n > 0 ? n : 1));
   const float c = __builtin_fmaxf(hi - mean, mean - lo);   // rounding is monotone: = max over the rows of |fl(x - mean)|
-  const bool ok = c > 0.f && c < __builtin_inff() && mean == mean;
-  if (!(c >= 0.f && c < __builtin_inff() && mean == mean)) atomicOr(&stats->nonfinite, 1u);
-  col[d] = ok ? mean : 0.f;
-  col[kDim + d] = ok ? 127.0f / c : 0.f;   // a constant dimension quantises to 0 (its residual is 0 too)
-  col[2 * kDim + d] = ok ? c / 127.0f : 0.f;
+  const bool finite = c >= 0.f && c < __builtin_inff() && mean == mean;
+  const float inv = finite && c > 0.f ? 127.0f / c : 0.f;
+  if (!finite || !(inv < __builtin_inff())) atomicOr(&stats->nonfinite, 1u);
+  // a constant dimension (c == 0) keeps its mean -- x - mean = 0 exactly, it quantises to 0 with residual 0 and its whole
+  // contribution q_d x_d sits in the query's offset q.mean
+  col[d] = finite ? mean : 0.f;
+  col[kDim + d] = inv;
+  col[2 * kDim + d] = finite && c > 0.f ? c / 127.0f : 0.f;
 }
 
-// one wave per row: xi = clamp(rint((x - mean) 127 / c)); R, Xn, Xf of QuantStats (rounded up a little, as non-negative float bits)
+// xi = clamp(rint((x - mean) 127 / c)); R, Xn, Xf of QuantStats (rounded up a little, as non-negative float bits).
+// 16 lanes per row (8 dimensions = 16 bytes of fp16 in, 8 bytes of int8 out each), four rows per wave and trip, a grid-stride
+// loop; the maxima are kept per lane group and reach the device words once per wave.
 __global__ __launch_bounds__(256) void quantise_rows_i8(const _Float16* __restrict__ xb, long long n, const float* __restrict__ col,
                                                         signed char* __restrict__ xb8, QuantStats* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
-  const float mu0 = col[2 * lane], mu1 = col[2 * lane + 1];
-  const float inv0 = col[kDim + 2 * lane], inv1 = col[kDim + 2 * lane + 1];
-  float max_r = 0.f, max_i = 0.f, max_x = 0.f;
-  for (long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4, e = 0; e < 4 && row < n; ++e, ++row) {
-    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    const f16x2 v = *(const f16x2*)(xb + row * kDim + 2 * lane);
-    const float x0 = (float)v[0], x1 = (float)v[1];
-    const float v0 = (x0 - mu0) * inv0, v1 = (x1 - mu1) * inv1;
-    const float i0 = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(v0)));
-    const float i1 = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(v1)));
-    const float r0 = v0 - i0, r1 = v1 - i1;
-    typedef signed char i8x2 __attribute__((ext_vector_type(2)));
-    const i8x2 o = {(signed char)(int)i0, (signed char)(int)i1};
-    *(i8x2*)(xb8 + row * kDim + 2 * lane) = o;
-    max_r = __builtin_fmaxf(max_r, wave_sum_f(r0 * r0 + r1 * r1));
-    max_i = __builtin_fmaxf(max_i, wave_sum_f(i0 * i0 + i1 * i1));
-    max_x = __builtin_fmaxf(max_x, wave_sum_f(x0 * x0 + x1 * x1));
+  const int sub = lane & 15;
+  float mu[8], inv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = col[sub * 8 + e];
+    inv[e] = col[kDim + sub * 8 + e];
   }
+  float max_r = 0.f, max_i = 0.f, max_x = 0.f;
+  const long long stride = (long long)gridDim.x * 16;
+  for (long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); row < n; row += stride) {
+    const f16x8 v = *(const f16x8*)(xb + row * kDim + sub * 8);
+    float sr = 0.f, si = 0.f, sx = 0.f;
+    typedef signed char i8x8 __attribute__((ext_vector_type(8)));
+    i8x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float x = (float)v[e];
+      const float t = (x - mu[e]) * inv[e];
+      const float i = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(t)));
+      const float r = t - i;
+      o[e] = (signed char)(int)i;
+      sr += r * r;
+      si += i * i;
+      sx += x * x;
+    }
+    *(i8x8*)(xb8 + row * kDim + sub * 8) = o;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes of the row
+      sr += __shfl_xor(sr, off, 64);
+      si += __shfl_xor(si, off, 64);
+      sx += __shfl_xor(sx, off, 64);
+    }
+    // (a NaN -- non-finite rows, flagged by column_stats -- compares false and leaves the maxima alone)
+    max_r = sr > max_r ? sr : max_r;
+    max_i = si > max_i ? si : max_i;
+    max_x = sx > max_x ? sx : max_x;
+  }
+  max_r = wave_max_f(max_r);
+  max_i = wave_max_f(max_i);
+  max_x = wave_max_f(max_x);
   if (lane == 0) {
-    // a NaN (non-finite rows: flagged by column_stats) compares false everywhere and leaves the maxima alone
     const float r = __builtin_sqrtf(max_r) * (1.0f + 0x1p-10f), i = __builtin_sqrtf(max_i) * (1.0f + 0x1p-10f),
                 x = __builtin_sqrtf(max_x) * (1.0f + 0x1p-10f);
     if (r > 0.f) atomicMax(&stats->max_resid, __float_as_uint(r));
@@ -842,9 +923,11 @@ __global__ __launch_bounds__(256) void prep_queries_i8(const _Float16* __restric
   if (lane == 0) {
     const float R = __uint_as_float(stats->max_resid) + 0x1p-10f, Xn = __uint_as_float(stats->max_inorm),
                 Xf = __uint_as_float(stats->max_xnorm);
-    // score units: the fp32 accumulation of the exact score's MFMA sums, fp16 subnormal operands should the matrix cores flush
-    // them (see query_margins), the rounding of `off` itself
-    const float delta = 0x1p-16f * n_q * Xf + 11.32f * 0x1p-14f * (n_q + Xf) + 0x1p-20f * abs_off;
+    // score units: the fp32 accumulation of the exact score's MFMA sums and the rounding of `off` itself.  (No term for fp16
+    // subnormal operands: v_mfma_f32_32x32x16_f16 multiplies them as their values on gfx950 --
+    // scripts/native/mfma_f16_subnormal_probe.cpp -- so the exact score is the sum the bound is about; with the term the
+    // exact-float32 mode carries for that case, corpora of values around 1e-3 nominated every row.)
+    const float delta = 0x1p-16f * n_q * Xf + 0x1p-20f * abs_off;
     NominateParams p;
     p.off = (float)off;
     p.inv_unit = inv;
@@ -2215,7 +2298,9 @@ hipError_t launch_column_stats(const void* xb16, long long n, float* partial, fl
 
 hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, QuantStats* stats, hipStream_t st) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(quantise_rows_i8, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, (const _Float16*)xb16, n, col, xb8, stats);
+  const long long want = (n + 15) / 16;
+  const unsigned grid = (unsigned)std::min<long long>(want, 8ll * 1024);
+  hipLaunchKernelGGL(quantise_rows_i8, dim3(grid), dim3(256), 0, st, (const _Float16*)xb16, n, col, xb8, stats);
   return hipGetLastError();
 }
 

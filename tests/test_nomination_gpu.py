@@ -1,0 +1,274 @@
+"""The int8 nomination scan (mips_filter_i8 + MFMA re-scoring in topk_merge) must be invisible: every result is the fp16
+scan's, bit for bit -- ids AND scores -- and therefore the oracle's on integer-valued corpora.
+
+Replaces the same call site as the fp16 scan: /root/reference/retrieval/eval_retrieval.py:98-104
+(`faiss.IndexFlatIP.add` / `.search`).  Mode "always" makes shards below the automatic 65536-row minimum and batches of
+<= 256 queries take the int8 rounds, so that the oracle still finishes in seconds."""
+import numpy as np
+import pytest
+
+from oracle import search_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _int_corpus(rng, n, lo=-4, hi=4):
+    return rng.integers(lo, hi + 1, (n, 128)).astype(np.float16)
+
+
+def _both(xb, xq, k, add=None, idx_offset=0):
+    """(D, I, stats) of the fp16 scan and of the int8 nomination scan on the same rows"""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    out = []
+    tq = torch.from_numpy(xq).cuda()
+    for mode in ("off", "always"):
+        ix = IndexFlatIP(128)
+        ix.configure_nomination(mode)
+        (add or (lambda index, rows: index.add(rows)))(ix, xb)
+        D, I = ix.search_device(tq, k, idx_offset=idx_offset)
+        out.append((D.cpu().numpy(), I.cpu().numpy(), ix.last_stats(), ix))
+    return out
+
+
+@pytest.mark.parametrize("n,nq,k,lo,hi", [(70000, 600, 80, -4, 4), (20000, 300, 80, -4, 4), (100000, 257, 5, -8, 8),
+                                          (40000, 512, 128, 0, 1), (9000, 40, 80, -4, 4), (70000, 1100, 1, -2, 2)])
+def test_integer_corpora_ids_and_scores_identical_to_the_oracle(gpu_device, n, nq, k, lo, hi):
+    rng = np.random.default_rng(n + nq + k)
+    xb, xq = _int_corpus(rng, n, lo, hi), _int_corpus(rng, nq, lo, hi)
+    (D0, I0, st0, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    assert st1["nomination"] and not st0["nomination"] and st1["nominated"] >= nq * min(k, 1)
+    np.testing.assert_array_equal(I1, Io)
+    np.testing.assert_array_equal(D1, Do)
+    np.testing.assert_array_equal(I0, Io)
+
+
+@pytest.mark.parametrize("dist", ["normal", "shifted", "anisotropic", "constant_dims", "tiny", "huge"])
+def test_float_corpora_bit_identical_to_the_fp16_scan(gpu_device, dist):
+    """Random fp16 data in the shapes that stress the quantiser: a large common component (what the centring is for), dimensions
+    of very different scale (per-dimension equalisation), constant dimensions (they quantise to nothing; their contribution
+    sits in the query's offset), values near the bottom / top of the fp16 range."""
+    rng = np.random.default_rng(5)
+    n, nq, k = 150000, 520, 80
+    xb = rng.standard_normal((n, 128)).astype(np.float32)
+    xq = rng.standard_normal((nq, 128)).astype(np.float32)
+    if dist == "shifted":
+        xb += 20.0
+    elif dist == "anisotropic":
+        xb *= np.exp(rng.uniform(-4, 4, 128)).astype(np.float32)
+    elif dist == "constant_dims":
+        xb[:, ::3] = 7.5
+        xb[:, 1] = 2000.0
+    elif dist == "tiny":
+        xb *= 1e-3
+        xq *= 1e-2
+    elif dist == "huge":
+        xb *= 40.0
+        xq *= 8.0
+    xb, xq = xb.astype(np.float16), xq.astype(np.float16)
+    (D0, I0, st0, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    assert st1["nomination"] and st1["fallback_rounds"] == 0
+    np.testing.assert_array_equal(I1, I0)
+    np.testing.assert_array_equal(D1.view(np.int32), D0.view(np.int32))
+    # and the fp16 scan is the oracle's search (same tolerance as test_random_fp16_matches_oracle)
+    Do, Io = search_oracle.topk_ip(xq[:64], xb, k)
+    np.testing.assert_allclose(D1[:64], Do, rtol=1e-5, atol=1e-4 * max(1.0, float(np.abs(Do).max())))
+    assert np.mean([len(set(a) & set(b)) / k for a, b in zip(I1[:64], Io)]) > 1 - 1e-4
+    # the margin is rigorous, not generous: a few times the fp16 scan's candidates (scripts/dev_int8_margin.py)
+    assert st1["nominated"] < 8 * max(st0["candidates"], nq * k), (st1, st0)
+
+
+def test_a_row_the_int8_score_undersells_by_most_of_the_margin_is_still_returned(gpu_device):
+    """A planted row whose rounding residuals all point along the query: its int8 score falls short of its exact score by 45 % of
+    the rigorous margin (0.44 against 0.97 in score units), and its exact score sits 0.04 above the k-th best.  A scan that
+    lowered its threshold by less than 40 % of the bound would lose it."""
+    rng = np.random.default_rng(17)
+    n, nq, k = 80000, 300, 10
+    xb = (rng.integers(-128, 129, (n, 128)) / 64.0).astype(np.float16)          # fp16-exact grid, |x| <= 2
+    xq = (rng.integers(-64, 65, (nq, 128)) / 64.0).astype(np.float16)
+    x32, q32 = xb.astype(np.float32), xq.astype(np.float32)
+    # the quantiser of csrc/mips_kernels.hip, restated: centre, scale every dimension to +-127, round
+    mu = x32.mean(axis=0)
+    c = np.abs(x32 - mu).max(axis=0)
+    q = 0                                                                         # the query the row is planted for
+    tau = np.sort(x32 @ q32[q])[-k]
+    # the planted row: a multiple of the query on the int8 grid plus a residual of 0.49 grid steps in every dimension, signed
+    # like the query's weight in that dimension (so that every rounding error lowers the int8 score); the multiple is raised
+    # until the exact score is just above tau
+    w = q32[q] * c / 127.0
+    s_q = np.abs(w).max() / 127.0
+    qi = np.clip(np.rint(w / s_q), -127, 127)
+    best = None
+    for alpha in np.arange(0.0, 120.0, 0.05):
+        base_i = np.clip(np.rint(alpha * q32[q] / np.abs(q32[q]).max()), -100, 100)
+        row = (mu + (c / 127.0) * (base_i + 0.49 * np.sign(w))).astype(np.float16).astype(np.float32)
+        score = float(row @ q32[q])
+        if score > tau:
+            xi = np.clip(np.rint((row - mu) * 127.0 / c), -127, 127)
+            best = (score - tau, row, score - (float(q32[q] @ mu) + s_q * float(qi @ xi)))
+            break
+    assert best is not None and best[0] < 0.2
+    xb[n // 2] = best[1].astype(np.float16)
+    x32 = xb.astype(np.float32)
+    u = w / (np.abs(w).max() / 127.0)
+    v = (x32 - x32.mean(axis=0)) * 127.0 / np.abs(x32 - x32.mean(axis=0)).max(axis=0)
+    margin = (np.abs(w).max() / 127.0) * (np.linalg.norm(u) * np.linalg.norm(v - np.rint(v), axis=1).max()
+                                          + np.linalg.norm(u - np.rint(u)) * np.linalg.norm(np.rint(v), axis=1).max())
+    assert best[2] > 0.4 * margin, (best[2], margin)      # a real stress of the bound, not a row it covers ten times over
+    (D0, I0, _, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    assert st1["nomination"]
+    assert n // 2 in Io[q]                                 # the planted row belongs to the answer ...
+    np.testing.assert_array_equal(I1, I0)                  # ... and the nomination scan returns it
+    np.testing.assert_array_equal(D1.view(np.int32), D0.view(np.int32))
+    assert np.mean([len(set(a) & set(b)) / k for a, b in zip(I1, Io)]) > 1 - 1e-3
+
+
+def test_data_that_does_not_quantise_goes_back_to_the_fp16_scan(gpu_device):
+    """One outlier per dimension (-2000 where the bulk is within +-4; the queries are non-negative, so the outliers themselves
+    never rank) stretches every dimension's scale until the bulk rows all quantise to zero: the first search nominates
+    everything (lists overflow, the fp16 overflow-safe path finishes it -- the result is still exact); the automatic mode then
+    stays with the fp16 scan until the rows change."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(23)
+    n, nq, k = 70000, 300, 20
+    xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq, 0, 4)
+    for d in range(128):
+        xb[1000 + 37 * d, d] = -2000.0
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    ix = IndexFlatIP(128)
+    ix.add(xb)
+    tq = torch.from_numpy(xq).cuda()
+    stats = []
+    for _ in range(2):
+        D, I = ix.search_device(tq, k)
+        np.testing.assert_array_equal(I.cpu().numpy(), Io)
+        np.testing.assert_array_equal(D.cpu().numpy(), Do)
+        stats.append(ix.last_stats())
+    assert stats[0]["nomination"] and (stats[0]["fallback_rounds"] > 0 or stats[0]["nominated"] > nq * 4096)
+    assert not stats[1]["nomination"] and stats[1]["fallback_rounds"] == 0
+    ix.add(xb[:1000])                                        # the rows changed: the copy is rebuilt, the verdict forgotten
+    D, I = ix.search_device(tq, k)
+    assert ix.last_stats()["nomination"]
+    Do2, Io2 = search_oracle.topk_ip(xq, np.concatenate([xb, xb[:1000]]), k)
+    np.testing.assert_array_equal(I.cpu().numpy(), Io2)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do2)
+
+
+def test_adversarial_order_overflows_into_the_fp16_path(gpu_device):
+    """Scores that rise with the row number: every row is nominated, the lists of the int8 rounds overflow and the fp16
+    overflow-safe path re-scans them -- exact, with the fallback counted."""
+    rng = np.random.default_rng(3)
+    n, nq, k = 90000, 300, 80
+    xb = rng.integers(-1, 2, (n, 128)).astype(np.float16)
+    xb[:, 0] = np.minimum(np.arange(n) // 7, 2000)
+    xq = rng.integers(0, 2, (nq, 128)).astype(np.float16)
+    xq[:, 0] = 1
+    (D0, I0, _, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(I1, Io)
+    np.testing.assert_array_equal(D1, Do)
+    assert st1["nomination"] and st1["fallback_rounds"] > 0
+
+
+def test_non_finite_rows_switch_the_scan_off(gpu_device):
+    """inf / NaN rows cannot be centred or scaled: the int8 copy is marked unusable and the fp16 scan (heap rule for
+    non-finite scores) answers, also in mode "always"."""
+    rng = np.random.default_rng(31)
+    n, nq, k = 70000, 300, 80
+    xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq)
+    xq[:, 0] = 1.0
+    xb[rng.choice(n, 30, replace=False), 0] = np.inf
+    xb[rng.choice(n, 30, replace=False), 1] = np.nan
+    (D0, I0, _, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    Do, Io = search_oracle.topk_ip_heap(xq, xb, k)
+    assert not st1["nomination"]
+    np.testing.assert_array_equal(I1, Io)
+    np.testing.assert_array_equal(D1, Do)
+
+
+def test_non_finite_queries_still_get_the_heap_rule(gpu_device):
+    rng = np.random.default_rng(37)
+    n, nq, k = 70000, 300, 10
+    xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq)
+    xq[5, 3] = np.inf
+    xq[9, 4] = np.nan
+    xq[11] = 0
+    (D0, I0, _, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    Do, Io = search_oracle.topk_ip_heap(xq, xb, k)
+    np.testing.assert_array_equal(I1, Io)
+    np.testing.assert_array_equal(D1, Do)
+
+
+def test_shards_offsets_and_the_deferred_search(gpu_device):
+    """Shard-local int8 copies (each shard centres and scales on its own rows), global ids, the rank merge, and the enqueued
+    form of the search (`search_begin` / `finish`, what the sharded step uses)."""
+    import torch
+    from proqa_amd.index import IndexFlatIP, merge_topk_device
+    rng = np.random.default_rng(41)
+    n, nq, k = 210000, 400, 80
+    xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq)
+    tq = torch.from_numpy(xq).cuda()
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    parts = []
+    for lo, hi in ((0, 70000), (70000, 140001), (140001, n)):
+        ix = IndexFlatIP(128)
+        ix.configure_nomination("always")
+        ix.add(torch.from_numpy(xb[lo:hi]).cuda())
+        parts.append(ix.search_device(tq, k, idx_offset=lo))
+        assert ix.last_stats()["nomination"]
+    D, I = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do)
+
+
+def test_rows_added_after_a_search_rebuild_the_copy(gpu_device):
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(43)
+    xb, xq = _int_corpus(rng, 120000), _int_corpus(rng, 300)
+    tq = torch.from_numpy(xq).cuda()
+    ix = IndexFlatIP(128)
+    ix.configure_nomination("always")
+    ix.add(xb[:70000])
+    D, I = ix.search_device(tq, 80)
+    np.testing.assert_array_equal(I.cpu().numpy(), search_oracle.topk_ip(xq, xb[:70000], 80)[1])
+    ix.add(xb[70000:] * 3)                    # a different scale: the old per-dimension maxima no longer hold
+    both = np.concatenate([xb[:70000], xb[70000:] * 3])
+    D, I = ix.search_device(tq, 80)
+    Do, Io = search_oracle.topk_ip(xq, both, 80)
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do)
+    ix.reset()
+    ix.add(xb[:66000])
+    D, I = ix.search_device(tq, 80)
+    np.testing.assert_array_equal(I.cpu().numpy(), search_oracle.topk_ip(xq, xb[:66000], 80)[1])
+    assert ix.last_stats()["nomination"]
+
+
+def test_automatic_mode_picks_the_scan_by_shape(gpu_device):
+    """default mode: the int8 rounds for batches of more than 256 queries with k <= 128 on shards of >= 65536 rows; the fp16
+    scan for everything else (small batches, large k, small shards, exact-float32 indexes)."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(47)
+    xb = _int_corpus(rng, 70000)
+    ix = IndexFlatIP(128)
+    ix.add(xb)
+    for nq, k, want in ((300, 80, True), (256, 80, False), (300, 129, False), (300, 2000, False)):
+        xq = _int_corpus(rng, nq)
+        D, I = ix.search_device(torch.from_numpy(xq).cuda(), k)
+        assert ix.last_stats()["nomination"] == want, (nq, k)
+        Do, Io = search_oracle.topk_ip(xq, xb, k)
+        np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    small = IndexFlatIP(128)
+    small.add(xb[:60000])
+    small.search_device(torch.from_numpy(_int_corpus(rng, 300)).cuda(), 80)
+    assert not small.last_stats()["nomination"]
+    f32 = IndexFlatIP(128)
+    f32.add(xb.astype(np.float32) + np.float32(1e-4))        # values fp16 cannot hold: exact-float32 mode
+    assert f32.exact_f32
+    f32.search_device(torch.from_numpy(_int_corpus(rng, 300)).cuda(), 80)
+    assert not f32.last_stats()["nomination"]
