@@ -369,7 +369,10 @@ int proqa_npy_write_rows(const char* path, int64_t row0, int64_t n, const void* 
  * the caller's reference tokenizer.
  * ---------------------------------------------------------------------------------- */
 typedef struct proqa_wordpiece proqa_wordpiece;
-/* vocab: the tokens of vocab.txt joined by '\n' (token i has id i), vocab_bytes long; do_lower_case as the model's */
+/* vocab: the tokens of vocab.txt joined by '\n' (token i has id i), vocab_bytes long; do_lower_case: bit 0 as the model's,
+ * bit 1 = ASCII only (every text with a byte >= 0x80 is flagged -1: for callers whose reference tokenizer is NOT the
+ * tokenizers library the tables were generated from -- the pure-Python BertTokenizer lower-cases whole strings (final sigma),
+ * NFC-normalises first and carries its own Unicode data version) */
 int proqa_wordpiece_create(const char* vocab, size_t vocab_bytes, int do_lower_case, proqa_wordpiece** out);
 int proqa_wordpiece_free(proqa_wordpiece* tok);
 /* texts[i] (text_bytes[i] bytes, UTF-8, not NUL-terminated) -> ids_out[i, 0..max_length) = [CLS] pieces [SEP] truncated

@@ -111,6 +111,7 @@ struct Problem {
   Layout la = nullptr, lb = nullptr, lc = nullptr;
   size_t workspace = 0;
   bool usable = false;
+  Algo algo = {};   // the pinned algorithm as matmulIsAlgoSupported returned it for THIS problem (an in / out parameter)
 };
 
 }  // namespace
@@ -240,7 +241,13 @@ int lt_gemm_tn(LtGemm* g, const void* x, const void* w, void* out, int64_t M, in
   // prefetch in flight -- then returns garbage (errors of 1e3 and infinities at every M, N of scripts/dev_lt_grid.py).
   if (M % 256 || N % 256 || K % 64 || K < 256) return 1;
   const Api& a = api();
-  if (!g->searched) search_by_name(g, M, N, K);
+  if (!g->searched) {
+    search_by_name(g, M, N, K);
+    // said once per handle: which dense path the large layers run on (a ROCm point release can change it silently)
+    if (!g->have_algo)
+      fprintf(stderr, "proqa: no pinned hipBLASLt kernel in the loaded library (%d x %d x %d): the large dense layers run on "
+              "rocblas_gemm_ex\n", (int)M, N, K);
+  }
   if (!g->have_algo) return 1;
   const auto key = std::make_tuple(M, N, K);
   auto it = g->problems.find(key);
@@ -253,8 +260,8 @@ int lt_gemm_tn(LtGemm* g, const void* x, const void* w, void* out, int64_t M, in
     const float alpha = 1.f, beta = 0.f;
     if (make_layouts(a, M, N, K, p)) {
       size_t need = 0;
-      Algo algo = g->algo;
-      p.usable = a.supported(g->handle, g->desc, &alpha, p.la, p.lb, &beta, p.lc, p.lc, algo, need) == HIPBLAS_STATUS_SUCCESS;
+      p.algo = g->algo;
+      p.usable = a.supported(g->handle, g->desc, &alpha, p.la, p.lb, &beta, p.lc, p.lc, p.algo, need) == HIPBLAS_STATUS_SUCCESS;
       p.workspace = need;
     }
     it = g->problems.emplace(key, p).first;
@@ -270,7 +277,7 @@ int lt_gemm_tn(LtGemm* g, const void* x, const void* w, void* out, int64_t M, in
     g->ws_bytes = p.workspace;
   }
   const float alpha = 1.f, beta = 0.f;
-  const hipblasStatus_t s = a.matmul(g->handle, g->desc, &alpha, w, p.la, x, p.lb, &beta, out, p.lc, out, p.lc, &g->algo, g->ws,
+  const hipblasStatus_t s = a.matmul(g->handle, g->desc, &alpha, w, p.la, x, p.lb, &beta, out, p.lc, out, p.lc, &p.algo, g->ws,
                                      g->ws_bytes, st);
   if (s != HIPBLAS_STATUS_SUCCESS) return fail(PROQA_EHIP, "hipblasLtMatmul (%s) failed: status %d", g->name.c_str(), (int)s);
   return 0;

@@ -45,6 +45,7 @@ struct proqa_index {
   bool exact = false;
   float* xb32 = nullptr;
   int64_t capacity32 = 0;
+  int64_t rows32 = 0;                      // float32 rows written so far (>= n while an add call is uploading its pieces)
   unsigned* norm_stats = nullptr;          // device: {max ||x - fp16(x)||, max ||fp16(x)||} as float bits
   float* xq32 = nullptr;                   // workspace [ws_nq_pad,128]
   float* margin = nullptr;                 // workspace [ws_nq_pad]
@@ -163,8 +164,12 @@ int reserve_rows32(proqa_index* idx, int64_t rows) {
   hipError_t e = try_malloc((void**)&p, (size_t)cap * kDim * 4);
   if (e != hipSuccess) return fail(PROQA_ENOMEM, "hipMalloc of %lld float32 index rows failed: %s", (long long)cap,
                                    hipGetErrorString(e));
-  if (idx->n > 0 && idx->xb32)
-    PROQA_HIP(hipMemcpy(p, idx->xb32, (size_t)idx->n * kDim * 4, hipMemcpyDeviceToDevice));
+  // every float32 row written so far moves along -- idx->n counts the rows of COMPLETED calls only, the earlier pieces of
+  // the call in progress sit above it (a reset() index re-filled by one large inexact float32 add used to lose them here)
+  // (nothing is kept while the index is being switched to exact mode: enable_exact rewrites every row)
+  const int64_t keep = std::min(idx->capacity32, idx->exact ? std::max(idx->n, idx->rows32) : idx->rows32);
+  if (keep > 0 && idx->xb32)
+    PROQA_HIP(hipMemcpy(p, idx->xb32, (size_t)keep * kDim * 4, hipMemcpyDeviceToDevice));
   if (idx->xb32) PROQA_HIP(hipFree(idx->xb32));
   idx->xb32 = p;
   idx->capacity32 = cap;
@@ -178,9 +183,11 @@ int enable_exact(proqa_index* idx, hipStream_t st) {
   PROQA_HIP(hipStreamSynchronize(st));
   if (!idx->norm_stats) PROQA_HIP(hipMalloc((void**)&idx->norm_stats, 2 * sizeof(unsigned)));
   PROQA_HIP(hipMemsetAsync(idx->norm_stats, 0, 2 * sizeof(unsigned), st));
+  idx->rows32 = 0;   // whatever an earlier exact episode left in the buffer is stale
   if (int rc = reserve_rows32(idx, std::max<int64_t>(idx->n, 1))) return rc;
   PROQA_HIP(launch_upconvert_f16_to_f32(idx->xb, idx->xb32, idx->n * kDim, st));
   PROQA_HIP(launch_row_norm_stats(idx->xb32, idx->xb, idx->n, idx->norm_stats, st));
+  idx->rows32 = idx->n;
   idx->exact = true;
   return PROQA_OK;
 }
@@ -196,6 +203,7 @@ int finish_rows_exact(proqa_index* idx, int64_t r0, int64_t m, const float* src3
   else
     PROQA_HIP(launch_upconvert_f16_to_f32(idx->xb + (size_t)r0 * kDim * 2, dst, m * kDim, st));
   PROQA_HIP(launch_row_norm_stats(dst, idx->xb + (size_t)r0 * kDim * 2, m, idx->norm_stats, st));
+  idx->rows32 = std::max(idx->rows32, r0 + m);
   return PROQA_OK;
 }
 
@@ -908,7 +916,8 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool la
   if (p.n_sample > idx->n / 4) return p;                       // k is a large part of the shard
   // Dense regime (thousands of queries x a large k: more than every second 32-row unit of a wave holds a score above its
   // threshold): compact lists of 8-byte keys, ~24 per list of 70; otherwise column records, ~8 per list of 24.
-  p.compact = kOnePassCompact && !latency_bound && expected / (double)idx->n * 2048.0 > 0.5;
+  // (compact lists exist for the 8 x 64-query tiling only: with PROQA_FILTER_QW=4 / 1 the launch logs column records)
+  p.compact = kOnePassCompact && !latency_bound && kWideQw == 2 && expected / (double)idx->n * 2048.0 > 0.5;
   p.lane_cap = p.compact ? (unsigned)kCompactLaneCap : (unsigned)kOnePassLaneCap;
   const double per_list = p.compact ? 24.0 : 8.0;
   p.want_chunks = round_up<unsigned>((unsigned)std::ceil(expected / (2.0 * per_list)), 8);   // two lists per chunk
@@ -1096,12 +1105,14 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
   const int rc = search_device_impl(idx, xq_dev, nq, dtype, k, idx_offset, D_dev, I_dev, st, defer, status_dev);
 #ifdef PROQA_FILTER_STAMPS
   {
-    unsigned long long h[5];
+    unsigned long long h[8];
     read_filter_stamps(h);
     if (h[4])
       fprintf(stderr, "filter stamps (one wave per workgroup, %llu workgroups over all launches of the search): per unit MFMA section %.1f "
-              "ticks, test section %.1f ticks; units per wave %.0f, wave lifetime per unit %.1f ticks\n", h[4], (double)h[0] / h[2],
-              (double)h[1] / h[2], (double)h[2] / h[4], (double)h[3] / h[2]);
+              "ticks, test section %.1f ticks; units per wave %.0f, wave lifetime per unit %.1f ticks; int8 scan: barrier + DMA issue %.1f "
+              "ticks per unit, %.3f excursions per unit of %.1f ticks each\n", h[4], (double)h[0] / h[2],
+              (double)h[1] / h[2], (double)h[2] / h[4], (double)h[3] / h[2], (double)h[5] / h[2], (double)h[7] / h[2],
+              h[7] ? (double)h[6] / h[7] : 0.0);
   }
 #endif
   // a search that ran to completion has a final result: its status word is 0 (the deferred kind writes the word itself)
@@ -1375,6 +1386,7 @@ int proqa_index_reset(proqa_index* idx) {
     idx->owns_xb = true;
   }
   idx->n = 0;
+  idx->rows32 = 0;
   ++idx->rows_epoch;
   idx->exact = false;   // the float32 buffer stays allocated for the next use
   return PROQA_OK;

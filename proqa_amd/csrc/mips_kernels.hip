@@ -682,13 +682,29 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
 #pragma unroll
   for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(lds + off0 + rd_off[j]);
   constexpr int kSubs = kStageRows / kSubRows;
+#ifdef PROQA_FILTER_STAMPS
+  unsigned long long stamp_mfma = 0, stamp_test = 0, stamp_units = 0, stamp_bar = 0, stamp_hit = 0, stamp_hits = 0;
+  const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int s = 0; s < nstages; ++s) {
 #pragma unroll
     for (int u = 0; u < kSubs; ++u) {
       if (u == 2 && !(a.flags & 16u)) {   // (flag 16, cut experiment: no barrier, no DMA after the prologue -- stale stages)
+#ifdef PROQA_FILTER_STAMPS
+        const unsigned long long sb0 = __builtin_amdgcn_s_memtime();
+#endif
         publish(s + 2 < nstages);
         if (s + 3 < nstages) issue_stage(s + 3, off3);
+#ifdef PROQA_FILTER_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        stamp_bar += __builtin_amdgcn_s_memtime() - sb0;
+#endif
       }
+#ifdef PROQA_FILTER_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       const char* nxt = (u + 1 < kSubs) ? lds + off0 + (u + 1) * kSubBytesI8 : lds + off1;
       i32x16 acc[QW];
 #pragma unroll
@@ -703,6 +719,11 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
       if (a.flags & 1u) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
+#ifdef PROQA_FILTER_STAMPS
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 
       bool hit[QW];
       bool any_hit = false;
@@ -718,6 +739,15 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
         asm volatile("" :: "v"(acc[0][0]), "v"(acc[QW - 1][15]));   // keeps the MFMAs
       }
       if (a.flags & 32u) any_hit = false;   // cut experiment: examined, never logged
+#ifdef PROQA_FILTER_STAMPS
+      const bool stamp_any = __any(any_hit);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+      stamp_mfma += st1 - st0;
+      stamp_test += st2 - st1;
+      ++stamp_units;
+#endif
       if (__builtin_expect(__any(any_hit), 0)) {
         int rel0 = s * kStageRows + u * kSubRows;
         asm volatile("" : "+v"(rel0));
@@ -734,6 +764,13 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
           }
         }
       }
+#ifdef PROQA_FILTER_STAMPS
+      if (stamp_any) {
+        __builtin_amdgcn_sched_barrier(0);
+        stamp_hit += __builtin_amdgcn_s_memtime() - st2;
+        ++stamp_hits;
+      }
+#endif
     }
     const int t = off0;
     off0 = off1;
@@ -741,6 +778,19 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     off2 = off3;
     off3 = t;
   }
+#ifdef PROQA_FILTER_STAMPS
+  if (lane == 0 && wave == 3) {   // one wave per workgroup reports: sums over its units (s_memtime ticks)
+    unsigned long long* dbg = g_filter_stamps;
+    atomicAdd(dbg + 0, stamp_mfma);
+    atomicAdd(dbg + 1, stamp_test);
+    atomicAdd(dbg + 2, stamp_units);
+    atomicAdd(dbg + 3, __builtin_amdgcn_s_memtime() - stamp_t0);
+    atomicAdd(dbg + 4, 1ull);
+    atomicAdd(dbg + 5, stamp_bar);
+    atomicAdd(dbg + 6, stamp_hit);
+    atomicAdd(dbg + 7, stamp_hits);
+  }
+#endif
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk) {
     if (lane_n[blk] > lane_cap) {
@@ -2313,9 +2363,9 @@ hipError_t launch_prep_queries_i8(const void* xq_pad16, long long nq_pad, const 
 }
 
 #ifdef PROQA_FILTER_STAMPS
-void read_filter_stamps(unsigned long long* out5) {
+void read_filter_stamps(unsigned long long* out5) {   // (eight words)
   (void)hipDeviceSynchronize();
-  (void)hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_filter_stamps), 5 * sizeof(unsigned long long));
+  (void)hipMemcpyFromSymbol(out5, HIP_SYMBOL(g_filter_stamps), 8 * sizeof(unsigned long long));
   unsigned long long z[8] = {};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_filter_stamps), z, sizeof z);
 }

@@ -187,8 +187,11 @@ class TokenizeCollate:
                 if basic is not None and (getattr(basic, "never_split", None) or not getattr(basic, "tokenize_chinese_chars", True)
                                           or getattr(basic, "strip_accents", None) not in (None, bool(getattr(basic, "do_lower_case", True)))):
                     return None
-                lower = bool(getattr(tokenizer, "do_lower_case", True))
-            return ("\n".join(toks).encode("utf-8"), lower)
+                # the generated tables restate the tokenizers library's BertNormalizer; the pure-Python BasicTokenizer differs from
+                # it beyond ASCII (str.lower() applies the final-sigma rule, NFC before anything else, another Unicode data
+                # version): the native path takes ASCII texts only, everything else goes to the tokenizer itself (bit 1)
+                lower = int(bool(getattr(tokenizer, "do_lower_case", True))) | 2
+            return ("\n".join(toks).encode("utf-8"), int(lower))
         except Exception:
             return None
 
@@ -199,7 +202,7 @@ class TokenizeCollate:
             lib = _lib.load()
             h = ctypes.c_void_p()
             blob, lower = self._native_spec
-            _lib.check(lib.proqa_wordpiece_create(blob, len(blob), 1 if lower else 0, ctypes.byref(h)))
+            _lib.check(lib.proqa_wordpiece_create(blob, len(blob), int(lower), ctypes.byref(h)))
             self._native = (lib, h)
         return self._native
 

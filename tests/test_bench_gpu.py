@@ -23,6 +23,7 @@ def _run(gpus, extra_env=None):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]            # exactly one line on stdout
+    assert len(lines[0]) <= 6000                        # the driver keeps ~8 KB of tail: every leg must be inside it
     return json.loads(lines[0])
 
 
@@ -38,6 +39,26 @@ def test_bench_starts_its_own_ranks(gpu_device):
     assert two["scaling"] == "strong" and two["value"] > 0
     # sharded == unsharded, bit for bit (ids and scores of all 64 x 80 results)
     assert two["result"] == one["result"]
+
+
+def test_the_full_line_fits_the_drivers_tail(gpu_device):
+    """The default N = 1 run with every leg (shrunk: 1M rows, 3 steps, 20 k passages) prints one line of <= 6000 bytes that
+    still carries the headline, the roofline object, the fp16 scan beside the nomination scan, and the secondary legs."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rows", "1000000", "--queries", "600", "--steps", "3", "--warmup", "1",
+           "--encode-steps", "2", "--corpus-passages", "4096", "--cli-passages", "4096"]
+    env = dict(os.environ)
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 6000, len(lines[0])
+    line = json.loads(lines[0])
+    for key in ("roofline", "cpu_baseline", "scan_small_batch", "shard_sweep", "large_k", "search_cli_eval", "kmeans", "online",
+                "float32_index", "encode", "recall_parity"):
+        assert key in line, key
+    assert line["roofline"]["nomination"] == "int8" and line["fp16_scan"]["ids_equal"] and line["fp16_scan"]["scores_equal"]
+    assert line["encode"]["gemm_kernel"]
 
 
 def test_bench_refuses_a_launcher_of_another_size(gpu_device):

@@ -396,6 +396,44 @@ def test_native_wordpiece_is_declined_for_other_tokenizers(tokenizer):
     assert datasets.TokenizeCollate._native_vocab(tokenizer) is not None
 
 
+def test_a_pure_python_tokenizer_gets_the_native_path_for_ascii_only(tokenizer):
+    """The generated tables restate the tokenizers library's BertNormalizer.  A pure-Python BertTokenizer (what the reference's
+    transformers 2.5.1 BertTokenizer is) lower-cases whole strings -- final sigma: "ΟΔΟΣ" -> "οδος", per character "οδοσ" --
+    NFC-normalises first and carries another Unicode data version, so for such a tokenizer the native code takes ASCII texts
+    only (bit 1 of proqa_wordpiece_create's flag) and flags everything else for the tokenizer itself."""
+    import ctypes
+    from proqa_amd import _lib
+
+    class PurePython:   # no backend_tokenizer / _tokenizer: the slow-tokenizer branch of _native_vocab
+        unk_token, cls_token, sep_token = "[UNK]", "[CLS]", "[SEP]"
+        do_lower_case = True
+        do_basic_tokenize = True
+        added_tokens_encoder = {}
+        basic_tokenizer = None
+
+        def get_vocab(self):
+            return {"[PAD]": 0, "[UNK]": 1, "[CLS]": 2, "[SEP]": 3, "street": 4, "οδος": 5, "οδοσ": 6}
+    spec = datasets.TokenizeCollate._native_vocab(PurePython())
+    assert spec is not None and spec[1] == 3                      # lower-case | ASCII only
+    assert datasets.TokenizeCollate._native_vocab(tokenizer)[1] in (0, 1)   # the tokenizers-backed one: whole BMP
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.proqa_wordpiece_create(spec[0], len(spec[0]), spec[1], ctypes.byref(h)))
+    try:
+        for text, want in (("Street", [2, 4, 3]), ("ΟΔΟΣ", None), ("street ΟΔΟΣ", None), ("caf\u00e9", None)):
+            b = text.encode("utf-8")
+            row = np.zeros((1, 8), dtype=np.int64)
+            ln = np.empty(1, dtype=np.int32)
+            _lib.check(lib.proqa_wordpiece_encode_batch(h, (ctypes.c_char_p * 1)(b), (ctypes.c_int64 * 1)(len(b)), 1, 8,
+                                                        row.ctypes.data, ln.ctypes.data, 1))
+            if want is None:
+                assert ln[0] == -1, text
+            else:
+                assert ln[0] == len(want) and row[0, : ln[0]].tolist() == want
+    finally:
+        lib.proqa_wordpiece_free(h)
+
+
 def test_jsonl_texts_is_the_lazy_form_of_emdataset(tokenizer, tmp_path):
     texts = _random_strings(300, 9)
     path = tmp_path / "in.jsonl"

@@ -646,6 +646,40 @@ def test_exact_mode_switch_in_a_later_upload_piece(gpu_device):
     np.testing.assert_array_equal(D, Do)
 
 
+def test_exact_index_refilled_after_reset_by_a_larger_inexact_file(gpu_device, tmp_path):
+    """reset() keeps the float32 buffer of the exact episode before it.  A later add_npy of a LARGER float32 file whose first
+    inexact value comes late grows that buffer in the middle of the call: the float32 copies of the pieces uploaded before
+    must move along (they used to be dropped: idx->n counts completed calls only), or the re-scoring reads garbage rows."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(57)
+    index = IndexFlatIP(128)
+    first = rng.integers(-4, 5, (20000, 128)).astype(np.float32)
+    first[7, 3] = 1.0 + 2.0 ** -12                             # not an fp16 number: exact mode, a 20000-row float32 buffer
+    index.add(first)
+    assert index.exact_f32
+    index.reset()
+    n = 200000                                                 # > the old buffer; pieces of 16384 rows
+    xb = rng.integers(-4, 5, (n, 128)).astype(np.float32)
+    xb[:, 0] = rng.integers(-2000, 2001, n)
+    xb[150000:, 1] += np.float32(2.0 ** -12)                   # the first inexact values sit in a late piece
+    path = tmp_path / "rows.npy"
+    np.save(path, xb)
+    index.add_npy(str(path))
+    assert index.exact_f32 and index.ntotal == n
+    xq = rng.integers(-3, 4, (11, 128)).astype(np.float32)
+    xq[:, 0] = 1.0
+    D, I = index.search(xq, 40)
+    Do, Io = search_oracle.topk_ip_exact(xq, xb, 40)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    # the same through add() of a host array (1M-row pieces): the late switch inside one call
+    index.reset()
+    index.add(xb)
+    D, I = index.search(xq, 40)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+
+
 def test_exact_mode_on_an_adopted_shard(gpu_device):
     """An adopted (caller-owned, fp16) shard searched with float32 queries fp16 cannot hold: the index builds
     its float32 copies next to the adopted rows."""
