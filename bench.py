@@ -231,8 +231,9 @@ def encode_leg(args, device, world, rank):
     res = {
         "metric": "passages/sec encoded", "value": pps, "unit": "passages/s", "ms_per_step": dt / args.encode_steps * 1e3,
         "steps": args.encode_steps, "scaling": "weak", "dtype": "f16",
-        "config": {"workload": "bert-base-uncased shape (12x768x12x3072), batch 512 x 128 pre-tokenised ids, "
-                               "fp16 weights/activations, fp32 accumulate, random N(0,0.02) weights", "batch": B,
+        # bert-base-uncased shape (12 x 768 x 12 x 3072), pre-tokenised ids, fp16 weights / activations, fp32 accumulate,
+        # random N(0, 0.02) weights (BASELINE configs[1])
+        "config": {"workload": f"bert-base shape, {B} x {S} pre-tokenised ids, fp16, random weights (configs[1])", "batch": B,
                    "seq_len": S},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": tf / PEAK_MFMA_F16_TFLOPS, "traffic": encode_traffic(B, S),
@@ -457,7 +458,7 @@ def cli_text_leg(args, device, sd, non_ascii=0.0, n_pass=None):
                                 "gpu_busy_seconds": st["gpu_busy_seconds"], "loader_wait_seconds": st["loader_wait_seconds"],
                                 "feed_seconds": st["feed_seconds"], "upload_seconds": st["upload_seconds"],
                                 "gpu_idle_fraction": max(0.0, 1.0 - st["gpu_busy_seconds"] / st["loop_seconds"])},
-                "non_ascii_passage_fraction": non_ascii, "tokenised_by_the_native_wordpiece": native_share,
+                "non_ascii_passage_fraction": non_ascii, "native_wordpiece": native_share,
                 "tokenise_only": {"passages_per_s": n_tok / t_tok, "passages": n_tok,
                                   "note": "the same loader (TextBatchLoader: one producer thread; libproqa_hip.so's table-driven "
                                           "WordPiece on cores - 2 threads) with nothing consumed on the GPU"},
@@ -595,7 +596,15 @@ def cli_eval_leg(args, device, xb, xq, I_top, k):
             blob[:, 8 - j] = ord("0") + (ids // 10 ** j) % 10
         blob.tofile(os.path.join(d, "idx_id.ids"))
         np.save(os.path.join(d, "idx_id.off.npy"), np.arange(n + 1, dtype=np.int64) * 11)
-        del blob, ids, words, docs
+        # the text sidecar of gen_index_id_map.write_text_sidecar, in bulk: every distinct passage once, row r -> span of
+        # passage r % n_docs (rows with the same text share it)
+        enc = [t.encode("utf-8") for t in docs]
+        ends = np.cumsum([len(b_) for b_ in enc], dtype=np.int64)
+        with open(os.path.join(d, "idx_id.txt"), "wb") as f:
+            f.write(b"".join(enc))
+        doc_spans = np.stack([ends - np.array([len(b_) for b_ in enc], dtype=np.int64), ends], axis=1)
+        np.save(os.path.join(d, "idx_id.txtoff.npy"), doc_spans[ids])
+        del blob, ids, words, docs, enc, doc_spans
         t_prep = time.perf_counter() - t_prep
 
         def drop_cache():
@@ -649,6 +658,14 @@ def cli_eval_leg(args, device, xb, xq, I_top, k):
                "--idx-id-map", os.path.join(d, "idx_id.ids")]
         env = {kk: v for kk, v in os.environ.items() if kk not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env["PROQA_STATS_JSON"] = stats_path
+        # first the reference's route for the texts (row -> doc id -> one sqlite query per hit), then the same command line
+        # with the index's text sidecar in use (the default when <stem>.txt sits next to the id map): same printed lines
+        t0 = time.perf_counter()
+        proc_db = subprocess.run(cmd + ["--no-text-sidecar"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        wall_db = time.perf_counter() - t0
+        if proc_db.returncode != 0:
+            return {"error": proc_db.stderr[-800:]}
+        st_db = json.load(open(stats_path))
         t0 = time.perf_counter()
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         wall = time.perf_counter() - t0
@@ -656,6 +673,7 @@ def cli_eval_leg(args, device, xb, xq, I_top, k):
             return {"error": proc.stderr[-800:]}
         st = json.load(open(stats_path))
         lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("Top ")]
+        same_lines = lines == [ln for ln in proc_db.stdout.splitlines() if ln.startswith("Top ")]
         recall = {ln.split()[1]: float(ln.split(": ")[1].split()[0]) for ln in lines}
         # the reference's own id map (json.load of {"<row>": id}, eval_retrieval.py:73-74) on a 1M-entry sample
         sample = 1_000_000
@@ -677,7 +695,9 @@ def cli_eval_leg(args, device, xb, xq, I_top, k):
                                "search": st.get("search_seconds"),
                                "idx2id": st.get("idx2id_seconds"), "scoring": st.get("scoring_seconds"),
                                "main_total": st.get("total_seconds"), "process_wall": wall},
-            "load_GBs_in_cli": st.get("load_gbs"),
+            "load_GBs_in_cli": st.get("load_gbs"), "text_sidecar": st.get("text_sidecar"),
+            "sqlite_route": {"value": wall_db, "idx2id": st_db.get("idx2id_seconds"), "scoring": st_db.get("scoring_seconds"),
+                             "same_printed_lines": same_lines},
             "loader": {"cold_GBs": load_cold, "warm_GBs": load_warm, "dd_style_read_cold_GBs": dd_cold, "dd_style_read_warm_GBs": dd_warm,
                        "cache_drop_seconds": t_drop,
                        "note": "proqa_index_add_npy (4 reader threads -> pinned ring -> HBM) on the whole file (cold = also the first call of the process); dd-style = one thread "
@@ -978,10 +998,11 @@ def main():
             ix.adopt_device(xb[:rows_g])
             dt_g = timed(lambda: ix.search_device(xq, k), max(5, args.steps // 2), 2, 1, device)
             ms_g = dt_g / max(5, args.steps // 2) * 1e3
-            sweep.append({"ranks": g_, "rows_per_rank": rows_g, "ms_per_search": ms_g,
-                          "queries_per_s_projected": nq / (ms_g * 1e-3)})
+            sweep.append((g_, rows_g, ms_g))
             ix.close()
-        line["shard_sweep"] = {"note": "N=1 timing of the per-rank search of a G-rank job (no collective)", "points": sweep}
+        # N=1 timing of the per-rank search of a G-rank job (no collective): parallel arrays
+        line["shard_sweep"] = {"ranks": [p_[0] for p_ in sweep], "rows_per_rank": [p_[1] for p_ in sweep],
+                               "ms_per_search": [p_[2] for p_ in sweep]}
         # the reference's large-k callers on the same index: retrieval/trec_process.py:76 (6980 MS MARCO dev queries,
         # top-10000 of 8.8M passages) and qa/online_sampler.py:113 (one question, k = 5000)
         large = {}
@@ -1070,7 +1091,8 @@ NESTED_DROP = {"note", "metric", "gemm_kernel_full", "host_cores", "loader_worke
                "loader_wait_seconds", "gpu_busy_seconds", "bytes_written_per_rank", "parity_rows", "prepare_seconds_untimed",
                "index_file_bytes", "cache_drop_seconds", "iterations_warm", "iterations_timed", "scorer_processes", "seconds_d2h",
                "seconds_npy_write", "dd_style_read_cold_GBs", "dd_style_read_warm_GBs", "idx2id_json_route", "recall_expected",
-               "objective", "tokens_per_s", "gflop_per_passage_reference", "entries_sample", "higher_is_better", "seconds_encode_loop"}
+               "objective", "tokens_per_s", "gflop_per_passage_reference", "entries_sample", "higher_is_better", "seconds_encode_loop",
+               "traffic_age_commits", "points", "centroids", "non_ascii_passage_fraction", "recall_printed", "hbm_bytes_algorithmic"}
 
 
 def compact(obj, depth=0, parent=None):
@@ -1081,6 +1103,8 @@ def compact(obj, depth=0, parent=None):
         for k, v in obj.items():
             if depth > 0 and k in NESTED_DROP:
                 continue
+            if depth > 1 and k in ("unit", "passages", "dtype", "steps", "scaling") and parent not in ("roofline", "cpu_baseline"):
+                continue   # sub-legs inherit them from their leg (a roofline / cpu_baseline object keeps its unit)
             if k == "workload" and parent != "config":
                 continue
             if isinstance(v, str) and len(v) > MAX_STRING and k not in ("workload", "sample"):
@@ -1089,8 +1113,8 @@ def compact(obj, depth=0, parent=None):
         return out
     if isinstance(obj, (list, tuple)):
         return [compact(v, depth + 1, parent) for v in obj]
-    if isinstance(obj, float):
-        return float(f"{obj:.5g}") if obj == obj and abs(obj) != float("inf") else None
+    if isinstance(obj, float):   # five significant digits; four below the second level
+        return float(f"{obj:.5g}" if depth <= 2 else f"{obj:.4g}") if obj == obj and abs(obj) != float("inf") else None
     if isinstance(obj, str) and len(obj) > MAX_STRING:
         return obj[:MAX_STRING - 3] + "..."
     return obj

@@ -586,6 +586,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     ma.xq16 = idx->xq_pad;
     ma.xb16 = idx->xb;
     ma.stat_nominated = idx->stat_nom;
+    ma.lean = (kFilterFlags & 128u) ? 1 : 0;   // experiment switch
     PROQA_HIP(launch_merge(ma, nq_pad, st));
     if (kDebugCand) {   // developer: records the scan logged / rows the merges re-scored so far / candidates so far
       (void)hipStreamSynchronize(st);
@@ -654,6 +655,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.xq16 = nullptr;
   ma.xb16 = nullptr;
   ma.stat_nominated = nullptr;
+  ma.lean = 0;
 #ifdef PROQA_MERGE_STAMPS
   {
     static unsigned long long* dbg_buf = nullptr;

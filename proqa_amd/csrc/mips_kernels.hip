@@ -678,6 +678,7 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     return;
   }
 
+  if ((a.flags & 4u) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
   i32x4 af[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(lds + off0 + rd_off[j]);
@@ -791,6 +792,182 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     atomicAdd(dbg + 7, stamp_hits);
   }
 #endif
+#pragma unroll
+  for (int blk = 0; blk < QW; ++blk) {
+    if (lane_n[blk] > lane_cap) {
+      *a.overflow = 1u;
+      lane_n[blk] = lane_cap;
+    }
+    a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
+  }
+}
+
+// The same scan with HALF the workgroup barriers: the ring is two PAIRS of stages (2 x 32 KiB); the barrier at the top of pair
+// p publishes it (every wave's DMA pieces of the pair have landed: issued one pair -- eight units -- earlier; the only
+// younger vector-memory operations of the wave are its record stores, counted) and frees the buffers of pair p-1, which
+// receive pair p+1 right behind it.  Cycle stamps of the stage-wise kernel put 40 % of a wave's time into its one barrier per
+// stage (the eight waves of a workgroup drift apart by their excursions and by the issue arbitration).
+template <int QW>
+__global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8_pairs(FilterArgsI8 a) {
+  static_assert(QW == 1 || QW == 2, "8 waves x 32 / 64 queries");
+  __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytesI8];
+  constexpr int NW = kFilterWaves;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31;
+  const int half = lane >> 5;
+
+  const unsigned b = blockIdx.x;
+  const unsigned xcd = b & 7u;
+  const unsigned rest = b >> 3;
+  const unsigned qt = rest % a.store.n_qtiles;
+  const unsigned grp = rest / a.store.n_qtiles;
+  const unsigned chunk = grp * 8 + xcd;
+  const long long row_begin = a.slab_row0 + (long long)chunk * a.rows_per_chunk;
+  if (row_begin >= a.slab_row1) return;
+  long long row_end = row_begin + a.rows_per_chunk;
+  if (row_end > a.slab_row1) row_end = a.slab_row1;
+  const int n_rows = (int)(row_end - row_begin);
+  const int nstages = (n_rows + kStageRows - 1) / kStageRows;
+  const int npairs = (nstages + 1) / 2;
+  const unsigned row_begin32 = (unsigned)row_begin;
+  const signed char* chunk_base = a.xb8 + row_begin * kRowBytesI8;
+
+  const unsigned q0 = qt * (NW * QW * 32) + wave * (QW * 32);
+  i32x4 qf[QW][4];
+  int thr[QW];
+  WaveRecord* lane_list[QW];
+  unsigned lane_n[QW];
+  bool wave_live = false;
+#pragma unroll
+  for (int blk = 0; blk < QW; ++blk) {
+    const unsigned q = q0 + blk * 32 + li;
+    const signed char* qrow = a.xq8 + (size_t)q * kRowBytesI8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qf[blk][j] = *(const i32x4*)(qrow + (2 * j + half) * 16);
+    thr[blk] = nominate_threshold(a.tau[q], a.qp[q]);
+    wave_live = wave_live || thr[blk] != 0x7fffffff;
+    lane_n[blk] = 0u;
+    lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
+  }
+  wave_live = __any(wave_live);
+  const unsigned lane_cap = a.store.lane_cap;
+
+  unsigned rd_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rd_off[j] = li * kRowBytesI8 + (((2 * j + half) ^ ((li >> 1) & 7)) << 4);
+
+  constexpr int kDmaPerWave = (kStageBytesI8 / 1024) / NW;   // 2 per stage
+  int dma_rel[kDmaPerWave];
+  int dma_piece_off[kDmaPerWave];
+#pragma unroll
+  for (int e = 0; e < kDmaPerWave; ++e) {
+    dma_rel[e] = (wave * kDmaPerWave + e) * 8 + (lane >> 3);
+    dma_piece_off[e] = ((lane & 7) ^ ((dma_rel[e] >> 1) & 7)) * 16;
+  }
+  auto issue_pair = [&](int p) {   // stages 2p, 2p+1 -> the pair buffer p & 1
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s = 2 * p + h;
+      if (s < nstages) {
+#pragma unroll
+        for (int e = 0; e < kDmaPerWave; ++e) {
+          int rel = s * kStageRows + dma_rel[e];
+          rel = rel < n_rows ? rel : n_rows - 1;
+          const signed char* src = chunk_base + (long long)rel * kRowBytesI8 + dma_piece_off[e];
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(lds + ((p & 1) * 2 + h) * kStageBytesI8 +
+                                                                                     (wave * kDmaPerWave + e) * 1024),
+                                           16, 0, QW == 1 ? kDmaAux : 0);
+        }
+      }
+    }
+  };
+  int st_cur = 0;   // record-store instructions of this wave since the last barrier: all younger than the awaited DMA pieces
+  auto publish = [&]() {
+    const int allowed = __builtin_amdgcn_readfirstlane(st_cur);
+    if (allowed >= 40) {
+      asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    } else if (allowed >= 30) {
+      asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+    } else if (allowed >= 20) {
+      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    } else if (allowed >= 15) {
+      asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    } else if (allowed >= 10) {
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    } else if (allowed >= 5) {
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    st_cur = 0;
+  };
+  issue_pair(0);
+  if (!wave_live) {   // padding / exhausted queries only: the wave helps streaming and meets the barriers
+    for (int p = 0; p < npairs; ++p) {
+      publish();
+      if (p + 1 < npairs) issue_pair(p + 1);
+    }
+#pragma unroll
+    for (int blk = 0; blk < QW; ++blk)
+      a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
+    return;
+  }
+  for (int p = 0; p < npairs; ++p) {
+    publish();
+    if (p + 1 < npairs) issue_pair(p + 1);
+    const char* base = lds + (p & 1) * 2 * kStageBytesI8;
+    const int nunits = (nstages - 2 * p >= 2 ? 2 : 1) * (kStageRows / kSubRows);
+    i32x4 af[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(base + rd_off[j]);
+    for (int u0 = 0; u0 < nunits; u0 += 4) {
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        const int u = u0 + uu;
+        const char* nxt = base + (u + 1 < nunits ? u + 1 : u) * kSubBytesI8;
+        i32x16 acc[QW];
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk) acc[blk] = i32x16{0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+          for (int blk = 0; blk < QW; ++blk)
+            acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j], qf[blk][j], acc[blk], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
+        bool hit[QW];
+        bool any_hit = false;
+#pragma unroll
+        for (int blk = 0; blk < QW; ++blk) {
+          hit[blk] = max16_i32(acc[blk]) > thr[blk];
+          any_hit = any_hit || hit[blk];
+        }
+        if (__builtin_expect(__any(any_hit), 0)) {
+          int rel0 = (2 * p * 4 + u) * kSubRows;
+          asm volatile("" : "+v"(rel0));
+          const int rel = rel0 + 4 * half;
+#pragma unroll
+          for (int blk = 0; blk < QW; ++blk) {
+            if (__any(hit[blk])) {
+              st_cur += 5;
+              if (hit[blk]) {
+                const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;
+                write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, thr[blk]);
+                ++lane_n[blk];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int blk = 0; blk < QW; ++blk) {
     if (lane_n[blk] > lane_cap) {
@@ -1222,12 +1399,17 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
 //        re-scoring modes are instantiations of their own -- their LDS lists and registers stay out of the fp16 kernel
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
 // T = threads: 256, or 512 for the largest CAP (one workgroup per CU there: the second wave per SIMD hides the latencies)
-constexpr int kMergeF16 = 0, kMergeExactF32 = 1, kMergeNominatedI8 = 2;
+// kMergeNominatedI8Lean: the same merge within the fp16 merge's budget (64 VGPRs, < 20 KiB of LDS: eight workgroups per CU, so
+//        that the 2032 merges of a round are resident at once): the nominee list and the work queue live inside keys[] (upper
+//        half / lower quarter -- the passing keys of a round are limited to CAP / 2), the query fragments come from LDS, the rows
+//        are gathered in two halves of four k-steps
+constexpr int kMergeF16 = 0, kMergeExactF32 = 1, kMergeNominatedI8 = 2, kMergeNominatedI8Lean = 3;
 template <int MODE, int CAP, int T = kMergeThreads>
-__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE ? 4 : 8)))
+__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE == 1 || MODE == 2 ? 4 : 8)))
 void topk_merge(MergeArgs a) {
   constexpr bool EXACT = MODE == kMergeExactF32;   // nominated rows are re-scored from the float32 rows in double
-  constexpr bool NOM = MODE == kMergeNominatedI8;  // ... from the fp16 rows on the fp16 filter's MFMA sequence
+  constexpr bool NOM = MODE == kMergeNominatedI8 || MODE == kMergeNominatedI8Lean;  // ... from the fp16 rows on the fp16 filter's MFMA sequence
+  constexpr bool LEAN = MODE == kMergeNominatedI8Lean;
   constexpr bool RESCORE = EXACT || NOM;
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
@@ -1237,8 +1419,10 @@ void topk_merge(MergeArgs a) {
   // the one-pass search's sample round put ~2 k records of a query into one pass: 4096 -- with 1024, half of them took the
   // one-at-a-time path and the sample merge of 6980 queries 1.4-1.5 ms instead of 1.1)
   // (int8 nomination rounds log ~3 x the records of an fp16 round: 2048)
-  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 12288 : (CAP > kMidSortKeys ? 4096 : (CAP > kMaxSortKeys ? 3072 : (MODE == 2 ? 2048 : 1024)));
-  __shared__ unsigned short s_work[kWorkCap];
+  constexpr unsigned kWorkCap = CAP > kBigSortKeys ? 12288 : (CAP > kMidSortKeys ? 4096 : (CAP > kMaxSortKeys ? 3072 : (NOM ? 2048 : 1024)));
+  __shared__ unsigned short s_work_own[LEAN ? 2 : kWorkCap];
+  static_assert(!LEAN || kWorkCap * sizeof(unsigned short) <= CAP * sizeof(unsigned long long) / 2, "the lean work queue sits below the nominee list");
+  unsigned short* const s_work = LEAN ? (unsigned short*)keys : s_work_own;
   __shared__ unsigned s_n_keys, s_n_work;
   __shared__ unsigned long long s_dummy;   // target of the stores of lanes that have nothing to append
   // work item = (list within the pass << kSlotBits) | slot in 16 bits: 1024 lists x 64 slots, or (T = 1024) 2048 x 32
@@ -1264,10 +1448,10 @@ void topk_merge(MergeArgs a) {
     xq32_lds = s_xq32;
   }
   if constexpr (NOM) {
-    __shared__ unsigned s_nom[CAP];
+    __shared__ unsigned s_nom_own[LEAN ? 1 : CAP];
     __shared__ unsigned s_n_nom;
     if (tid == 0) s_n_nom = 0;   // visible after the first barrier below
-    ex.nom = s_nom;
+    ex.nom = LEAN ? (unsigned*)(keys + CAP / 2) : s_nom_own;   // lean: CAP row ids in the upper half of keys[]
     ex.n_nom = &s_n_nom;
   }
   const unsigned n_lists = 2 * a.n_chunks;
@@ -1573,6 +1757,45 @@ void topk_merge(MergeArgs a) {
     if (tid == 0) a.stat_nominated[q] += n_nom;
     const float tau_exact = a.tau[q];
     const int lane = tid & 63, w = tid >> 6, li = lane & 31, half = lane >> 5;
+    if constexpr (LEAN) {
+      // the query's fp16 row in LDS (its fragments are re-read per k-step: 32 VGPRs less), the rows gathered in two halves of
+      // four k-steps (16 VGPRs in flight instead of 32); passing keys go to the LOWER half of keys[] only -- the nominee list
+      // occupies the upper half -- and a round with more of them than that is re-scanned (overflow)
+      __shared__ __attribute__((aligned(16))) char s_q16[kRowBytes];
+      if (tid < kRowBytes / 16) ((uint4*)s_q16)[tid] = ((const uint4*)((const char*)a.xq16 + (size_t)q * kRowBytes))[tid];
+      __syncthreads();
+      for (unsigned c0 = (unsigned)w * 32; c0 < n_nom; c0 += (T / 64) * 32) {   // wave-uniform trip count
+        const unsigned mine = c0 + (unsigned)li < n_nom ? c0 + (unsigned)li : c0;
+        const unsigned row = ex.nom[mine];
+        const char* ap = a.xb16 + (size_t)row * kRowBytes;
+        f32x16 acc = {0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f16x8 af[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[j] = *(const f16x8*)(ap + (2 * (4 * h + j) + half) * 16);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f16x8 qv = *(const f16x8*)(s_q16 + (2 * (4 * h + j) + half) * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qv, acc, 0, 0, 0);
+          }
+        }
+        if (li == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s_sc[w][(r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
+        }
+        const float score = s_sc[w][li];
+        const bool keep = half == 0 && c0 + (unsigned)li < n_nom && score > tau_exact;
+        wave_append(keep, pack_key(score, row), keys, &s_n_keys, (unsigned)CAP / 2);
+      }
+      __syncthreads();
+      if (s_n_keys > (unsigned)CAP / 2) {   // workgroup-uniform
+        if (tid == 0) {
+          *a.overflow = 1u;
+          s_n_keys = CAP / 2;
+        }
+      }
+    } else
     if (n_nom) {   // workgroup-uniform
       f16x8 qf[8];
       const char* qrow = (const char*)a.xq16 + (size_t)q * kRowBytes;
@@ -2331,8 +2554,15 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
 }
 
 hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st) {
-  if (qw == 2)
-    hipLaunchKernelGGL((mips_filter_i8<2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+  if (a.flags & 64u) {   // experiment switch: one barrier per two stages
+    if (qw == 2)
+      hipLaunchKernelGGL((mips_filter_i8_pairs<2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((mips_filter_i8_pairs<1>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+    return hipGetLastError();
+  }
+  if (qw == 2)   // (flag 256, experiment: 24 KiB of unused dynamic LDS leave room for ONE workgroup per CU)
+    hipLaunchKernelGGL((mips_filter_i8<2>), dim3(grid), dim3(kFilterThreads), (a.flags & 256u) ? 24576 : 0, st, a);
   else if (qw == 1)
     hipLaunchKernelGGL((mips_filter_i8<1>), dim3(grid), dim3(kFilterThreads), 0, st, a);
   else
@@ -2446,7 +2676,10 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   const bool big = a.sort_cap > kMaxSortKeys;
   if (a.xb16) {   // records of the int8 nomination scan
     if (big || a.xq32 || a.compact || a.inclusive || a.bound_keys) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    if (a.lean)
+      hipLaunchKernelGGL((topk_merge<kMergeNominatedI8Lean, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   } else if (a.xq32) {
     if (big)
       hipLaunchKernelGGL((topk_merge<kMergeExactF32, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);

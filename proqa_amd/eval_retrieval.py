@@ -26,29 +26,55 @@ from .utils import DocDB, normalize
 
 PROCESS_TOK = None
 PROCESS_DB = None
+PROCESS_TEXTS = None    # TextSidecar of the index (row -> passage text), when one sits next to the id map
 DEFAULT_IDX_ID = "../pretrained_models/idx_id.json"   # hard-coded in the reference (:69)
 FIXED_CUTOFFS = (5, 10, 20, 50)
 
 
-def init(db_path):
-    """Per-worker state: a tokenizer and a sqlite connection."""
-    global PROCESS_TOK, PROCESS_DB
+def init(db_path, text_sidecar=None):
+    """Per-worker state: a tokenizer and a sqlite connection (and, when the index comes with one, its text sidecar)."""
+    global PROCESS_TOK, PROCESS_DB, PROCESS_TEXTS
     PROCESS_TOK = SimpleTokenizer()
     Finalize(PROCESS_TOK, PROCESS_TOK.shutdown, exitpriority=100)
     PROCESS_DB = DocDB(db_path)
     Finalize(PROCESS_DB, PROCESS_DB.close, exitpriority=100)
+    if text_sidecar:
+        from .gen_index_id_map import TextSidecar
+        PROCESS_TEXTS = TextSidecar(text_sidecar)
 
 
 def _words(text):
     return PROCESS_TOK.tokenize(normalize(text)).words(uncased=True)
 
 
-def para_has_answer(answer, para, return_matched=False):
-    """True if any answer alias occurs in the paragraph as a contiguous token sequence."""
-    tokens = PROCESS_TOK.tokenize(normalize(para))
+def _fold(text):
+    """Lower-cased with both lower-case sigmas made one: a token's .lower() and the same characters inside the lower-cased
+    paragraph can differ in nothing but the final-sigma rule (every other lower-case mapping is per character)."""
+    return text.lower().replace("\u03c2", "\u03c3")
+
+
+def _may_match(needles, folded_para):
+    """False only if NO alias can occur in the paragraph: an alias matches as a contiguous run of tokens, every token is a
+    substring of the (normalised) paragraph, so every token of a matching alias occurs in the folded paragraph as a folded
+    substring.  An alias without tokens matches every paragraph (the reference's loop finds the empty run at i = 0)."""
+    for needle in needles:
+        if all(tok in folded_para for tok in needle):
+            return True
+    return False
+
+
+def para_has_answer(answer, para, return_matched=False, needles=None):
+    """True if any answer alias occurs in the paragraph as a contiguous token sequence (eval_retrieval.py:27-45 of the
+    reference).  The paragraph is tokenised only if some alias has all its tokens somewhere in it -- a plain substring test on
+    the folded text that cannot reject a match (`_may_match`); most of a question's top-k paragraphs hold none of them."""
+    norm = normalize(para)
+    if needles is None:
+        needles = [_words(alias) for alias in answer]
+    if not _may_match([[_fold(t) for t in needle] for needle in needles], _fold(norm)):
+        return (False, "") if return_matched else False
+    tokens = PROCESS_TOK.tokenize(norm)
     text = tokens.words(uncased=True)
-    for alias in answer:
-        needle = _words(alias)
+    for needle in needles:
         span = len(needle)
         for i in range(len(text) - span + 1):
             if text[i:i + span] == needle:
@@ -58,15 +84,28 @@ def para_has_answer(answer, para, return_matched=False):
     return (False, "") if return_matched else False
 
 
-def get_score(answer_doc, topk=80):
-    """Hit flags of one question at cut-offs topk, 5, 10, 20, 50 (computed on the top-k list)."""
-    _question, answer, doc_ids = answer_doc
-    paras = [PROCESS_DB.get_doc_text(doc_id) for doc_id in doc_ids][:topk]
-    hits = [int(para_has_answer(answer, p)) for p in paras]
+def _score_paras(answer, paras, topk):
+    needles = [_words(alias) for alias in answer]      # once per question, not once per paragraph
+    hits = [int(para_has_answer(answer, p, needles=needles)) for p in paras]
     scores = {str(topk): int(sum(hits) > 0)}
     for c in FIXED_CUTOFFS:
         scores[str(c)] = int(sum(hits[:c]) > 0)
     return scores
+
+
+def get_score(answer_doc, topk=80):
+    """Hit flags of one question at cut-offs topk, 5, 10, 20, 50 (computed on the top-k list)."""
+    _question, answer, doc_ids = answer_doc
+    paras = [PROCESS_DB.get_doc_text(doc_id) for doc_id in doc_ids][:topk]
+    return _score_paras(answer, paras, topk)
+
+
+def get_score_rows(answer_rows, topk=80):
+    """get_score with the paragraphs taken from the index's text sidecar by ROW (gen_index_id_map.write_text_sidecar) instead
+    of row -> doc id -> one sqlite query per hit."""
+    _question, answer, rows = answer_rows
+    paras = [PROCESS_TEXTS[int(r)] for r in rows][:topk]
+    return _score_paras(answer, paras, topk)
 
 
 def convert_idx2id(idxs, mapping_path=DEFAULT_IDX_ID):
@@ -74,8 +113,7 @@ def convert_idx2id(idxs, mapping_path=DEFAULT_IDX_ID):
     memory-mapped sidecar written by gen_index_id_map (path ending in .ids): same result."""
     if mapping_path.endswith(".ids"):
         from .gen_index_id_map import SidecarMap
-        idx_id = SidecarMap(mapping_path)
-        return [[idx_id[int(i)] for i in row] for row in idxs]
+        return SidecarMap(mapping_path).take(np.asarray(idxs))    # one gather + one parse for all ids
     with open(mapping_path) as f:
         idx_id = json.load(f)
     return [[idx_id[str(int(i))] for i in row] for row in idxs]
@@ -174,6 +212,9 @@ def build_parser():
                         help="idx_id.json (the reference reads ../pretrained_models/idx_id.json)")
     parser.add_argument("--allow-fp16-rounding", action="store_true",
                         help="round float32 embeddings to fp16 instead of searching them in exact-float32 mode")
+    parser.add_argument("--no-text-sidecar", action="store_true",
+                        help="fetch the passage texts from the sqlite DB by document id even if a text sidecar (<stem>.txt, "
+                             "gen_index_id_map --texts) sits next to the id map")
     parser.add_argument("--dump-results", type=str, default=None,
                         help="also write the search result (D float32 [Q,k], I int64 [Q,k]) to this .npz (not in the reference)")
     return parser
@@ -195,8 +236,11 @@ def main(argv=None):
     questions = [item["question"] for item in qas]
     answers = [item["answer"] for item in qas]
 
+    # the passage texts by row, when the index was built with them (gen_index_id_map --texts): no id mapping, no sqlite
+    from .gen_index_id_map import text_sidecar_of
+    text_sidecar = None if args.no_text_sidecar else text_sidecar_of(args.idx_id_map)
     # fork the scorer pool before any HIP call (and before the process group's threads exist)
-    processes = ProcessPool(processes=args.num_workers, initializer=init, initargs=[args.db])
+    processes = ProcessPool(processes=args.num_workers, initializer=init, initargs=[args.db, text_sidecar])
     try:
         t0 = time.perf_counter()
         D, I = search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding)
@@ -204,16 +248,21 @@ def main(argv=None):
         if args.dump_results:
             np.savez(args.dump_results, D=D, I=I)
         t1 = time.perf_counter()
-        retrieval_results = convert_idx2id(I, args.idx_id_map)
-        t2 = time.perf_counter()
-        assert len(retrieval_results) == len(questions) == len(answers)
-        results = processes.map(partial(get_score, topk=args.topk), zip(questions, answers, retrieval_results))
+        if text_sidecar:
+            t2 = t1
+            assert len(I) == len(questions) == len(answers)
+            results = processes.map(partial(get_score_rows, topk=args.topk), zip(questions, answers, I.tolist()))
+        else:
+            retrieval_results = convert_idx2id(I, args.idx_id_map)
+            t2 = time.perf_counter()
+            assert len(retrieval_results) == len(questions) == len(answers)
+            results = processes.map(partial(get_score, topk=args.topk), zip(questions, answers, retrieval_results))
         t3 = time.perf_counter()
     finally:
         processes.close()
         processes.join()
     LAST_RUN_STATS.update(startup_seconds=t0 - t_start, search_total_seconds=t1 - t0, idx2id_seconds=t2 - t1,
-                          scoring_seconds=t3 - t2, scorer_processes=args.num_workers)
+                          scoring_seconds=t3 - t2, scorer_processes=args.num_workers, text_sidecar=bool(text_sidecar))
 
     aggregate = defaultdict(list)
     for r in results:

@@ -91,6 +91,70 @@ def test_sidecar_map_equals_json_route(gold, tmp_path):
         ev.convert_idx2id(np.array([[n]]), str(out))
 
 
+def _reference_para_has_answer(answer, para):
+    """the reference's loop, verbatim in behaviour (eval_retrieval.py:27-45): tokenise everything, compare runs of words"""
+    text = ev.PROCESS_TOK.tokenize(normalize(para)).words(uncased=True)
+    for alias in answer:
+        needle = ev.PROCESS_TOK.tokenize(normalize(alias)).words(uncased=True)
+        for i in range(len(text) - len(needle) + 1):
+            if text[i:i + len(needle)] == needle:
+                return True
+    return False
+
+
+def test_the_substring_prefilter_never_changes_a_verdict(gold):
+    """para_has_answer tokenises a paragraph only if some alias has all its tokens in it as substrings of the folded text.
+    10 000 random (answer, paragraph) pairs over an alphabet built to hurt: Greek capitals with both lower-case sigmas (the
+    one context-sensitive lower-case rule), the dotted capital I (lower-cases to two characters), combining marks (NFD),
+    apostrophes inside words, empty and punctuation-only aliases."""
+    rng = np.random.default_rng(5)
+    alphabet = list("abAB \u03a3\u03c3\u03c2\u039f\u0394\u0130\u00e9e\u0301'.-\u4e2d") + ["  "]
+    def rand_text(n):
+        return "".join(rng.choice(alphabet, size=n))
+    same = 0
+    for _ in range(10000):
+        para = rand_text(int(rng.integers(0, 40)))
+        answer = [rand_text(int(rng.integers(0, 5))) for _ in range(int(rng.integers(1, 4)))]
+        if rng.random() < 0.3 and len(para) > 4:        # plant an alias cut out of the paragraph (often a real match)
+            a = int(rng.integers(0, len(para) - 2))
+            answer.append(para[a:a + int(rng.integers(1, 6))].swapcase())
+        want = _reference_para_has_answer(answer, para)
+        assert ev.para_has_answer(answer, para) == want, (answer, para)
+        assert ev.para_has_answer(answer, para, True)[0] == want
+        same += want
+    assert 500 < same < 9500     # both verdicts are exercised
+
+
+def test_text_sidecar_scores_like_the_sqlite_route(gold, tmp_path):
+    """SURVEY section 8f row 3, second half: the passage texts by ROW from the memory-mapped sidecar give the score dicts the
+    reference's route (row -> doc id -> sqlite) gives, and SidecarMap.take is the per-id lookup, vectorised."""
+    from proqa_amd import gen_index_id_map as gm
+    corpus = tmp_path / "paras.txt"
+    corpus.write_text("".join(json.dumps({"id": d[0], "text": d[1]}) + "\n" for d in gold["docs"]))
+    out = tmp_path / "idx_id.json"
+    gm.build(str(corpus), str(out), texts=True)
+    txt = gm.text_sidecar_of(str(out))
+    assert txt == str(tmp_path / "idx_id.txt") and gm.text_sidecar_of(str(tmp_path / "idx_id.ids")) == txt
+    texts = gm.TextSidecar(txt)
+    assert [texts[i] for i in range(len(texts))] == [d[1] for d in gold["docs"]]
+    with pytest.raises(KeyError):
+        texts[len(texts)]
+    # rows of the golden I matrix index gold["idx_id"]; map them to rows of THIS corpus (= position of the doc in gold["docs"])
+    pos = {normalize(d[0]): i for i, d in enumerate(gold["docs"])}
+    ev.init(os.path.join(GOLDEN, "recall_docs.db"), txt)
+    try:
+        for topk, want in gold["scores"].items():
+            for qa, ids, w in zip(gold["qas"], gold["doc_ids"], want):
+                rows = [pos[normalize(i)] for i in ids]
+                assert ev.get_score_rows((qa["question"], qa["answer"], rows), topk=int(topk)) == w
+    finally:
+        ev.init(os.path.join(GOLDEN, "recall_docs.db"))
+    m = gm.SidecarMap(str(tmp_path / "idx_id.ids"))
+    rows = np.random.default_rng(1).integers(0, len(m), (7, 5))
+    assert m.take(rows) == [[m[int(i)] for i in r] for r in rows]
+    assert m.take(np.zeros((0, 3), np.int64)) == []
+
+
 def test_eval_retrieval_command_line_does_not_import_pytorch():
     """The single-process eval_retrieval.py path needs numpy, sqlite and the C library only: importing PyTorch costs a second
     or two of a ~2 s command and makes the scorer pool's fork heavier.  (The row-sharded path under torchrun imports it.)"""
