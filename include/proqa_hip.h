@@ -153,7 +153,7 @@ int proqa_index_configure(proqa_index* idx, int first_slab_rows, int growth);
  * a multiple of 32 up to 8192, 0 disables it.  Used for k <= rows/4 (at most 256) on indexes of >= 4*rows rows;
  * the result never depends on it.  Default 4096. */
 int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
-/* The int8 nomination scan of the k <= 128 rounds (batches of more than 256 queries, fp16 indexes of >= 65536 rows): the
+/* The int8 nomination scan of the k <= 128 rounds (fp16 indexes of >= 65536 rows): the
  * rounds scan an int8 copy of the centred, per-dimension-scaled rows at twice the fp16 MFMA rate, nominate every row whose
  * integer score exceeds the running threshold lowered by a rigorous bound on the quantisation error, and re-score the
  * nominated rows from the fp16 rows -- the result is the fp16 scan's, bit for bit.  mode 0: never (fp16 scan);

@@ -2554,7 +2554,7 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
 }
 
 hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st) {
-  if (a.flags & 64u) {   // experiment switch: one barrier per two stages
+  if (!(a.flags & 64u)) {   // the shipped form: one barrier per two stages (flag 64: the stage-wise kernel, for A/B runs and cut experiments)
     if (qw == 2)
       hipLaunchKernelGGL((mips_filter_i8_pairs<2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
     else

@@ -249,15 +249,15 @@ def test_rows_added_after_a_search_rebuild_the_copy(gpu_device):
 
 
 def test_automatic_mode_picks_the_scan_by_shape(gpu_device):
-    """default mode: the int8 rounds for batches of more than 256 queries with k <= 128 on shards of >= 65536 rows; the fp16
-    scan for everything else (small batches, large k, small shards, exact-float32 indexes)."""
+    """default mode: the int8 rounds for k <= 128 on shards of >= 65536 rows (any batch size); the fp16 scan for everything
+    else (large k, small shards, exact-float32 indexes)."""
     import torch
     from proqa_amd.index import IndexFlatIP
     rng = np.random.default_rng(47)
     xb = _int_corpus(rng, 70000)
     ix = IndexFlatIP(128)
     ix.add(xb)
-    for nq, k, want in ((300, 80, True), (256, 80, False), (300, 129, False), (300, 2000, False)):
+    for nq, k, want in ((300, 80, True), (256, 80, True), (1, 5, True), (300, 129, False), (300, 2000, False)):
         xq = _int_corpus(rng, nq)
         D, I = ix.search_device(torch.from_numpy(xq).cuda(), k)
         assert ix.last_stats()["nomination"] == want, (nq, k)
