@@ -972,21 +972,34 @@ def main():
     # the HBM-bound regime of the same kernel (north_star: "achieved HBM GB/s for the MIPS scan"):
     # 32 queries over the same shard -- intensity 32 flop/B, the corpus stream is the bound
     nq_small = 32
-    for profiled in (False, True):
-        sharded.local_index.set_profiling(profiled)
-        small = [None] * 3
-        for i in range(3):
-            sharded.local_index.search_device(xq[:nq_small], k)
-            small[i] = sharded.local_index.last_stats()["filter_ms"]
-    sharded.local_index.set_profiling(False)
-    small_s = float(np.mean(small)) / 1e3
-    small_gbs = (hi - lo) * D * 2 / small_s / 1e9
+
+    def small_filter_ms():
+        for profiled in (False, True):
+            local.set_profiling(profiled)
+            small = [None] * 3
+            for i in range(3):
+                local.search_device(xq[:nq_small], k)
+                small[i] = local.last_stats()["filter_ms"]
+        local.set_profiling(False)
+        return float(np.mean(small)) / 1e3, bool(local.last_stats().get("nomination"))
+
+    small_s, small_nom = small_filter_ms()
+    row_bytes = D * (1 if small_nom else 2)          # what the scan streams per row: the int8 copy, or the fp16 rows
+    small_gbs = (hi - lo) * row_bytes / small_s / 1e9
+    # achieved = bytes the scan STREAMS per search (rows x 128 B of the int8 copy under the nomination scan, rows x 256 B
+    # of fp16 otherwise) over the HIP-event time of all filter launches of the search; fp16_rows_GBs prices the same time
+    # against the algorithmic bytes of SURVEY 8(d) (rows x 256 B): it may exceed the HBM peak, the bytes are not read
     line["scan_small_batch"] = {
         "queries": nq_small, "filter_ms_per_search": small_s * 1e3,
         "roofline": {"bound": "hbm", "achieved": small_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": small_gbs / PEAK_HBM_GBS, "kernel": "mips_filter_f16<QW=1>",
-                     "note": "algorithmic bytes = rows x 256 B per search over the HIP-event time of all filter launches of the search; "
-                             "peak_measured.hbm_read_GBs is what a read-only stream reaches on this box"}}
+                     "frac": small_gbs / PEAK_HBM_GBS, "kernel": "mips_filter_i8<QW=1>" if small_nom else "mips_filter_f16<QW=1>",
+                     "bytes_per_row": row_bytes, "fp16_rows_GBs": (hi - lo) * D * 2 / small_s / 1e9}}
+    if small_nom:
+        local.configure_nomination("off")
+        s16, _ = small_filter_ms()
+        local.configure_nomination("auto")
+        g16 = (hi - lo) * D * 2 / s16 / 1e9
+        line["scan_small_batch"]["fp16_scan"] = {"filter_ms_per_search": s16 * 1e3, "achieved": g16, "frac": g16 / PEAK_HBM_GBS}
 
     if world == 1 and not args.skip_extras:
         # per-rank work of the strong-scaling runs, timed on this one GPU: the same queries over the first

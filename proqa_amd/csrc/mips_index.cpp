@@ -93,6 +93,7 @@ struct proqa_index {
   // int8 nomination scan (mips_kernels.hip): an int8 copy of the centred, per-dimension-scaled rows, built lazily by the first
   // search that can use it and rebuilt when the rows changed (rows_epoch); the fp16 rows stay the data every score comes from
   signed char* xb8 = nullptr;
+  float2* blk8 = nullptr;                  // per 32-row block: scale and largest integer row norm (FilterArgsI8::blk)
   int64_t capacity8 = 0;
   float* col = nullptr;                    // device [3][128]: mean, 127 / c, c / 127
   float* col_partial = nullptr;            // device [kColStatGroups][3][128]
@@ -252,10 +253,15 @@ int ensure_q8(proqa_index* idx, hipStream_t st) {
   if (idx->n > idx->capacity8) {
     PROQA_HIP(hipStreamSynchronize(st));
     if (idx->xb8) PROQA_HIP(hipFree(idx->xb8));
+    if (idx->blk8) PROQA_HIP(hipFree(idx->blk8));
     idx->xb8 = nullptr;
+    idx->blk8 = nullptr;
     idx->capacity8 = 0;
     const int64_t cap = round_up<int64_t>(std::max(idx->n, idx->capacity), kStageRows);
-    if (try_malloc((void**)&idx->xb8, (size_t)cap * kDim) != hipSuccess) {
+    if (try_malloc((void**)&idx->xb8, (size_t)cap * kDim) != hipSuccess ||
+        try_malloc((void**)&idx->blk8, (size_t)(cap / 32 + 16) * sizeof(float2)) != hipSuccess) {
+      if (idx->xb8) (void)hipFree(idx->xb8);
+      idx->xb8 = nullptr;
       idx->q8_epoch = idx->rows_epoch;   // no room for the copy: this index is searched on its fp16 rows
       return PROQA_OK;
     }
@@ -263,7 +269,7 @@ int ensure_q8(proqa_index* idx, hipStream_t st) {
   }
   PROQA_HIP(hipMemsetAsync(idx->qstats, 0, sizeof(QuantStats), st));
   PROQA_HIP(launch_column_stats(idx->xb, idx->n, idx->col_partial, idx->col, idx->qstats, st));
-  PROQA_HIP(launch_quantise_rows_i8(idx->xb, idx->n, idx->col, idx->xb8, idx->qstats, st));
+  PROQA_HIP(launch_quantise_rows_i8(idx->xb, idx->n, idx->col, idx->xb8, idx->blk8, idx->qstats, st));
   QuantStats h;
   PROQA_HIP(hipMemcpyAsync(&h, idx->qstats, sizeof h, hipMemcpyDeviceToHost, st));
   PROQA_HIP(hipStreamSynchronize(st));
@@ -566,6 +572,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     fa.rows_per_chunk = g.rows_per_chunk;
     fa.tau = idx->tau;
     fa.qp = idx->qparams;
+    fa.blk = idx->blk8;
     fa.store = store_of(idx, nq_pad, n_qtiles, kNominateLaneCap, round_up<unsigned>(g.chunks, 8));
     fa.overflow = overflow_word;
     fa.flags = kFilterFlags;
@@ -586,7 +593,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     ma.xq16 = idx->xq_pad;
     ma.xb16 = idx->xb;
     ma.stat_nominated = idx->stat_nom;
-    ma.lean = (kFilterFlags & 128u) ? 1 : 0;   // experiment switch
+    ma.lean = 0;
     PROQA_HIP(launch_merge(ma, nq_pad, st));
     if (kDebugCand) {   // developer: records the scan logged / rows the merges re-scored so far / candidates so far
       (void)hipStreamSynchronize(st);
@@ -1368,6 +1375,7 @@ int proqa_index_free(proqa_index* idx) {
   if (idx->stage_dev) (void)hipFree(idx->stage_dev);
   if (idx->boot_scores) (void)hipFree(idx->boot_scores);
   if (idx->xb8) (void)hipFree(idx->xb8);
+  if (idx->blk8) (void)hipFree(idx->blk8);
   if (idx->col) (void)hipFree(idx->col);
   if (idx->col_partial) (void)hipFree(idx->col_partial);
   if (idx->qstats) (void)hipFree(idx->qstats);

@@ -118,21 +118,21 @@ struct MergeArgs {
 };
 
 // ---- int8 nomination scan (the k <= kPageK rounds of an fp16 index; see "int8 nomination" in mips_kernels.hip) ----------
-// An int8 copy of the centred, per-dimension-scaled rows is scanned on v_mfma_i32_32x32x32_i8 (twice the fp16 rate, exact
-// i32 sums); a row is NOMINATED when its integer score exceeds the query's running threshold lowered by a rigorous bound on
-// the quantisation error; the merge re-scores the nominated rows from the fp16 rows with the filter's own MFMA sequence
-// (bit-identical scores) and keeps those that beat the exact threshold.
+// An int8 copy of the centred, per-dimension- and per-32-row-block-scaled rows is scanned on v_mfma_i32_32x32x32_i8 (twice the
+// fp16 rate, exact i32 sums); a row is NOMINATED when its integer score exceeds the query's running threshold lowered by a
+// rigorous bound on the quantisation error; the merge re-scores the nominated rows from the fp16 rows with the filter's own
+// MFMA sequence (bit-identical scores) and keeps those that beat the exact threshold.
 constexpr int kStageBytesI8 = kStageRows * kDim;   // 16 KiB: a 128-row stage of int8 rows
-struct NominateParams {     // per query, written by prep_queries_i8
-  float off;                // q . mean (the centring constant of this query's scores)
-  float inv_unit;           // 1 / s_q: integer score units per score unit
-  float margin;             // bound on |exact score - off - s_q * integer score| in integer units, all slack included
-  float pad;
+struct NominateParams {     // per query, written by prep_queries_i8 (threshold of block b: A G_b - B - E X_b, A = (tau - off) / s_q)
+  float off;                // q . mean (the centring constant of this query's scores) + the slack in score units
+  float inv_unit;           // 1 / s_q
+  float margin_r;           // B = ||w / s_q|| R: the rows' rounding residuals, in integer units
+  float err_norm;           // E = ||e||: the query's own rounding residual (times the block's max ||xi||)
 };
 static_assert(sizeof(NominateParams) == 16, "one 16-byte load per lane");
 struct QuantStats {         // device words maintained by the quantisation passes (floats as bits: atomicMax on non-negatives)
   unsigned max_resid;       // R  = max over rows of ||127 (x - mean) / c - xi||
-  unsigned max_inorm;       // Xn = max over rows of ||xi||
+  unsigned max_inorm;       // max over rows of ||xi|| (per block: blk[b].y)
   unsigned max_xnorm;       // Xf = max over rows of ||x|| (fp16 rows)
   unsigned nonfinite;       // rows or statistics that are not finite: the scan is not used
 };
@@ -144,17 +144,20 @@ struct FilterArgsI8 {
   int rows_per_chunk;       // multiple of kStageRows
   const float* tau;         // exact running k-th best score per query (+inf: padding / exhausted, -inf: fewer than k rows yet)
   const NominateParams* qp; // [nq_pad]
+  const float2* blk;        // per 32-row block of the shard: {G_b = 127 / f_b, X_b = max ||xi|| of its rows}; readable for 8
+                            // blocks past the shard's last one (the scan fetches whole pairs of stages)
   CandidateStore store;     // column records whose scores / threshold words are int32
   unsigned* overflow;
   unsigned flags;           // developer cut experiments (PROQA_FILTER_FLAGS; wrong results), 0 in production
 };
 hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st);
 // column statistics of fp16 rows [0, n): partial[g][0..127] sums, [g][128..255] minima, [g][256..383] maxima per workgroup g
-// (deterministic two-level reduction), then mean / scale per dimension: col[0..127] mean, col[128..255] 127 / c, col[256..383] c / 127
+// (deterministic two-level reduction), then mean / scale per dimension: col[0..127] mean, col[128..255] 1 / c, col[256..383] c
 constexpr int kColStatGroups = 1024;
 hipError_t launch_column_stats(const void* xb16, long long n, float* partial, float* col, QuantStats* stats, hipStream_t st);
-// xi = clamp(rint((x - mean) * 127 / c)), and the three maxima of QuantStats
-hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, QuantStats* stats, hipStream_t st);
+// xi = clamp(rint(127 (x - mean) / (c f_b))) with the block scales f_b, blk[(n + 31) / 32], and the maxima of QuantStats
+hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, float2* blk, QuantStats* stats,
+                                   hipStream_t st);
 // int8 queries + NominateParams of every padded query (fp16 padded queries in, as the filter reads them)
 // (also zeroes stat_nom[0, nq_pad))
 hipError_t launch_prep_queries_i8(const void* xq_pad16, long long nq_pad, const float* col, const QuantStats* stats,

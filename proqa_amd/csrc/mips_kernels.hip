@@ -481,20 +481,26 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 // int8 nomination scan
 // ---------------------------------------------------------------------------------------
 // The fp16 scan above is bound by the matrix pipe (MFMA-bound from ~300 queries per corpus pass on); v_mfma_i32_32x32x32_i8
-// does the same 128-long dot products at twice the rate, exactly (i32 sums).  The rounds of a k <= kPageK search on an fp16
-// index therefore scan an int8 copy of the rows:
-//     x_d  ~ mean_d + (c_d / 127) xi_d        xi = clamp(rint(127 (x - mean) / c)),  c_d = max |x_d - mean_d| over the shard
-//     q.x  = q.mean + sum_d w_d (xi_d + r_d)  w_d = q_d c_d / 127,   r = 127 (x - mean) / c - xi        (|r_d| <= 1/2)
-//          = q.mean + s_q sum_d (qi_d + e_d) xi_d + sum_d w_d r_d     qi = rint(w / s_q), s_q = max |w| / 127, e = w / s_q - qi
-//     |q.x - q.mean - s_q acc| <= s_q (||w / s_q|| R + ||e|| Xn)       acc = sum_d qi_d xi_d (the MFMA result),
-//                                                                      R = max ||r||, Xn = max ||xi|| over the rows (Cauchy-Schwarz)
+// does the same 128-long dot products at twice the rate, exactly (i32 sums), and small batches stream half the bytes.  The
+// rounds of a k <= 128 search on an fp16 index therefore scan an int8 copy of the rows:
+//     u_d  = (x_d - mean_d) / c_d             c_d = max |x_d - mean_d| over the shard (per-dimension equalisation), |u_d| <= 1
+//     xi_d = rint(127 u_d / f_b)              f_b = max |u| over the row's 32-ROW BLOCK (one MFMA M-tile): a block scale
+//     q.x  = q.mean + (f_b / 127) sum_d w_d (xi_d + r_d)          w_d = q_d c_d,  r = 127 u / f_b - xi   (|r_d| <= 1/2)
+//          = q.mean + (f_b / 127) s_q [acc + sum_d e_d xi_d + sum_d (w_d / s_q) r_d]
+//                                              qi = rint(w / s_q), s_q = max |w| / 127, e = w / s_q - qi, acc = sum_d qi_d xi_d
+//     |q.x - q.mean - (f_b / 127) s_q acc| <= (f_b / 127) s_q (||e|| X_b + ||w / s_q|| R)        (Cauchy-Schwarz)
+//                                              X_b = max ||xi|| over the block's rows, R = max ||r|| over the shard's rows
 // Centring matters: q.mean is a per-query constant that does not change the ranking, and embeddings with a large common
-// component would otherwise spend the eight bits on it (scripts/dev_int8_margin.py: 256 x k nominations uncentred, 2 x k centred
-// on the end-to-end test's corpus).  A row whose exact score (the fp16 filter's MFMA sum) beats the running threshold tau has
-// acc > (tau - q.mean) / s_q - margin, so the scan NOMINATES every row above the integer threshold T = floor(that) - 1 and
-// can miss none; the merge re-scores the nominated rows from the fp16 rows with the fp16 filter's own MFMA sequence -- the
-// same bits as the fp16 scan produces -- and everything downstream (running lists, thresholds, ties, overflow-safe path,
-// shards) works on exact scores.  Nothing here depends on the accuracy of mean / c: the residual norms are measured.
+// component would otherwise spend the eight bits on it (scripts/dev_int8_margin.py: 256 x k nominations uncentred, 2 x k
+// centred on the end-to-end test's corpus).  Block scales matter: a handful of rows of large norm (tests plant 2032 rows of
+// 8 x the typical norm among 18M) stretch c_d for everyone, but only their own blocks' f_b and X_b -- with one scale for the
+// shard those rows quintupled every query's margin and the lists overflowed.  A row whose exact score (the fp16 filter's
+// MFMA sum) beats the running threshold tau has
+//     acc > A_q G_b - B_q - E_q X_b,     A_q = (tau - q.mean - slack) / s_q,  G_b = 127 / f_b,  B_q = ||w / s_q|| R,  E_q = ||e||
+// so the scan NOMINATES every row above that per-block threshold (two fused multiply-adds per 32-row unit and query block)
+// and can miss none; the merge re-scores the nominated rows from the fp16 rows with the fp16 filter's own MFMA sequence --
+// the same bits as the fp16 scan produces -- and everything downstream (running lists, thresholds, ties, overflow-safe path,
+// shards) works on exact scores.  Nothing here depends on the accuracy of mean / c / f: the residual norms are measured.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 constexpr int kRowBytesI8 = kDim;                        // 128 B per int8 corpus row
@@ -513,302 +519,60 @@ __device__ __forceinline__ int max16_i32(const i32x16& v) {
   return imax(imax(imax(m0, m1), m2), imax(imax(m3, m4), v[15]));
 }
 
-// the integer threshold of a query whose exact threshold is tau: every row with exact score > tau has acc > T
-__device__ __forceinline__ int nominate_threshold(float tau, const NominateParams& p) {
-  if (!(tau > -__builtin_inff())) return (int)0x80000000;                 // fewer than k rows yet: every row is a candidate
-  if (tau == __builtin_inff()) return 0x7fffffff;                         // padding / exhausted query: never
-  float t = (tau - p.off) * p.inv_unit - p.margin;
-  t = __builtin_floorf(t - __builtin_fabsf(t) * 0x1p-20f - 1.0f);         // the roundings of this line itself
-  if (!(t > -2147483000.f)) return (int)0x80000000;                       // (also a NaN from non-finite parameters: nominate everything)
-  if (t > 2147483000.f) return 0x7ffffffe;
-  return (int)t;
+// What a lane keeps of its query for the per-block threshold T_b = A G_b - B - E X_b (see above).  A is lowered by 2^-20 of
+// itself -- the roundings of the two fused multiply-adds and of G_b -- so that T_b never exceeds the exact bound.
+struct LaneThreshold {
+  float A, B, E;
+};
+__device__ __forceinline__ LaneThreshold lane_threshold(float tau, const NominateParams& p) {
+  LaneThreshold t;
+  t.B = p.margin_r;
+  t.E = p.err_norm;
+  if (!(tau > -__builtin_inff())) {
+    t.A = -__builtin_inff();                      // fewer than k rows yet: every row is a candidate
+  } else if (tau == __builtin_inff()) {
+    t.A = __builtin_inff();                       // padding / exhausted query: never
+  } else {
+    const float a = (tau - p.off) * p.inv_unit;   // (a NaN from non-finite parameters compares false below: nominates nothing --
+    t.A = a - __builtin_fabsf(a) * 0x1p-20f;      //  such an index is never scanned: QuantStats::nonfinite)
+  }
+  return t;
+}
+__device__ __forceinline__ float block_threshold(const LaneThreshold& t, float G, float X) {
+  return __builtin_fmaf(-t.E, X, __builtin_fmaf(t.A, G, -t.B));
 }
 
-__device__ __forceinline__ void write_record_i32(WaveRecord* dst, const i32x16& acc, unsigned q, unsigned row0, int rows_left, int thr) {
+// (the threshold word of such a record is the FLOAT per-block threshold the int32 scores were tested against)
+__device__ __forceinline__ void write_record_i32(WaveRecord* dst, const i32x16& acc, unsigned q, unsigned row0, int rows_left, float thr) {
   uint4* d = (uint4*)dst;
-  d[0] = make_uint4(q, row0, (unsigned)rows_left, (unsigned)thr);
+  d[0] = make_uint4(q, row0, (unsigned)rows_left, __float_as_uint(thr));
 #pragma unroll
   for (int g = 0; g < 4; ++g)
     d[1 + g] = make_uint4((unsigned)acc[4 * g], (unsigned)acc[4 * g + 1], (unsigned)acc[4 * g + 2], (unsigned)acc[4 * g + 3]);
 }
 
 // Same tiling as mips_filter_f16 -- 8 waves, wave w keeps its QW x 32 queries as MFMA B fragments for its lifetime, the
-// workgroup streams a contiguous chunk of rows through a four-stage LDS ring filled by LDS-DMA, each lane owns one query
-// column of the 32x32 accumulator so the test is lane-local -- with what the half-size operands change:
-//   * a stage of 128 rows is 16 KiB, the ring 64 KiB: TWO workgroups per CU, i.e. four waves per SIMD.  The matrix pipe is
-//     kept busy by the other waves of the SIMD while one wave examines its accumulators or logs a column, so the loop needs no
-//     software pipeline across units (no second accumulator set: <= 128 VGPRs);
+// workgroup streams a contiguous chunk of rows through LDS filled by LDS-DMA, each lane owns one query column of the 32x32
+// accumulator so the test is lane-local -- with what the half-size operands change:
+//   * 128 rows are 16 KiB and the LDS image of a workgroup 64 KiB: TWO workgroups per CU, i.e. four waves per SIMD; no second
+//     accumulator set for a software pipeline across units (<= 128 VGPRs), the other waves of the SIMD fill the matrix pipe
+//     while one examines its accumulators or logs a column;
+//   * the image is two PAIRS of 128-row stages (2 x 32 KiB): the barrier at the top of pair p publishes it (every wave's DMA
+//     pieces of the pair have landed: issued one pair -- eight units -- earlier; the only younger vector-memory operations of
+//     the wave are its record stores, COUNTED: memory operations of a wave retire in issue order, so `vmcnt(stores since)`
+//     is exact and no barrier waits for a write acknowledgement) and frees the buffers of pair p-1, which receive pair p+1
+//     right behind it.  One barrier per 256 rows: a stage-wise ring with one per 128 measured 3.5 % slower (ABLATIONS R5.3);
 //   * a unit (32 rows x QW x 32 queries) is 4 QW MFMAs of 32 cycles instead of 8 QW;
 //   * rows are 128 B = 8 pieces of 16 B; piece p of row r sits at slot p ^ ((r >> 1) & 7) of its LDS row (XOR on the DMA
 //     SOURCE address, the LDS image stays lane-linear), which keeps the four lane groups of ds_read_b128 on 16 distinct
 //     16-byte bank slots each (MI355X_MICROARCH.md, LDS table);
-//   * the MFMA k-order is permuted identically on both operands (piece 2j + half at k-step j); integer sums do not depend on it.
-// A lane whose column maximum exceeds its integer threshold logs the 16 int32 scores as one 80-byte record (the format of
-// the fp16 scan, threshold word = T); a full list is reported through `overflow` (the round is then re-scanned by the fp16
-// overflow-safe path): no spill log, no capacity branch in the hit path.
+//   * the MFMA k-order is permuted identically on both operands (piece 2j + half at k-step j); integer sums do not depend on it;
+//   * the block constants (G_b, X_b) of a unit are wave-uniform: scalar loads, two fused multiply-adds per unit and query block.
+// A lane whose column maximum exceeds its threshold logs the 16 int32 scores as one 80-byte record (the format of the fp16
+// scan; threshold word = the float threshold of the block); a full list is reported through `overflow` (the round is then
+// re-scanned by the fp16 overflow-safe path): no spill log, no capacity branch in the hit path.
 template <int QW>
 __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8 a) {
-  static_assert(QW == 1 || QW == 2, "8 waves x 32 / 64 queries");
-  __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytesI8];
-  constexpr int NW = kFilterWaves;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 31;
-  const int half = lane >> 5;
-
-  const unsigned b = blockIdx.x;
-  const unsigned xcd = b & 7u;
-  const unsigned rest = b >> 3;
-  const unsigned qt = rest % a.store.n_qtiles;
-  const unsigned grp = rest / a.store.n_qtiles;
-  const unsigned chunk = grp * 8 + xcd;
-  const long long row_begin = a.slab_row0 + (long long)chunk * a.rows_per_chunk;
-  if (row_begin >= a.slab_row1) return;
-  long long row_end = row_begin + a.rows_per_chunk;
-  if (row_end > a.slab_row1) row_end = a.slab_row1;
-  const int n_rows = (int)(row_end - row_begin);
-  const int nstages = (n_rows + kStageRows - 1) / kStageRows;
-  const unsigned row_begin32 = (unsigned)row_begin;
-  const signed char* chunk_base = a.xb8 + row_begin * kRowBytesI8;
-
-  const unsigned q0 = qt * (NW * QW * 32) + wave * (QW * 32);
-  i32x4 qf[QW][4];
-  int thr[QW];
-  WaveRecord* lane_list[QW];
-  unsigned lane_n[QW];
-  bool wave_live = false;
-#pragma unroll
-  for (int blk = 0; blk < QW; ++blk) {
-    const unsigned q = q0 + blk * 32 + li;
-    const signed char* qrow = a.xq8 + (size_t)q * kRowBytesI8;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) qf[blk][j] = *(const i32x4*)(qrow + (2 * j + half) * 16);
-    thr[blk] = nominate_threshold(a.tau[q], a.qp[q]);
-    wave_live = wave_live || thr[blk] != 0x7fffffff;
-    lane_n[blk] = 0u;
-    lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
-  }
-  wave_live = __any(wave_live);
-  const unsigned lane_cap = a.store.lane_cap;
-
-  unsigned rd_off[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) rd_off[j] = li * kRowBytesI8 + (((2 * j + half) ^ ((li >> 1) & 7)) << 4);
-
-  // LDS-DMA: 1 KiB per wave-instruction = 8 rows; lane t lands at (row t >> 3, slot t & 7) and fetches piece slot ^ ((row >> 1) & 7)
-  constexpr int kDmaPerWave = (kStageBytesI8 / 1024) / NW;   // 2
-  static_assert(kDmaPerWave == 2, "counted vmcnt below");
-  int dma_rel[kDmaPerWave];
-  int dma_piece_off[kDmaPerWave];
-#pragma unroll
-  for (int e = 0; e < kDmaPerWave; ++e) {
-    dma_rel[e] = (wave * kDmaPerWave + e) * 8 + (lane >> 3);
-    dma_piece_off[e] = ((lane & 7) ^ ((dma_rel[e] >> 1) & 7)) * 16;
-  }
-  auto issue_stage = [&](int s, int buf_off) {
-#pragma unroll
-    for (int e = 0; e < kDmaPerWave; ++e) {
-      int rel = s * kStageRows + dma_rel[e];
-      rel = rel < n_rows ? rel : n_rows - 1;
-      const signed char* src = chunk_base + (long long)rel * kRowBytesI8 + dma_piece_off[e];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(lds + buf_off + (wave * kDmaPerWave + e) * 1024),
-                                       16, 0, QW == 1 ? kDmaAux : 0);
-    }
-  };
-  // The barrier that publishes stage s+1 must know that this wave's DMA pieces of that stage have landed.  Vector memory
-  // operations of a wave complete in issue order on gfx9 (one counter for loads, LDS-DMA and stores; hipcc's own counted
-  // waits rely on it), so "at most the operations issued AFTER those pieces outstanding" is exact: the kDmaPerWave pieces of
-  // the younger stage plus the record stores of the two windows since -- counted per wave.  Waiting for the stores as
-  // well (`vmcnt(2)`, the fp16 scan's form: never wrong, only longer) makes every stage barrier wait for the write
-  // acknowledgement of whatever column was logged just before it: 0.5 of 4.1 ms at 2032 x 18M (cut experiments, ABLATIONS R5.2).
-  int st_prev = 0, st_cur = 0;   // record-store instructions of this wave: between the last two barriers / since the last one
-  auto publish = [&](bool younger_stage_in_flight) {
-    if (younger_stage_in_flight) {
-      const int allowed = __builtin_amdgcn_readfirstlane(2 + st_prev + st_cur);
-      if (a.flags & 2u) {   // experiment switch: the conservative form
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      } else if (allowed >= 37) {
-        asm volatile("s_waitcnt vmcnt(37)" ::: "memory");
-      } else if (allowed >= 32) {
-        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-      } else if (allowed >= 27) {
-        asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
-      } else if (allowed >= 22) {
-        asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-      } else if (allowed >= 17) {
-        asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-      } else if (allowed >= 12) {
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      } else if (allowed >= 7) {
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    } else {
-      dma_wait_barrier();
-    }
-    st_prev = st_cur;
-    st_cur = 0;
-  };
-  int off0 = 0, off1 = kStageBytesI8, off2 = 2 * kStageBytesI8, off3 = 3 * kStageBytesI8;
-  issue_stage(0, off0);
-  if (nstages > 1) issue_stage(1, off1);
-  if (nstages > 2) issue_stage(2, off2);
-  publish(nstages > 2);
-
-  if (!wave_live) {   // padding / exhausted queries only: the wave helps streaming and meets the barriers
-    for (int s = 0; s < nstages; ++s) {
-      publish(s + 2 < nstages);
-      if (s + 3 < nstages) issue_stage(s + 3, off3);
-      const int t = off0;
-      off0 = off1;
-      off1 = off2;
-      off2 = off3;
-      off3 = t;
-    }
-#pragma unroll
-    for (int blk = 0; blk < QW; ++blk)
-      a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
-    return;
-  }
-
-  if ((a.flags & 4u) && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // experiment: static priority for the younger half
-  i32x4 af[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(lds + off0 + rd_off[j]);
-  constexpr int kSubs = kStageRows / kSubRows;
-#ifdef PROQA_FILTER_STAMPS
-  unsigned long long stamp_mfma = 0, stamp_test = 0, stamp_units = 0, stamp_bar = 0, stamp_hit = 0, stamp_hits = 0;
-  const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
-#endif
-  for (int s = 0; s < nstages; ++s) {
-#pragma unroll
-    for (int u = 0; u < kSubs; ++u) {
-      if (u == 2 && !(a.flags & 16u)) {   // (flag 16, cut experiment: no barrier, no DMA after the prologue -- stale stages)
-#ifdef PROQA_FILTER_STAMPS
-        const unsigned long long sb0 = __builtin_amdgcn_s_memtime();
-#endif
-        publish(s + 2 < nstages);
-        if (s + 3 < nstages) issue_stage(s + 3, off3);
-#ifdef PROQA_FILTER_STAMPS
-        __builtin_amdgcn_sched_barrier(0);
-        stamp_bar += __builtin_amdgcn_s_memtime() - sb0;
-#endif
-      }
-#ifdef PROQA_FILTER_STAMPS
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long st0 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      const char* nxt = (u + 1 < kSubs) ? lds + off0 + (u + 1) * kSubBytesI8 : lds + off1;
-      i32x16 acc[QW];
-#pragma unroll
-      for (int blk = 0; blk < QW; ++blk) acc[blk] = i32x16{0};
-      if (a.flags & 1u) __builtin_amdgcn_s_setprio(3);   // experiment: the wave that has MFMAs to issue goes first
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int blk = 0; blk < QW; ++blk)
-          acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j], qf[blk][j], acc[blk], 0, 0, 0);
-      }
-      if (a.flags & 1u) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
-#ifdef PROQA_FILTER_STAMPS
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long st1 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-
-      bool hit[QW];
-      bool any_hit = false;
-      if (!(a.flags & 8u)) {   // (flag 8, cut experiment: the accumulators are not examined at all)
-#pragma unroll
-        for (int blk = 0; blk < QW; ++blk) {
-          hit[blk] = max16_i32(acc[blk]) > thr[blk];
-          any_hit = any_hit || hit[blk];
-        }
-      } else {
-#pragma unroll
-        for (int blk = 0; blk < QW; ++blk) hit[blk] = false;
-        asm volatile("" :: "v"(acc[0][0]), "v"(acc[QW - 1][15]));   // keeps the MFMAs
-      }
-      if (a.flags & 32u) any_hit = false;   // cut experiment: examined, never logged
-#ifdef PROQA_FILTER_STAMPS
-      const bool stamp_any = __any(any_hit);
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned long long st2 = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_sched_barrier(0);
-      stamp_mfma += st1 - st0;
-      stamp_test += st2 - st1;
-      ++stamp_units;
-#endif
-      if (__builtin_expect(__any(any_hit), 0)) {
-        int rel0 = s * kStageRows + u * kSubRows;
-        asm volatile("" : "+v"(rel0));
-        const int rel = rel0 + 4 * half;
-#pragma unroll
-        for (int blk = 0; blk < QW; ++blk) {
-          if (__any(hit[blk])) {   // (wave-uniform: exactly the regions whose five stores are issued are counted)
-            st_cur += 5;
-            if (hit[blk]) {
-              const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
-              write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, thr[blk]);
-              ++lane_n[blk];
-            }
-          }
-        }
-      }
-#ifdef PROQA_FILTER_STAMPS
-      if (stamp_any) {
-        __builtin_amdgcn_sched_barrier(0);
-        stamp_hit += __builtin_amdgcn_s_memtime() - st2;
-        ++stamp_hits;
-      }
-#endif
-    }
-    const int t = off0;
-    off0 = off1;
-    off1 = off2;
-    off2 = off3;
-    off3 = t;
-  }
-#ifdef PROQA_FILTER_STAMPS
-  if (lane == 0 && wave == 3) {   // one wave per workgroup reports: sums over its units (s_memtime ticks)
-    unsigned long long* dbg = g_filter_stamps;
-    atomicAdd(dbg + 0, stamp_mfma);
-    atomicAdd(dbg + 1, stamp_test);
-    atomicAdd(dbg + 2, stamp_units);
-    atomicAdd(dbg + 3, __builtin_amdgcn_s_memtime() - stamp_t0);
-    atomicAdd(dbg + 4, 1ull);
-    atomicAdd(dbg + 5, stamp_bar);
-    atomicAdd(dbg + 6, stamp_hit);
-    atomicAdd(dbg + 7, stamp_hits);
-  }
-#endif
-#pragma unroll
-  for (int blk = 0; blk < QW; ++blk) {
-    if (lane_n[blk] > lane_cap) {
-      *a.overflow = 1u;
-      lane_n[blk] = lane_cap;
-    }
-    a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = lane_n[blk];
-  }
-}
-
-// The same scan with HALF the workgroup barriers: the ring is two PAIRS of stages (2 x 32 KiB); the barrier at the top of pair
-// p publishes it (every wave's DMA pieces of the pair have landed: issued one pair -- eight units -- earlier; the only
-// younger vector-memory operations of the wave are its record stores, counted) and frees the buffers of pair p-1, which
-// receive pair p+1 right behind it.  Cycle stamps of the stage-wise kernel put 40 % of a wave's time into its one barrier per
-// stage (the eight waves of a workgroup drift apart by their excursions and by the issue arbitration).
-template <int QW>
-__global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8_pairs(FilterArgsI8 a) {
   static_assert(QW == 1 || QW == 2, "8 waves x 32 / 64 queries");
   __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytesI8];
   constexpr int NW = kFilterWaves;
@@ -836,7 +600,7 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8_pairs(Filter
 
   const unsigned q0 = qt * (NW * QW * 32) + wave * (QW * 32);
   i32x4 qf[QW][4];
-  int thr[QW];
+  LaneThreshold thr[QW];
   WaveRecord* lane_list[QW];
   unsigned lane_n[QW];
   bool wave_live = false;
@@ -846,8 +610,8 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8_pairs(Filter
     const signed char* qrow = a.xq8 + (size_t)q * kRowBytesI8;
 #pragma unroll
     for (int j = 0; j < 4; ++j) qf[blk][j] = *(const i32x4*)(qrow + (2 * j + half) * 16);
-    thr[blk] = nominate_threshold(a.tau[q], a.qp[q]);
-    wave_live = wave_live || thr[blk] != 0x7fffffff;
+    thr[blk] = lane_threshold(a.tau[q], a.qp[q]);
+    wave_live = wave_live || thr[blk].A != __builtin_inff();
     lane_n[blk] = 0u;
     lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
   }
@@ -918,50 +682,70 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8_pairs(Filter
       a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
     return;
   }
+  // The block constants {G_b, X_b} of a pair's eight units are wave-uniform: ONE scalar load of 64 bytes per pair, issued a
+  // pair ahead (hipcc turns `a.blk[i]` into a vector load per unit -- a memory round trip inside every unit, and one more
+  // operation in the counted vmcnt).  The load is asynchronous (lgkmcnt): the wait that makes it readable is the
+  // `lgkmcnt(0)` below, tied to the registers by an in/out operand so that no use is scheduled above it.  (An outstanding
+  // scalar load only makes hipcc's own counted lgkmcnt waits for the fragment reads stricter, never laxer.)
+  auto load_blocks = [&](int p) {
+    const unsigned long long addr = (unsigned long long)(a.blk + (row_begin >> 5) + 8ll * p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)addr);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(addr >> 32));
+    const unsigned long long uaddr = ((unsigned long long)hi << 32) | lo;
+    f32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(uaddr) : "memory");
+    return v;
+  };
+  f32x16 bc_next = load_blocks(0);
   for (int p = 0; p < npairs; ++p) {
     publish();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bc_next)::"memory");
+    const f32x16 bc = bc_next;
     if (p + 1 < npairs) issue_pair(p + 1);
     const char* base = lds + (p & 1) * 2 * kStageBytesI8;
     const int nunits = (nstages - 2 * p >= 2 ? 2 : 1) * (kStageRows / kSubRows);
     i32x4 af[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(base + rd_off[j]);
-    for (int u0 = 0; u0 < nunits; u0 += 4) {
 #pragma unroll
-      for (int uu = 0; uu < 4; ++uu) {
-        const int u = u0 + uu;
-        const char* nxt = base + (u + 1 < nunits ? u + 1 : u) * kSubBytesI8;
-        i32x16 acc[QW];
+    for (int u = 0; u < 8; ++u) {
+      if (u == 4 && nunits <= 4) break;   // (the chunk's last pair may hold one stage)
+      // (the next pair's constants: requested mid-pair, not next to the first fragment reads behind the barrier, whose
+      // lgkmcnt(0) would wait for the scalar load as well)
+      if (u == 2 && p + 1 < npairs) bc_next = load_blocks(p + 1);
+      const char* nxt = base + (u + 1 < nunits ? u + 1 : u) * kSubBytesI8;
+      i32x16 acc[QW];
 #pragma unroll
-        for (int blk = 0; blk < QW; ++blk) acc[blk] = i32x16{0};
+      for (int blk = 0; blk < QW; ++blk) acc[blk] = i32x16{0};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j) {
 #pragma unroll
-          for (int blk = 0; blk < QW; ++blk)
-            acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j], qf[blk][j], acc[blk], 0, 0, 0);
-        }
+        for (int blk = 0; blk < QW; ++blk)
+          acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j], qf[blk][j], acc[blk], 0, 0, 0);
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
-        bool hit[QW];
-        bool any_hit = false;
+      for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
+      bool hit[QW];
+      float tb[QW];
+      bool any_hit = false;
+#pragma unroll
+      for (int blk = 0; blk < QW; ++blk) {
+        tb[blk] = block_threshold(thr[blk], bc[2 * u], bc[2 * u + 1]);
+        hit[blk] = (float)max16_i32(acc[blk]) > tb[blk];   // (|acc| <= 127 * 127 * 128 < 2^24: the conversion is exact)
+        any_hit = any_hit || hit[blk];
+      }
+      if (__builtin_expect(__any(any_hit), 0)) {
+        int rel0 = (2 * p * 4 + u) * kSubRows;
+        asm volatile("" : "+v"(rel0));
+        const int rel = rel0 + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < QW; ++blk) {
-          hit[blk] = max16_i32(acc[blk]) > thr[blk];
-          any_hit = any_hit || hit[blk];
-        }
-        if (__builtin_expect(__any(any_hit), 0)) {
-          int rel0 = (2 * p * 4 + u) * kSubRows;
-          asm volatile("" : "+v"(rel0));
-          const int rel = rel0 + 4 * half;
-#pragma unroll
-          for (int blk = 0; blk < QW; ++blk) {
-            if (__any(hit[blk])) {
-              st_cur += 5;
-              if (hit[blk]) {
-                const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;
-                write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, thr[blk]);
-                ++lane_n[blk];
-              }
+          if (__any(hit[blk])) {   // (wave-uniform: exactly the regions whose five stores are issued are counted)
+            st_cur += 5;
+            if (hit[blk]) {
+              const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
+              write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, tb[blk]);
+              ++lane_n[blk];
             }
           }
         }
@@ -1040,7 +824,7 @@ __global__ __launch_bounds__(256) void column_stats_partial(const _Float16* __re
   }
 }
 
-// col[0..127] = mean, col[128..255] = 127 / c, col[256..383] = c / 127, with c = max |x - mean| as the quantiser computes it
+// col[0..127] = mean, col[128..255] = 1 / c, col[256..383] = c, with c = max |x - mean| as the quantiser computes it
 __global__ __launch_bounds__(kDim) void column_stats_finish(const float* __restrict__ partial, int groups, long long n, float* __restrict__ col,
                                                             QuantStats* __restrict__ stats) {
   const int d = threadIdx.x;
@@ -1055,22 +839,24 @@ __global__ __launch_bounds__(kDim) void column_stats_finish(const float* __restr
   const float mean = (float)(sum / (double)(n > 0 ? n : 1));
   const float c = __builtin_fmaxf(hi - mean, mean - lo);   // rounding is monotone: = max over the rows of |fl(x - mean)|
   const bool finite = c >= 0.f && c < __builtin_inff() && mean == mean;
-  const float inv = finite && c > 0.f ? 127.0f / c : 0.f;
+  const float inv = finite && c > 0.f ? 1.0f / c : 0.f;
   if (!finite || !(inv < __builtin_inff())) atomicOr(&stats->nonfinite, 1u);
   // a constant dimension (c == 0) keeps its mean -- x - mean = 0 exactly, it quantises to 0 with residual 0 and its whole
   // contribution q_d x_d sits in the query's offset q.mean
   col[d] = finite ? mean : 0.f;
   col[kDim + d] = inv;
-  col[2 * kDim + d] = finite && c > 0.f ? c / 127.0f : 0.f;
+  col[2 * kDim + d] = finite ? c : 0.f;
 }
 
-// xi = clamp(rint((x - mean) 127 / c)); R, Xn, Xf of QuantStats (rounded up a little, as non-negative float bits).
-// 16 lanes per row (8 dimensions = 16 bytes of fp16 in, 8 bytes of int8 out each), four rows per wave and trip, a grid-stride
-// loop; the maxima are kept per lane group and reach the device words once per wave.
+// One wave per 32-row block (16 lanes per row, four rows per trip, the block's 8 KiB held in registers): u = (x - mean) / c,
+// the block scale f_b = max |u|, xi = clamp(rint(127 u / f_b)); blk[b] = {G_b = 127 / f_b, X_b = max ||xi|| of its rows}; R, Xn,
+// Xf of QuantStats (all rounded up a little; maxima as non-negative float bits).  Rows past n (the shard's last block) count
+// as the mean.
 __global__ __launch_bounds__(256) void quantise_rows_i8(const _Float16* __restrict__ xb, long long n, const float* __restrict__ col,
-                                                        signed char* __restrict__ xb8, QuantStats* __restrict__ stats) {
+                                                        signed char* __restrict__ xb8, float2* __restrict__ blk,
+                                                        QuantStats* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
-  const int sub = lane & 15;
+  const int sub = lane & 15, rsub = lane >> 4;
   float mu[8], inv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -1078,34 +864,62 @@ __global__ __launch_bounds__(256) void quantise_rows_i8(const _Float16* __restri
     inv[e] = col[kDim + sub * 8 + e];
   }
   float max_r = 0.f, max_i = 0.f, max_x = 0.f;
-  const long long stride = (long long)gridDim.x * 16;
-  for (long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); row < n; row += stride) {
-    const f16x8 v = *(const f16x8*)(xb + row * kDim + sub * 8);
-    float sr = 0.f, si = 0.f, sx = 0.f;
-    typedef signed char i8x8 __attribute__((ext_vector_type(8)));
-    i8x8 o;
+  const long long n_blocks = (n + 31) / 32;
+  for (long long b = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); b < n_blocks; b += (long long)gridDim.x * 4) {
+    float u[8][8];
+    float amax = 0.f, sx_max = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float x = (float)v[e];
-      const float t = (x - mu[e]) * inv[e];
-      const float i = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(t)));
-      const float r = t - i;
-      o[e] = (signed char)(int)i;
-      sr += r * r;
-      si += i * i;
-      sx += x * x;
-    }
-    *(i8x8*)(xb8 + row * kDim + sub * 8) = o;
+    for (int it = 0; it < 8; ++it) {
+      const long long row = b * 32 + it * 4 + rsub;
+      f16x8 v = {0};
+      const bool live = row < n;
+      if (live) v = *(const f16x8*)(xb + row * kDim + sub * 8);
+      float sx = 0.f;
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes of the row
-      sr += __shfl_xor(sr, off, 64);
-      si += __shfl_xor(si, off, 64);
-      sx += __shfl_xor(sx, off, 64);
+      for (int e = 0; e < 8; ++e) {
+        const float x = (float)v[e];
+        u[it][e] = live ? (x - mu[e]) * inv[e] : 0.f;
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(u[it][e]));
+        sx += live ? x * x : 0.f;
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) sx += __shfl_xor(sx, off, 64);
+      sx_max = sx > sx_max ? sx : sx_max;
     }
-    // (a NaN -- non-finite rows, flagged by column_stats -- compares false and leaves the maxima alone)
-    max_r = sr > max_r ? sr : max_r;
-    max_i = si > max_i ? si : max_i;
-    max_x = sx > max_x ? sx : max_x;
+    float f = wave_max_f(amax);
+    if (!(f > 0.f)) f = 1.0f;                  // every row of the block is the mean (or the block is not finite: flagged)
+    const float G = 127.0f / f;
+    float si_max = 0.f, sr_max = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const long long row = b * 32 + it * 4 + rsub;
+      typedef signed char i8x8 __attribute__((ext_vector_type(8)));
+      i8x8 o;
+      float sr = 0.f, si = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = u[it][e] * G;
+        const float i = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, __builtin_rintf(t)));
+        const float r = t - i;
+        o[e] = (signed char)(int)i;
+        sr += r * r;
+        si += i * i;
+      }
+      if (row < n) *(i8x8*)(xb8 + row * kDim + sub * 8) = o;
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {   // the 16 lanes of the row
+        sr += __shfl_xor(sr, off, 64);
+        si += __shfl_xor(si, off, 64);
+      }
+      // (a NaN -- non-finite rows, flagged by column_stats -- compares false and leaves the maxima alone)
+      sr_max = sr > sr_max ? sr : sr_max;
+      si_max = si > si_max ? si : si_max;
+    }
+    const float xb_ = __builtin_sqrtf(wave_max_f(si_max)) * (1.0f + 0x1p-10f);
+    if (lane == 0) blk[b] = make_float2(G, xb_);
+    max_r = sr_max > max_r ? sr_max : max_r;
+    max_i = si_max > max_i ? si_max : max_i;
+    max_x = sx_max > max_x ? sx_max : max_x;
   }
   max_r = wave_max_f(max_r);
   max_i = wave_max_f(max_i);
@@ -1148,19 +962,18 @@ __global__ __launch_bounds__(256) void prep_queries_i8(const _Float16* __restric
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) off += __shfl_xor(off, d, 64);
   if (lane == 0) {
-    const float R = __uint_as_float(stats->max_resid) + 0x1p-10f, Xn = __uint_as_float(stats->max_inorm),
-                Xf = __uint_as_float(stats->max_xnorm);
-    // score units: the fp32 accumulation of the exact score's MFMA sums and the rounding of `off` itself.  (No term for fp16
-    // subnormal operands: v_mfma_f32_32x32x16_f16 multiplies them as their values on gfx950 --
-    // scripts/native/mfma_f16_subnormal_probe.cpp -- so the exact score is the sum the bound is about; with the term the
-    // exact-float32 mode carries for that case, corpora of values around 1e-3 nominated every row.)
+    const float R = __uint_as_float(stats->max_resid) + 0x1p-10f, Xf = __uint_as_float(stats->max_xnorm);
+    // score units: the fp32 accumulation of the exact score's MFMA sums and the rounding of `off` itself -- added to the
+    // offset, i.e. taken off the threshold.  (No term for fp16 subnormal operands: v_mfma_f32_32x32x16_f16 multiplies them as
+    // their values on gfx950 -- scripts/native/mfma_f16_subnormal_probe.cpp -- so the exact score is the sum the bound is
+    // about; with the term the exact-float32 mode carries for that case, corpora of values around 1e-3 nominated every row.)
     const float delta = 0x1p-16f * n_q * Xf + 0x1p-20f * abs_off;
     NominateParams p;
-    p.off = (float)off;
-    p.inv_unit = inv;
-    p.margin = ok ? ((n_u * R + n_e * Xn) + delta * inv) * (1.0f + 0x1p-10f) + 1.0f : 1.0f;   // !ok: a zero query -- acc = 0 > -2 always
-    if (!(stats->nonfinite == 0u)) p.margin = __builtin_nanf("");   // never used on such an index; a NaN nominates everything
-    p.pad = 0.f;
+    p.off = (float)off + delta + __builtin_fabsf((float)off) * 0x1p-22f;
+    p.inv_unit = inv;                                          // (0 for a zero query: A = 0, every row with acc = 0 > -B passes)
+    p.margin_r = n_u * R * (1.0f + 0x1p-10f) + 0x1p-6f;       // + the roundings of the threshold's own arithmetic
+    p.err_norm = n_e;
+    if (!(stats->nonfinite == 0u)) p.margin_r = __builtin_inff();   // never scanned (QuantStats::nonfinite); would nominate everything
     qp[q] = p;
     stat_nom[q] = 0ull;
   }
@@ -1203,7 +1016,7 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
     const unsigned raw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const bool pass = INT_SCORES ? ((int)raw[e] > (int)h.w) : (inclusive ? (sc[e] >= tau) : (sc[e] > tau));
+      const bool pass = INT_SCORES ? ((float)(int)raw[e] > tau) : (inclusive ? (sc[e] >= tau) : (sc[e] > tau));
       if (pass && (e + 8 * g) < rows_left) {
         const unsigned row = h.y + (unsigned)(e + 8 * g);
         if (ex.nom) {  // the fp16 score only nominates the row
@@ -1630,13 +1443,12 @@ void topk_merge(MergeArgs a) {
             }
           }
         } else if constexpr (NOM) {   // int8 nomination: int32 scores above the integer threshold name the rows to re-score
-          const int thr = __shfl((int)v.w, head, 64);
-          const int raw[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+          const int raw[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};   // (tau: the float threshold of the record's block)
           bool p[4];
           unsigned long long m[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            p[e] = live && piece != 0 && raw[e] > thr && (e + 8 * g) < rows_left;
+            p[e] = live && piece != 0 && (float)raw[e] > tau && (e + 8 * g) < rows_left;
             m[e] = __ballot(p[e]);
           }
           const unsigned n0 = (unsigned)__builtin_popcountll(m[0]), n1 = (unsigned)__builtin_popcountll(m[1]),
@@ -2556,9 +2368,9 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
 hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st) {
   if (!(a.flags & 64u)) {   // the shipped form: one barrier per two stages (flag 64: the stage-wise kernel, for A/B runs and cut experiments)
     if (qw == 2)
-      hipLaunchKernelGGL((mips_filter_i8_pairs<2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+      hipLaunchKernelGGL((mips_filter_i8<2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
     else
-      hipLaunchKernelGGL((mips_filter_i8_pairs<1>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+      hipLaunchKernelGGL((mips_filter_i8<1>), dim3(grid), dim3(kFilterThreads), 0, st, a);
     return hipGetLastError();
   }
   if (qw == 2)   // (flag 256, experiment: 24 KiB of unused dynamic LDS leave room for ONE workgroup per CU)
@@ -2576,11 +2388,12 @@ hipError_t launch_column_stats(const void* xb16, long long n, float* partial, fl
   return hipGetLastError();
 }
 
-hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, QuantStats* stats, hipStream_t st) {
+hipError_t launch_quantise_rows_i8(const void* xb16, long long n, const float* col, signed char* xb8, float2* blk, QuantStats* stats,
+                                   hipStream_t st) {
   if (n == 0) return hipSuccess;
-  const long long want = (n + 15) / 16;
+  const long long want = ((n + 31) / 32 + 3) / 4;
   const unsigned grid = (unsigned)std::min<long long>(want, 8ll * 1024);
-  hipLaunchKernelGGL(quantise_rows_i8, dim3(grid), dim3(256), 0, st, (const _Float16*)xb16, n, col, xb8, stats);
+  hipLaunchKernelGGL(quantise_rows_i8, dim3(grid), dim3(256), 0, st, (const _Float16*)xb16, n, col, xb8, blk, stats);
   return hipGetLastError();
 }
 

@@ -17,7 +17,9 @@ root = sys.argv[1]
 def short(name):
     if "mips_filter_f16<1" in name:
         return "mips_filter_f16_qw1"      # the HBM-bound small-batch instantiation (bench.py scan_small_batch)
-    for key in ("mips_filter_f16", "topk_merge", "merge_sorted_lists", "merge_lists", "kmeans_assign", "segmented_mean", "bootstrap_scores", "bootstrap_select", "prep_queries",
+    if "mips_filter_i8_pairs<1" in name or "mips_filter_i8<1" in name:
+        return "mips_filter_i8_qw1"
+    for key in ("mips_filter_i8", "mips_filter_f16", "quantise_rows_i8", "column_stats", "prep_queries_i8", "topk_merge", "merge_sorted_lists", "merge_lists", "kmeans_assign", "segmented_mean", "bootstrap_scores", "bootstrap_select", "prep_queries",
                 "finalize_topk", "gemm_tn_f16", "attention_fwd", "attention_cls_fwd", "bias_gelu", "bias_residual_layernorm",
                 "embed_layernorm", "pool_project", "cls_dense_mfma", "small_dense_mfma", "gather_rows_kernel", "stream_copy", "stream_read", "mfma_loop", "Cijk_"):
         if key in name:
@@ -71,38 +73,49 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
         d.setdefault("duration_ns_" + sub, dur[n])
         d.update(per[n])
 
-f = summary.get("mips_filter_f16", {})
-derived = {}
-searches = None
-if "launches_pmc_fetch" in f:
-    # full-size searches in the pass = launches of the QW=2 instantiation / rounds per search (bench line)
-    rounds = bench_line("pmc_fetch.log").get("config", {}).get("rounds", 8)
-    searches = f["launches_pmc_fetch"] / rounds
-    derived["rounds_per_search"] = rounds
-    derived["searches_profiled"] = searches
-    derived["FETCH_SIZE_KB_per_search_raw"] = f["FETCH_SIZE"] / searches
-    derived["hbm_read_bytes_per_search"] = 2 * f["FETCH_SIZE"] * 1024 / searches   # gfx950: FETCH_SIZE counts 1/2
-if "WRITE_SIZE" in f and searches:
-    derived["hbm_write_bytes_per_search_uncalibrated"] = f["WRITE_SIZE"] * 1024 / searches
-if "GRBM_GUI_ACTIVE" in f:
-    clk = f["GRBM_GUI_ACTIVE"] / 8 / f["duration_ns_pmc_grbm"]   # 8 XCD instances summed
-    derived["effective_clock_GHz_profiled"] = clk
-if "SQ_VALU_MFMA_BUSY_CYCLES" in f and "SQ_BUSY_CYCLES" in f:
-    # SQ_BUSY_CYCLES is summed over 32 shader engines; 1024 SIMDs
-    cycles = f["SQ_BUSY_CYCLES"] / 32
-    # two denominators: cycles in which a wave is resident somewhere (SQ busy), and all GPU-active cycles of the
-    # launches (GRBM_GUI_ACTIVE / 8 XCDs, from the GRBM pass scaled by launch count) -- the latter counts launch ramps
-    # and tails as idle and is the figure DESIGN.md section 2.3 quotes
-    derived["mfma_pipe_busy_of_sq_busy"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)
-    if "GRBM_GUI_ACTIVE" in f and f.get("launches_pmc_grbm"):
-        scale = f["launches_pmc_grbm"] / max(f.get("launches_pmc_sq", 1), 1)
-        derived["mfma_pipe_busy_of_gpu_active"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] * scale / (1024 * f["GRBM_GUI_ACTIVE"] / 8)
-    derived["lds_active_fraction"] = f["SQ_LDS_IDX_ACTIVE"] / (256 * cycles)
-    derived["wave_wait_fraction"] = f["SQ_WAIT_ANY"] / f["SQ_WAVE_CYCLES"]
-    derived["wave_issue_stall_fraction"] = f["SQ_WAIT_INST_ANY"] / f["SQ_WAVE_CYCLES"]
-g = summary.get("mips_filter_f16_qw1", {})
+def derive(f):
+    """per-search figures of one filter kernel from its counter sums"""
+    derived = {}
+    searches = None
+    if "launches_pmc_fetch" in f:
+        # full-size searches in the pass = launches of the QW=2 instantiation / rounds per search (bench line)
+        rounds = bench_line("pmc_fetch.log").get("config", {}).get("rounds", 8)
+        searches = f["launches_pmc_fetch"] / rounds
+        derived["rounds_per_search"] = rounds
+        derived["searches_profiled"] = searches
+        derived["FETCH_SIZE_KB_per_search_raw"] = f["FETCH_SIZE"] / searches
+        derived["hbm_read_bytes_per_search"] = 2 * f["FETCH_SIZE"] * 1024 / searches   # gfx950: FETCH_SIZE counts 1/2
+    if "WRITE_SIZE" in f and searches:
+        derived["hbm_write_bytes_per_search_uncalibrated"] = f["WRITE_SIZE"] * 1024 / searches
+    if "GRBM_GUI_ACTIVE" in f:
+        clk = f["GRBM_GUI_ACTIVE"] / 8 / f["duration_ns_pmc_grbm"]   # 8 XCD instances summed
+        derived["effective_clock_GHz_profiled"] = clk
+        derived["avg_launch_us_profiled"] = f["duration_ns_pmc_grbm"] / max(f.get("launches_pmc_grbm", 1), 1) / 1e3
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in f and "SQ_BUSY_CYCLES" in f:
+        # SQ_BUSY_CYCLES is summed over 32 shader engines; 1024 SIMDs
+        cycles = f["SQ_BUSY_CYCLES"] / 32
+        # two denominators: cycles in which a wave is resident somewhere (SQ busy), and all GPU-active cycles of the
+        # launches (GRBM_GUI_ACTIVE / 8 XCDs, from the GRBM pass scaled by launch count) -- the latter counts launch ramps
+        # and tails as idle and is the figure DESIGN.md section 2.3 quotes
+        derived["mfma_pipe_busy_of_sq_busy"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)
+        if "GRBM_GUI_ACTIVE" in f and f.get("launches_pmc_grbm"):
+            scale = f["launches_pmc_grbm"] / max(f.get("launches_pmc_sq", 1), 1)
+            derived["mfma_pipe_busy_of_gpu_active"] = f["SQ_VALU_MFMA_BUSY_CYCLES"] * scale / (1024 * f["GRBM_GUI_ACTIVE"] / 8)
+        derived["lds_active_fraction"] = f["SQ_LDS_IDX_ACTIVE"] / (256 * cycles)
+        derived["wave_wait_fraction"] = f["SQ_WAIT_ANY"] / f["SQ_WAVE_CYCLES"]
+        derived["wave_issue_stall_fraction"] = f["SQ_WAIT_INST_ANY"] / f["SQ_WAVE_CYCLES"]
+    return derived
+
+
+# the dominant kernel of the timed search: the int8 nomination scan when the bench ran it, with the fp16 scan beside it
+nominated = "mips_filter_i8" in summary
+derived = derive(summary.get("mips_filter_i8" if nominated else "mips_filter_f16", {}))
+derived["kernel"] = "mips_filter_i8" if nominated else "mips_filter_f16"
+if nominated and "mips_filter_f16" in summary:
+    summary["derived_mips_filter_f16"] = derive(summary["mips_filter_f16"])
+g = summary.get("mips_filter_i8_qw1" if nominated else "mips_filter_f16_qw1", {})
 if "FETCH_SIZE" in g:
-    # bench.py's scan_small_batch leg: 6 searches of 32 queries (3 plain + 3 with HIP-event brackets)
+    # bench.py's scan_small_batch leg: 6 searches of 32 queries (3 plain + 3 with HIP-event brackets) per scan
     derived["small_batch_hbm_read_bytes_per_search"] = 2 * g["FETCH_SIZE"] * 1024 / 6
 summary["derived_mips_filter"] = derived
 
@@ -171,9 +184,11 @@ if enc_traffic:
     summary["derived_encoder_traffic"] = enc_traffic
 json.dump(summary, open(os.path.join(root, "pmc_summary.json"), "w"), indent=1)
 if "hbm_read_bytes_per_search" in derived:
-    traffic = {"hbm_bytes_per_search": derived["hbm_read_bytes_per_search"],
-               "note": "mips_filter_f16: 2 x FETCH_SIZE (gfx950 correction) summed over the rounds of one search; "
-                       "algorithmic bytes are N*256 = 4.608e9"}
+    traffic = {"hbm_bytes_per_search": derived["hbm_read_bytes_per_search"], "nomination": nominated,
+               "note": derived["kernel"] + ": 2 x FETCH_SIZE (gfx950 correction) summed over the rounds of one search; algorithmic "
+                       "bytes are N*256 = 4.608e9 (fp16 rows; the int8 nomination scan streams N*128 = 2.304e9 of its copy)"}
+    if "derived_mips_filter_f16" in summary and "hbm_read_bytes_per_search" in summary["derived_mips_filter_f16"]:
+        traffic["fp16_scan_hbm_bytes_per_search"] = summary["derived_mips_filter_f16"]["hbm_read_bytes_per_search"]
     if "hbm_read_bytes_per_step" in enc_traffic:
         traffic["encode_hbm_read_bytes_per_step"] = enc_traffic["hbm_read_bytes_per_step"]
         traffic["encode_step_shape"] = [512, 128]

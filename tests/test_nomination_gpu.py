@@ -126,17 +126,17 @@ def test_a_row_the_int8_score_undersells_by_most_of_the_margin_is_still_returned
 
 
 def test_data_that_does_not_quantise_goes_back_to_the_fp16_scan(gpu_device):
-    """One outlier per dimension (-2000 where the bulk is within +-4; the queries are non-negative, so the outliers themselves
-    never rank) stretches every dimension's scale until the bulk rows all quantise to zero: the first search nominates
-    everything (lists overflow, the fp16 overflow-safe path finishes it -- the result is still exact); the automatic mode then
-    stays with the fp16 scan until the rows change."""
+    """An outlier row in EVERY 32-row block (-2000 in all dimensions where the bulk is within +-4; the queries are non-negative,
+    so the outliers themselves never rank) stretches every block's scale until the bulk rows all quantise to zero -- a few
+    outlier rows would only cost their own blocks (test_float_corpora... / test_full_size_properties).  The first search
+    nominates everything (lists overflow, the fp16 overflow-safe path finishes it -- the result is still exact); the
+    automatic mode then stays with the fp16 scan until the rows change."""
     import torch
     from proqa_amd.index import IndexFlatIP
     rng = np.random.default_rng(23)
     n, nq, k = 70000, 300, 20
     xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq, 0, 4)
-    for d in range(128):
-        xb[1000 + 37 * d, d] = -2000.0
+    xb[5::32] = -2000.0
     Do, Io = search_oracle.topk_ip(xq, xb, k)
     ix = IndexFlatIP(128)
     ix.add(xb)
