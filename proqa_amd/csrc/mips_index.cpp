@@ -554,6 +554,41 @@ struct RoundShape {
   bool compact = false;       // lane lists of 8-byte keys instead of column records (the dense one-pass launch)
 };
 
+#ifdef PROQA_MERGE_STAMPS
+// developer build: every 16th merge launch runs with s_memtime stamps of its phases and prints their medians
+bool merge_stamps_dump(MergeArgs& ma, unsigned nq_pad, hipStream_t st) {
+  static unsigned long long* dbg_buf = nullptr;
+  if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 16384 * 8 * 8);
+  ma.dbg = dbg_buf;
+  static int launches = 0;
+  if (!(getenv("PROQA_MERGE_STAMPS_DUMP") && ++launches % 16 == 15)) return false;
+  (void)launch_merge(ma, nq_pad, st);
+  (void)hipStreamSynchronize(st);
+  std::vector<unsigned long long> h((size_t)nq_pad * 8);
+  (void)hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
+  for (int ph = 1; ph <= 6; ++ph) {
+    std::vector<long long> d;
+    for (unsigned q = 0; q < nq_pad && q < 2000; ++q) d.push_back((long long)(h[q * 8 + ph] - h[q * 8 + ph - 1]));
+    std::sort(d.begin(), d.end());
+    fprintf(stderr, "merge phase %d: median %lld  p10 %lld  p90 %lld (s_memtime ticks)\n", ph, d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+  }
+  if (ma.xb16) {   // int8 nomination rounds: the re-scoring sits inside phase 4 (stamp 7 = its end)
+    std::vector<long long> d;
+    for (unsigned q = 0; q < nq_pad && q < 2000; ++q) d.push_back((long long)(h[q * 8 + 7] - h[q * 8 + 3]));
+    std::sort(d.begin(), d.end());
+    fprintf(stderr, "  of phase 4, re-scoring of the nominated rows: median %lld  p10 %lld  p90 %lld\n", d[d.size() / 2], d[d.size() / 10],
+            d[d.size() * 9 / 10]);
+  }
+  std::vector<long long> e;
+  unsigned long long t0 = ~0ull;
+  for (unsigned q = 0; q < nq_pad && q < 2000; ++q) t0 = std::min(t0, h[q * 8]);
+  for (unsigned q = 0; q < nq_pad && q < 2000; ++q) e.push_back((long long)(h[q * 8] - t0));
+  std::sort(e.begin(), e.end());
+  fprintf(stderr, "merge start skew: median %lld max %lld\n", e[e.size() / 2], e.back());
+  return true;
+}
+#endif
+
 int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, unsigned nq_pad, int k,
               bool inclusive, bool dense, bool bounded, unsigned* overflow_word, hipStream_t st, hipEvent_t f0,
               hipEvent_t f1, const RoundShape& shape = RoundShape()) {
@@ -594,6 +629,9 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     ma.xb16 = idx->xb;
     ma.stat_nominated = idx->stat_nom;
     ma.lean = 0;
+#ifdef PROQA_MERGE_STAMPS
+    if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
+#endif
     PROQA_HIP(launch_merge(ma, nq_pad, st));
     if (kDebugCand) {   // developer: records the scan logged / rows the merges re-scored so far / candidates so far
       (void)hipStreamSynchronize(st);
@@ -664,31 +702,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.stat_nominated = nullptr;
   ma.lean = 0;
 #ifdef PROQA_MERGE_STAMPS
-  {
-    static unsigned long long* dbg_buf = nullptr;
-    if (!dbg_buf) (void)hipMalloc((void**)&dbg_buf, 16384 * 8 * 8);
-    ma.dbg = dbg_buf;
-    static int launches = 0;
-    if (getenv("PROQA_MERGE_STAMPS_DUMP") && ++launches % 16 == 15) {
-      PROQA_HIP(launch_merge(ma, nq_pad, st));
-      (void)hipStreamSynchronize(st);
-      std::vector<unsigned long long> h((size_t)nq_pad * 8);
-      (void)hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
-      for (int ph = 1; ph <= 6; ++ph) {
-        std::vector<long long> d;
-        for (unsigned q = 0; q < nq_pad && q < 2000; ++q) d.push_back((long long)(h[q * 8 + ph] - h[q * 8 + ph - 1]));
-        std::sort(d.begin(), d.end());
-        fprintf(stderr, "merge phase %d: median %lld  p10 %lld  p90 %lld (s_memtime ticks)\n", ph, d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
-      }
-      std::vector<long long> e;
-      unsigned long long t0 = ~0ull;
-      for (unsigned q = 0; q < nq_pad && q < 2000; ++q) t0 = std::min(t0, h[q * 8]);
-      for (unsigned q = 0; q < nq_pad && q < 2000; ++q) e.push_back((long long)(h[q * 8] - t0));
-      std::sort(e.begin(), e.end());
-      fprintf(stderr, "merge start skew: median %lld max %lld\n", e[e.size() / 2], e.back());
-      return PROQA_OK;
-    }
-  }
+  if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
   PROQA_HIP(launch_merge(ma, nq_pad, st));
   return PROQA_OK;

@@ -1634,6 +1634,7 @@ void topk_merge(MergeArgs a) {
       }
     }
     __syncthreads();
+    PROQA_STAMP(7);
   }
 
   const unsigned n_seen = s_n_keys;
