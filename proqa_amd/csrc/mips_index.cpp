@@ -628,7 +628,6 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     ma.xq16 = idx->xq_pad;
     ma.xb16 = idx->xb;
     ma.stat_nominated = idx->stat_nom;
-    ma.lean = 0;
 #ifdef PROQA_MERGE_STAMPS
     if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -700,7 +699,6 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.xq16 = nullptr;
   ma.xb16 = nullptr;
   ma.stat_nominated = nullptr;
-  ma.lean = 0;
 #ifdef PROQA_MERGE_STAMPS
   if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif

@@ -114,7 +114,6 @@ struct MergeArgs {
   const void* xq16;              // fp16 [nq_pad,128] padded queries
   const char* xb16;              // fp16 corpus rows of this shard
   unsigned long long* stat_nominated;  // [nq_pad] rows re-scored per query (statistics)
-  int lean;                      // the eight-workgroups-per-CU form of that merge (kMergeNominatedI8Lean)
 };
 
 // ---- int8 nomination scan (the k <= kPageK rounds of an fp16 index; see "int8 nomination" in mips_kernels.hip) ----------

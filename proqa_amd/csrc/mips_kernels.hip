@@ -1212,17 +1212,17 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
 //        re-scoring modes are instantiations of their own -- their LDS lists and registers stay out of the fp16 kernel
 // CAP = keys one merge holds: kMaxSortKeys (k <= kPageK: 8 workgroups per CU) or kBigSortKeys (big pages)
 // T = threads: 256, or 512 for the largest CAP (one workgroup per CU there: the second wave per SIMD hides the latencies)
-// kMergeNominatedI8Lean: the same merge within the fp16 merge's budget (64 VGPRs, < 20 KiB of LDS: eight workgroups per CU, so
-//        that the 2032 merges of a round are resident at once): the nominee list and the work queue live inside keys[] (upper
-//        half / lower quarter -- the passing keys of a round are limited to CAP / 2), the query fragments come from LDS, the rows
-//        are gathered in two halves of four k-steps
-constexpr int kMergeF16 = 0, kMergeExactF32 = 1, kMergeNominatedI8 = 2, kMergeNominatedI8Lean = 3;
+// kMergeNominatedI8 keeps its nominee list and its work queue INSIDE keys[] (upper half / lower quarter: the passing keys of a
+//        round are limited to CAP / 2, more raise the overflow flag) and fits seven workgroups per CU (20.6 KiB, <= 72 VGPRs):
+//        with five (28.5 KiB) the 2032 merges of a round ran as 1.6 waves of workgroups, which is what an L2-resident early
+//        round's merge is bound by; a 64-VGPR form (eight per CU, rows gathered in two halves) measured slower (ABLATIONS R5.5)
+constexpr int kMergeF16 = 0, kMergeExactF32 = 1, kMergeNominatedI8 = 2;
 template <int MODE, int CAP, int T = kMergeThreads>
-__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE == 1 || MODE == 2 ? 4 : 8)))
+__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE == 1 ? 4 : (MODE == 2 ? 7 : 8))))
 void topk_merge(MergeArgs a) {
   constexpr bool EXACT = MODE == kMergeExactF32;   // nominated rows are re-scored from the float32 rows in double
-  constexpr bool NOM = MODE == kMergeNominatedI8 || MODE == kMergeNominatedI8Lean;  // ... from the fp16 rows on the fp16 filter's MFMA sequence
-  constexpr bool LEAN = MODE == kMergeNominatedI8Lean;
+  constexpr bool NOM = MODE == kMergeNominatedI8;  // ... from the fp16 rows on the fp16 filter's MFMA sequence
+  constexpr bool LEAN = NOM;                       // its lists live inside keys[]
   constexpr bool RESCORE = EXACT || NOM;
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
@@ -1569,45 +1569,6 @@ void topk_merge(MergeArgs a) {
     if (tid == 0) a.stat_nominated[q] += n_nom;
     const float tau_exact = a.tau[q];
     const int lane = tid & 63, w = tid >> 6, li = lane & 31, half = lane >> 5;
-    if constexpr (LEAN) {
-      // the query's fp16 row in LDS (its fragments are re-read per k-step: 32 VGPRs less), the rows gathered in two halves of
-      // four k-steps (16 VGPRs in flight instead of 32); passing keys go to the LOWER half of keys[] only -- the nominee list
-      // occupies the upper half -- and a round with more of them than that is re-scanned (overflow)
-      __shared__ __attribute__((aligned(16))) char s_q16[kRowBytes];
-      if (tid < kRowBytes / 16) ((uint4*)s_q16)[tid] = ((const uint4*)((const char*)a.xq16 + (size_t)q * kRowBytes))[tid];
-      __syncthreads();
-      for (unsigned c0 = (unsigned)w * 32; c0 < n_nom; c0 += (T / 64) * 32) {   // wave-uniform trip count
-        const unsigned mine = c0 + (unsigned)li < n_nom ? c0 + (unsigned)li : c0;
-        const unsigned row = ex.nom[mine];
-        const char* ap = a.xb16 + (size_t)row * kRowBytes;
-        f32x16 acc = {0};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          f16x8 af[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) af[j] = *(const f16x8*)(ap + (2 * (4 * h + j) + half) * 16);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f16x8 qv = *(const f16x8*)(s_q16 + (2 * (4 * h + j) + half) * 16);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qv, acc, 0, 0, 0);
-          }
-        }
-        if (li == 0) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) s_sc[w][(r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
-        }
-        const float score = s_sc[w][li];
-        const bool keep = half == 0 && c0 + (unsigned)li < n_nom && score > tau_exact;
-        wave_append(keep, pack_key(score, row), keys, &s_n_keys, (unsigned)CAP / 2);
-      }
-      __syncthreads();
-      if (s_n_keys > (unsigned)CAP / 2) {   // workgroup-uniform
-        if (tid == 0) {
-          *a.overflow = 1u;
-          s_n_keys = CAP / 2;
-        }
-      }
-    } else
     if (n_nom) {   // workgroup-uniform
       f16x8 qf[8];
       const char* qrow = (const char*)a.xq16 + (size_t)q * kRowBytes;
@@ -1630,10 +1591,19 @@ void topk_merge(MergeArgs a) {
         // (LDS operations of one wave execute in program order: the reads below see the writes of lanes 0 and 32)
         const float score = s_sc[w][li];
         const bool keep = half == 0 && c0 + (unsigned)li < n_nom && score > tau_exact;
-        wave_append(keep, pack_key(score, row), keys, &s_n_keys, (unsigned)CAP);
+        // (passing keys go to the LOWER half of keys[] only: the nominee list occupies the upper half)
+        wave_append(keep, pack_key(score, row), keys, &s_n_keys, (unsigned)CAP / 2);
       }
     }
     __syncthreads();
+    if (s_n_keys > (unsigned)CAP / 2) {   // workgroup-uniform: more passing rows than the lower half holds -- overflow-safe path
+      __syncthreads();
+      if (tid == 0) {
+        *a.overflow = 1u;
+        s_n_keys = CAP / 2;
+      }
+      __syncthreads();
+    }
     PROQA_STAMP(7);
   }
 
@@ -2490,10 +2460,7 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   const bool big = a.sort_cap > kMaxSortKeys;
   if (a.xb16) {   // records of the int8 nomination scan
     if (big || a.xq32 || a.compact || a.inclusive || a.bound_keys) return hipErrorInvalidValue;
-    if (a.lean)
-      hipLaunchKernelGGL((topk_merge<kMergeNominatedI8Lean, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
-    else
-      hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   } else if (a.xq32) {
     if (big)
       hipLaunchKernelGGL((topk_merge<kMergeExactF32, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
