@@ -13,6 +13,7 @@ DataParallel/DDP wrappers have no get_embed and cannot do this (SURVEY.md sectio
 """
 import json
 import os
+import sys
 import random
 
 import numpy as np
@@ -252,6 +253,17 @@ def main(argv=None):
     LAST_RUN_STATS.clear()
     embeds = predict(args, model, loader, device, fp16=args.efficient_eval, is_query_embed=is_query_embed, stats=LAST_RUN_STATS)
     LAST_RUN_STATS["loader_workers"] = workers
+    # which dense path the large layers ran on: the hipBLASLt kernel pinned by name, or rocblas_gemm_ex (the library falls
+    # back silently when the loaded hipBLASLt does not hold the pinned kernel: a ROCm point release can change that)
+    try:
+        kernel = model.gemm_kernels().get(bool(is_query_embed), "")
+        LAST_RUN_STATS["gemm_kernel"] = kernel or "rocblas_gemm_ex"
+        if rank == 0:
+            print("Dense layers: " + (f"hipBLASLt kernel {kernel}" if kernel else
+                                      "rocblas_gemm_ex (no pinned hipBLASLt kernel in the loaded library, or batches below 4096 token rows)"),
+                  file=sys.stderr)
+    except Exception:   # noqa: BLE001  (a log line must not fail the run)
+        pass
     del loader
     local = embeds.cpu().numpy()
     out_path = npy.save_path(args.embed_save_path)
