@@ -990,6 +990,21 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
     if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, shape.lane_cap))
       return rc == PROQA_ENOMEM ? PROQA_OK : rc;   // no room for the deep lists beside the caller's tensors: page by page
   }
+  // The compact lists of the dense launch hold 64 keys each and are sized for hits spread evenly over the shard.  A corpus
+  // ordered by document puts a query's hits into a few chunks: a list wraps, the launch is void.  Before going page by page
+  // (several times slower) the launch is repeated ONCE over four times the chunks -- against the thresholds the first
+  // attempt's merge left, which are still lower bounds of the k-th best scores and usually tighter.
+  auto big_launch_with_retry = [&](int sample_rounds) -> int {
+    int rc = one_pass_big_launch(idx, pl, shape, qw, n_qtiles, nq, nq_pad, k, out, st, sample_rounds, done);
+    if (rc || *done || !shape.compact || !idx->mirror->overflow[1]) return rc;
+    RoundShape wide = shape;
+    wide.want_chunks = round_up<unsigned>((unsigned)std::min<long long>(4ll * shape.want_chunks, idx->n / kStageRows), 8);
+    if (wide.want_chunks <= shape.want_chunks) return rc;
+    const LaunchGeom g = geometry(idx->n, n_qtiles, false, k, wide.want_chunks);
+    if (ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, wide.lane_cap) != PROQA_OK) return PROQA_OK;   // no room: pages
+    PROQA_HIP(hipMemsetAsync(idx->overflow + 1, 0, 2 * sizeof(unsigned), st));
+    return one_pass_big_launch(idx, pl, wide, qw, n_qtiles, nq, nq_pad, k, out, st, sample_rounds, done);
+  };
   // (1) thresholds from the sample (the round words were zeroed by prep_queries).  Overflow in here is harmless: it loosens the estimate.
   const int r = pl.r;
   // A rank beyond the bootstrap's (r = 512, 1024: thousands of queries with k in the thousands) would need ~7 rounds of
@@ -1049,7 +1064,7 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
         fprintf(stderr, "two-step sample: bootstrap rank %d of %lld rows, then rows [%lld, %lld) for rank %d: %.0f candidates per query "
                 "(expected %.0f)\n", r1, boot_rows, r0, r0 + m, r, (double)tot / (double)nq, c);
       }
-      return one_pass_big_launch(idx, pl, shape, qw, n_qtiles, nq, nq_pad, k, out, st, 2, done);
+      return big_launch_with_retry(2);
     }
   }
   long long boot = 0;
@@ -1099,7 +1114,7 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
               slabs[i].r0, slabs[i].r1, r, c, (double)c / (double)nq, ov);
     }
   }
-  return one_pass_big_launch(idx, pl, shape, qw, n_qtiles, nq, nq_pad, k, out, st, (int)slabs.size(), done);
+  return big_launch_with_retry((int)slabs.size());
 }
 
 // after the host sync of a search whose rounds ran on the int8 copy: statistics, and the profitability check -- a corpus

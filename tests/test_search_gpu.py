@@ -840,6 +840,29 @@ def test_begin_finish_equals_the_one_call_search(gpu_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("block_rows,one_pass_holds", [(100000, True), (10000, False)])
+def test_large_k_on_a_corpus_ordered_by_document(gpu_device, block_rows, one_pass_holds):
+    """Real corpora are ordered by document: a query's top-k rows sit in a few contiguous stretches, not spread evenly over the
+    shard as the compact 64-key lists of the dense one-pass launch assume.  Mild clustering (the hits within 100 k
+    consecutive rows) is absorbed by ONE repetition of the launch over four times the chunks -- no paging; strong clustering
+    (10 k rows) goes page by page.  Exact either way."""
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(block_rows)
+    n, nq, k = 400000, 300, 1500
+    n_blocks = n // block_rows
+    topics = rng.integers(-2, 3, (n_blocks, 128)).astype(np.float32)
+    xb = (np.repeat(topics, block_rows, axis=0) + rng.integers(-1, 2, (n, 128))).astype(np.float16)
+    xq = (topics[rng.integers(0, n_blocks, nq)] + rng.integers(-1, 2, (nq, 128))).astype(np.float16)
+    index = IndexFlatIP(128)
+    index.add(xb)
+    D, I = index.search(xq, k)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(I, Io)
+    np.testing.assert_array_equal(D, Do)
+    assert (index.last_stats()["fallback_rounds"] == 0) == one_pass_holds
+
+
+@pytest.mark.gpu
 def test_one_pass_store_that_cannot_be_allocated_falls_back_to_pages(gpu_device, monkeypatch):
     """The deep candidate store of the one-pass large-k search does not fit beside the caller's tensors (forced here: a
     hipMalloc that really fails, leaving HIP's sticky error behind): the search must fall back to the paged path and
