@@ -444,8 +444,12 @@ const double kBudget = getenv("PROQA_CAND_BUDGET") ? atof(getenv("PROQA_CAND_BUD
 // Default growth: 4 for MFMA-bound batches (fewer candidates per round keep the rare path rare); 8 for
 // the HBM-bound small batches (one query tile per wave: two rounds fewer of launch + merge latency,
 // measured 6-9 % on the whole search at Q <= 256, 3 % slower at Q >= 1024).
-double growth_for(int k, int configured, int qw) {
-  const int g = configured > 0 ? configured : (qw == 1 ? 8 : 4);
+// Rounds on the int8 copy: 2.  A nominated row costs a 256-byte gather and a share of an MFMA in the merge, and the scan
+// nominates ~1.9 x the rows that pass, so the time of a search follows the nominations more steeply than an fp16 search
+// follows its candidates; two or three more rounds (each ~35 us of launch + merge latency) are cheaper than the rows
+// they save (scripts/dev_schedule_sweep.py, 1 .. 2032 queries x 2.25M .. 18M rows: ABLATIONS R5.8).
+double growth_for(int k, int configured, int qw, bool nominating = false) {
+  const int g = configured > 0 ? configured : nominating ? 2 : (qw == 1 ? 8 : 4);
   // big pages: 60 % of the free keys of the big merge (the rest is headroom for the spread of the candidate count)
   const double budget = k <= kPageK ? kBudget : 0.6 * (kBigSortKeys - k);
   return std::min<double>(g, budget / k);
@@ -758,19 +762,21 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
     // grow by a smaller factor each, i.e. log fewer candidates (a 2.25M-row shard: 4 rounds either way, 1076 instead of
     // 1324 candidates per query, -40 us; where it would save a round instead -- 4.5M, 18M rows -- the larger bootstrap
     // costs what the round did)
+    // (nominating rounds: always -- the rows of the larger bootstrap are rows no round nominates from)
     if (idx->bootstrap_auto && kEqualGrowth && boot * 2 <= kBootstrapMaxRows && idx->n >= 8 * boot) {
-      const double cap = std::log(1.0 + growth_for(page_k, idx->growth, gqw));
+      const double cap = std::log(1.0 + growth_for(page_k, idx->growth, gqw, idx->q8_active));
       const int r1 = (int)std::ceil(std::log((double)idx->n / (double)boot) / cap - 1e-9);
       const int r2 = (int)std::ceil(std::log((double)idx->n / (double)(2 * boot)) / cap - 1e-9);
-      if (r1 == r2) boot *= 2;
+      if (r1 == r2 || idx->q8_active) boot *= 2;
     }
   }
   // every row of the first slab is a candidate (threshold -inf): it must fit one merge pass
   // (big pages: as many rows as the merge holds -- their growth per round is small, so the rounds should start high)
   const int first_cap = (sort_capacity(page_k) - page_k) / kStageRows * kStageRows;
   const int first = page_k > kPageK ? first_cap : std::min<int>(idx->first_slab_rows, first_cap);
-  plan->slabs = boot && kEqualGrowth && kGrowthList.empty() ? plan_slabs_equal(idx->n, boot, growth_for(page_k, idx->growth, gqw))
-                                                          : plan_slabs(idx->n, first, growth_for(page_k, idx->growth, gqw), boot);
+  const double page_growth = growth_for(page_k, idx->growth, gqw, idx->q8_active);
+  plan->slabs = boot && kEqualGrowth && kGrowthList.empty() ? plan_slabs_equal(idx->n, boot, page_growth)
+                                                          : plan_slabs(idx->n, first, page_growth, boot);
   plan->boot = boot;
   const std::vector<Slab>& slabs = plan->slabs;
   if ((int)slabs.size() + 2 > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
