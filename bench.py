@@ -808,11 +808,28 @@ def online_leg(args, device, index, n_rows):
     from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE
     model = BertForRetriever(BERT_BASE, device=device)
     model.load_state_dict(random_state_dict(BERT_BASE, seed=0))
+    from proqa_amd.online_retriever import GraphedQuestionEncoder
     r = OnlineRetriever(np.float16, None, device=device, index=index)
+    graphed = GraphedQuestionEncoder(model)
+    host_rng = np.random.default_rng(5)
     g = torch.Generator(device=device).manual_seed(5)
     mask = torch.ones((1, 16), dtype=torch.bool, device=device)
     out = {"metric": "ms per question: encode + exact top-k + row gather (online sampler step)", "unit": "ms",
            "rows": n_rows, "question_tokens": 16, "questions": 50}
+    # the captured HIP graph of the forward (GraphedQuestionEncoder: one launch call instead of ~90) beside the plain call
+    # the leg times: the same bits, and -- measured -- the same time: the forward is bound by the GPU's dispatch of ~90
+    # dependent microsecond kernels, not by the host's launch calls (ABLATIONS R5.9)
+    replay = []
+    for i in range(55):
+        tok = host_rng.integers(1000, 30522, 16).tolist()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        q = graphed(tok)
+        torch.cuda.synchronize()
+        replay.append(time.perf_counter() - t0)
+    out["encode_ms_graph_replay"] = float(np.median(replay[5:]) * 1e3)
+    t = torch.tensor([tok], dtype=torch.int64, device=device)
+    out["graph_equals_plain"] = bool(torch.equal(q, model.get_embed({"input_ids": t, "input_mask": mask}, True)["embed"]))
     for k in (80, 5000):
         enc, ret = [], []
         for i in range(55):

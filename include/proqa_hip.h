@@ -225,6 +225,11 @@ int proqa_encoder_set_gemm_tuning(proqa_encoder* enc, int enable);
  * rocblas_gemm_ex.  name_out receives the pinned kernel's name ("" = rocblas_gemm_ex: no name matched, or no large product
  * has run yet on this handle), truncated to name_len - 1 characters. */
 int proqa_encoder_gemm_kernel(const proqa_encoder* enc, char* name_out, size_t name_len);
+/* The activation workspace of the handle: base address and size (0 / 0 before the first forward).  A forward over more
+ * tokens or sequences than any before it REPLACES the workspace; a caller that captured forwards of this handle into a HIP
+ * graph (proqa_amd.online_retriever.GraphedQuestionEncoder) compares the base address before a replay and re-captures when
+ * it has changed.  forward itself is capturable once the workspace fits: no allocation, no host synchronisation. */
+int proqa_encoder_workspace(const proqa_encoder* enc, void** base_out, size_t* bytes_out);
 /* The library dense layer of this handle on its own (tests): out[m, n] = x[m, k] . w[n, k]^T, fp16 row-major device
  * pointers, fp32 accumulate -- the pinned hipBLASLt kernel where it applies, else rocblas_gemm_ex (small_dense_mfma for
  * <= 256 rows).  Asynchronous on `stream`. */

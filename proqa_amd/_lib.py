@@ -98,6 +98,7 @@ SIGNATURES = {
     "proqa_encoder_free": (c_int, [c_void_p]),
     "proqa_encoder_set_gemm_tuning": (c_int, [c_void_p, c_int]),
     "proqa_encoder_gemm_kernel": (c_int, [c_void_p, c_char_p, c_size_t]),
+    "proqa_encoder_workspace": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t)]),
     "proqa_encoder_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "proqa_encoder_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_int,
                                       c_void_p]),

@@ -258,6 +258,13 @@ int proqa_encoder_gemm_kernel(const proqa_encoder* e, char* name_out, size_t nam
   return PROQA_OK;
 }
 
+int proqa_encoder_workspace(const proqa_encoder* e, void** base_out, size_t* bytes_out) {
+  if (!e || !base_out || !bytes_out) return fail(PROQA_EINVAL, "encoder_workspace: NULL argument");
+  *base_out = e->ws.base;
+  *bytes_out = e->ws.bytes;
+  return PROQA_OK;
+}
+
 int proqa_encoder_dense(proqa_encoder* e, const void* x, const void* w, void* out, int64_t m, int n, int k, void* stream) {
   if (!e || !x || !w || !out || m < 0 || n <= 0 || k <= 0) return fail(PROQA_EINVAL, "encoder_dense: bad argument");
   PROQA_ON_DEVICE(e->device);

@@ -185,6 +185,14 @@ class BertForRetriever:
             out[key] = buf.value.decode()
         return out
 
+    def workspace(self, is_query_embed):
+        """(base address, bytes) of a tower's activation workspace (proqa_encoder_workspace): changes when a larger batch
+        replaces it -- what a captured HIP graph of the forward has to watch."""
+        import ctypes
+        base, size = ctypes.c_void_p(), ctypes.c_size_t()
+        _lib.check(self._lib.proqa_encoder_workspace(self.towers[bool(is_query_embed)]._handle, ctypes.byref(base), ctypes.byref(size)))
+        return (base.value or 0, size.value)
+
     def to(self, device):
         device = torch.device(device)
         if device.type != "cuda":

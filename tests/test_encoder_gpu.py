@@ -435,6 +435,39 @@ def test_question_sized_batches_against_oracle(gpu_device, lens):
                 assert cosine(got, ref).min() > COS_MIN
 
 
+def test_graphed_question_encoder_replays_the_plain_forward(gpu_device):
+    """GraphedQuestionEncoder (online_retriever.py): one captured HIP graph per question length.  The replay is the plain
+    call bit for bit -- for a second question of the same length, for other lengths, and after a larger batch through the
+    same tower has replaced the encoder's workspace (the graphs are then captured again, not replayed onto freed memory)."""
+    from proqa_amd.online_retriever import GraphedQuestionEncoder
+    from proqa_amd.retriever import BertForRetriever, random_state_dict, BERT_BASE, config_from_dict
+    cfg = config_from_dict(dict(BERT_BASE, num_hidden_layers=3))
+    model = BertForRetriever(cfg, device=gpu_device)
+    model.load_state_dict(random_state_dict(cfg, seed=4))
+    rng = np.random.default_rng(0)
+
+    def plain(ids):
+        t = torch.tensor([ids], dtype=torch.int64, device=gpu_device)
+        return model.get_embed({"input_ids": t, "input_mask": torch.ones_like(t, dtype=torch.bool)}, True)["embed"].cpu().numpy()
+
+    enc = GraphedQuestionEncoder(model)
+    questions = [rng.integers(1000, 30522, n).tolist() for n in (16, 16, 7, 30, 16, 1, 7)]
+    for ids in questions:
+        got = enc(ids)
+        assert got.shape == (1, 128)
+        np.testing.assert_array_equal(got.cpu().numpy(), plain(ids))
+    assert enc.captures == 4                                         # lengths 16, 7, 30, 1: captured once each
+    big = torch.from_numpy(rng.integers(1000, 30522, (64, 128))).to(gpu_device)
+    model.get_embed({"input_ids": big, "input_mask": torch.ones_like(big, dtype=torch.bool)}, True)   # replaces the workspace
+    for ids in questions[:3]:
+        np.testing.assert_array_equal(enc(ids).cpu().numpy(), plain(ids))
+    assert enc.captures == 6                                         # 16 and 7 again
+    # results of earlier calls are tensors of their own, not views of the graph's output
+    a = enc(questions[0])
+    b = enc(questions[1])
+    assert not torch.equal(a, b)
+
+
 def test_rejects_bad_inputs(gpu_device):
     from proqa_amd.retriever import BertForRetriever
     z, sd, cfg = load_golden()
