@@ -145,7 +145,7 @@ struct FilterArgsI8 {
   const NominateParams* qp; // [nq_pad]
   const float2* blk;        // per 32-row block of the shard: {G_b = 127 / f_b, X_b = max ||xi|| of its rows}; readable for 8
                             // blocks past the shard's last one (the scan fetches whole pairs of stages)
-  CandidateStore store;     // column records whose scores / threshold words are int32
+  CandidateStore store;     // lane lists of 8-byte records {first row of the column, 16 nominee bits} in the column records' slots
   unsigned* overflow;
   unsigned flags;           // developer cut experiments (PROQA_FILTER_FLAGS; wrong results), 0 in production
 };

@@ -543,12 +543,35 @@ __device__ __forceinline__ float block_threshold(const LaneThreshold& t, float G
 }
 
 // (the threshold word of such a record is the FLOAT per-block threshold the int32 scores were tested against)
-__device__ __forceinline__ void write_record_i32(WaveRecord* dst, const i32x16& acc, unsigned q, unsigned row0, int rows_left, float thr) {
-  uint4* d = (uint4*)dst;
-  d[0] = make_uint4(q, row0, (unsigned)rows_left, __float_as_uint(thr));
+// The record of the int8 scan: {first row of the lane's column, bit i set <=> accumulator i -- row (i & 3) + 8 (i >> 2) of the
+// column -- exceeds the block's threshold and lies inside the slab}.  The merge re-scores the rows from fp16 data, so the
+// integer scores themselves are not kept: 8 bytes and one store instead of 80 and five.  (float)acc > thr <=> acc >
+// floor(thr) for integers (|acc| < 2^24 converts exactly); thr is finite and below 2^21 on this path (the column maximum
+// exceeded it) or -inf.
+__device__ __forceinline__ unsigned nominee_mask(const i32x16& acc, float thr, int rows_left) {
+  const int ti = thr < -2147483000.f ? (int)0x80000000 : (int)__builtin_floorf(thr);
+  // mask = 2 mask + (acc[i] > ti), i = 15 .. 0: a compare into VCC and an add-with-carry per accumulator, no temporaries
+  // (the plain C++ form costs ten more registers than the kernel's 128 allow).  The accumulators were read by the
+  // column maximum before this point: no MFMA result is in flight.
+  unsigned mask = 0u;
+#define PROQA_BIT(n) "v_cmp_gt_i32 vcc, %" #n ", %17\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+  asm volatile(PROQA_BIT(16) PROQA_BIT(15) PROQA_BIT(14) PROQA_BIT(13) PROQA_BIT(12) PROQA_BIT(11) PROQA_BIT(10) PROQA_BIT(9)
+               PROQA_BIT(8) PROQA_BIT(7) PROQA_BIT(6) PROQA_BIT(5) PROQA_BIT(4) PROQA_BIT(3) PROQA_BIT(2) PROQA_BIT(1)
+               : "+v"(mask)
+               : "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]), "v"(acc[6]), "v"(acc[7]), "v"(acc[8]),
+                 "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]), "v"(ti)
+               : "vcc");
+#undef PROQA_BIT
+  if (rows_left < 28) {   // the slab ends inside this column (the last unit of the last chunk)
+    unsigned valid = 0u;
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
-    d[1 + g] = make_uint4((unsigned)acc[4 * g], (unsigned)acc[4 * g + 1], (unsigned)acc[4 * g + 2], (unsigned)acc[4 * g + 3]);
+    for (int g = 0; g < 4; ++g) {
+      const int c = rows_left - 8 * g;
+      valid |= (c >= 4 ? 0xFu : (c > 0 ? (1u << c) - 1u : 0u)) << (4 * g);
+    }
+    mask &= valid;
+  }
+  return mask;
 }
 
 // Same tiling as mips_filter_f16 -- 8 waves, wave w keeps its QW x 32 queries as MFMA B fragments for its lifetime, the
@@ -568,9 +591,10 @@ __device__ __forceinline__ void write_record_i32(WaveRecord* dst, const i32x16& 
 //     16-byte bank slots each (MI355X_MICROARCH.md, LDS table);
 //   * the MFMA k-order is permuted identically on both operands (piece 2j + half at k-step j); integer sums do not depend on it;
 //   * the block constants (G_b, X_b) of a unit are wave-uniform: scalar loads, two fused multiply-adds per unit and query block.
-// A lane whose column maximum exceeds its threshold logs the 16 int32 scores as one 80-byte record (the format of the fp16
-// scan; threshold word = the float threshold of the block); a full list is reported through `overflow` (the round is then
-// re-scanned by the fp16 overflow-safe path): no spill log, no capacity branch in the hit path.
+// A lane whose column maximum exceeds its threshold logs ONE 8-byte record {first row of its column, 16 nominee bits}
+// (nominee_mask: the merge re-scores the rows from fp16 data, the integer scores are not kept; the 80-byte column of the
+// fp16 scan would be five stores and ten times the write traffic); a full list is reported through `overflow` (the round is
+// then re-scanned by the fp16 overflow-safe path): no spill log, no capacity branch in the hit path.
 template <int QW>
 __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8 a) {
   static_assert(QW == 1 || QW == 2, "8 waves x 32 / 64 queries");
@@ -601,7 +625,7 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
   const unsigned q0 = qt * (NW * QW * 32) + wave * (QW * 32);
   i32x4 qf[QW][4];
   LaneThreshold thr[QW];
-  WaveRecord* lane_list[QW];
+  uint2* lane_list[QW];
   unsigned lane_n[QW];
   bool wave_live = false;
 #pragma unroll
@@ -613,7 +637,7 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     thr[blk] = lane_threshold(a.tau[q], a.qp[q]);
     wave_live = wave_live || thr[blk].A != __builtin_inff();
     lane_n[blk] = 0u;
-    lane_list[blk] = a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
+    lane_list[blk] = (uint2*)a.store.lane_log + lane_list_index(a.store, chunk, q, half) * a.store.lane_cap;
   }
   wave_live = __any(wave_live);
   const unsigned lane_cap = a.store.lane_cap;
@@ -651,18 +675,18 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
   int st_cur = 0;   // record-store instructions of this wave since the last barrier: all younger than the awaited DMA pieces
   auto publish = [&]() {
     const int allowed = __builtin_amdgcn_readfirstlane(st_cur);
-    if (allowed >= 40) {
-      asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-    } else if (allowed >= 30) {
-      asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-    } else if (allowed >= 20) {
-      asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    } else if (allowed >= 15) {
-      asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-    } else if (allowed >= 10) {
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    } else if (allowed >= 5) {
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (allowed >= 8) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (allowed >= 6) {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else if (allowed >= 4) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (allowed >= 3) {
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else if (allowed >= 2) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else if (allowed >= 1) {
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -740,11 +764,11 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
         const int rel = rel0 + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < QW; ++blk) {
-          if (__any(hit[blk])) {   // (wave-uniform: exactly the regions whose five stores are issued are counted)
-            st_cur += 5;
+          if (__any(hit[blk])) {   // (wave-uniform: exactly the regions whose store is issued are counted)
+            st_cur += 1;
             if (hit[blk]) {
               const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
-              write_record_i32(lane_list[blk] + slot, acc[blk], q0 + blk * 32 + li, row_begin32 + (unsigned)rel, n_rows - rel, tb[blk]);
+              lane_list[blk][slot] = make_uint2(row_begin32 + (unsigned)rel, nominee_mask(acc[blk], tb[blk], n_rows - rel));
               ++lane_n[blk];
             }
           }
@@ -1203,6 +1227,19 @@ __device__ __forceinline__ void load_and_sort(unsigned long long (&v)[NK], unsig
   sort_keys_desc<NK, T>(v, keys, tid);
 }
 
+// a record of the int8 scan (mips_filter_i8: {first row of the column, nominee bits}) -> the rows to re-score
+__device__ __forceinline__ void keep_nominees(uint2 rec, const ExactCtx& ex, unsigned cap) {
+  unsigned m = rec.y & 0xFFFFu;
+  if (!m) return;
+  unsigned pos = atomicAdd(ex.n_nom, (unsigned)__builtin_popcount(m));   // LDS
+  while (m) {
+    const unsigned b = (unsigned)__builtin_ctz(m);
+    m &= m - 1u;
+    if (pos < cap) ex.nom[pos] = rec.x + (b & 3u) + 8u * (b >> 2);
+    ++pos;
+  }
+}
+
 #ifdef PROQA_MERGE_STAMPS
 #define PROQA_STAMP(i) do { if (a.dbg && threadIdx.x == 0) a.dbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1367,13 +1404,15 @@ void topk_merge(MergeArgs a) {
         for (unsigned s = 0; s < cnt[e]; ++s) {
           if (pos + s < kWorkCap)
             s_work[pos + s] = (unsigned short)((t << kSlotBits) | s);
+          else if constexpr (NOM)
+            keep_nominees(((const uint2*)st.lane_log)[li[e] * lane_cap + s], ex, CAP);
           else
-            keep_scores<NOM>(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+            keep_scores<false>(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
         }
       }
     }
     // spill logs of q's wave slot (usually all empty): a wave walks the non-empty chunks its lanes found
-    {
+    if constexpr (!NOM) {
       const int lane = tid & 63;
       unsigned long long live = __ballot(n_spill != 0);
       while (live) {
@@ -1382,7 +1421,7 @@ void topk_merge(MergeArgs a) {
         const unsigned n_s = (unsigned)__shfl((int)n_spill, src, 64);
         const size_t slot_s = spill_slot0 + (size_t)((tid & ~63) + src) * spill_stride;
         for (unsigned i = lane; i < n_s; i += 64)
-          keep_scores<NOM>(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+          keep_scores<false>(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
       }
     }
     __syncthreads();
@@ -1405,8 +1444,15 @@ void topk_merge(MergeArgs a) {
         for (int g = 0; g < 5; ++g) b0[g] = r0[g];
 #pragma unroll
         for (int g = 0; g < 5; ++g) b1[g] = r1[g];
-        keep_scores_regs<NOM>(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
-        if (two) keep_scores_regs<NOM>(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+        keep_scores_regs<false>(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+        if (two) keep_scores_regs<false>(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+      }
+    } else if constexpr (NOM) {
+      // int8 rounds: 8-byte records, one per thread and trip (a round's ~260 records of a query: one or two trips)
+      for (unsigned w = tid; w < n_work; w += T) {
+        const unsigned item = s_work[w];
+        const unsigned l = base + (item >> kSlotBits);
+        keep_nominees(((const uint2*)st.lane_log)[lane_list_index(st, l >> 1, q, (int)(l & 1)) * lane_cap + (item & kSlotMask)], ex, CAP);
       }
     } else
     // FIVE lanes per record, one 16-byte piece each (12 records per wave and load instruction, two instructions in
