@@ -928,7 +928,7 @@ def main():
         t16 = flops / (st16["filter_ms"] / 1e3) / 1e12
         fp16_scan = {"value": nq * n16 / dt16, "unit": "queries/s", "ms_per_step": dt16 / n16 * 1e3, "filter_ms_per_search": st16["filter_ms"],
                      "achieved": t16, "frac": t16 / PEAK_MFMA_F16_TFLOPS, "kernel": "mips_filter_f16",
-                     "candidates_per_query": st16["candidates"] / max(nq, 1),
+                     "candidates_per_query": st16["candidates"] / max(nq, 1), "rounds": st16["rounds"],
                      "ids_equal": digest(result["DI"][1]) == ids_sha, "scores_equal": digest(result["DI"][0]) == scores_sha}
         step()   # (leave the nominated result in place for the legs below)
 

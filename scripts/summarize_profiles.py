@@ -73,13 +73,15 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_grbm"):
         d.setdefault("duration_ns_" + sub, dur[n])
         d.update(per[n])
 
-def derive(f):
-    """per-search figures of one filter kernel from its counter sums"""
+def derive(f, fp16_beside=False):
+    """per-search figures of one filter kernel from its counter sums (fp16_beside: the fp16 scan the bench times beside the
+    nomination scan -- its rounds per search are in the line's fp16_scan object, 6 where the int8 rounds are 8)"""
     derived = {}
     searches = None
     if "launches_pmc_fetch" in f:
         # full-size searches in the pass = launches of the QW=2 instantiation / rounds per search (bench line)
-        rounds = bench_line("pmc_fetch.log").get("config", {}).get("rounds", 8)
+        line = bench_line("pmc_fetch.log")
+        rounds = line.get("fp16_scan", {}).get("rounds", 6) if fp16_beside else line.get("config", {}).get("rounds", 8)
         searches = f["launches_pmc_fetch"] / rounds
         derived["rounds_per_search"] = rounds
         derived["searches_profiled"] = searches
@@ -112,7 +114,7 @@ nominated = "mips_filter_i8" in summary
 derived = derive(summary.get("mips_filter_i8" if nominated else "mips_filter_f16", {}))
 derived["kernel"] = "mips_filter_i8" if nominated else "mips_filter_f16"
 if nominated and "mips_filter_f16" in summary:
-    summary["derived_mips_filter_f16"] = derive(summary["mips_filter_f16"])
+    summary["derived_mips_filter_f16"] = derive(summary["mips_filter_f16"], fp16_beside=True)
 g = summary.get("mips_filter_i8_qw1" if nominated else "mips_filter_f16_qw1", {})
 if "FETCH_SIZE" in g:
     # bench.py's scan_small_batch leg: 6 searches of 32 queries (3 plain + 3 with HIP-event brackets) per scan
