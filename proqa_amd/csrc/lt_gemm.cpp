@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <hipblaslt/hipblaslt.h>
 #include <hipblaslt/hipblaslt-ext.hpp>
+#include <hipblaslt/hipblaslt-version.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -65,6 +66,7 @@ using Algo = hipblasLtMatmulAlgo_t;
 struct Api {
   hipblasStatus_t (*create)(Handle*) = nullptr;
   hipblasStatus_t (*destroy)(const Handle) = nullptr;
+  hipblasStatus_t (*get_version)(Handle, int*) = nullptr;
   hipblasStatus_t (*desc_create)(Desc*, hipblasComputeType_t, hipDataType) = nullptr;
   hipblasStatus_t (*desc_set)(Desc, hipblasLtMatmulDescAttributes_t, const void*, size_t) = nullptr;
   hipblasStatus_t (*desc_destroy)(const Desc) = nullptr;
@@ -90,6 +92,7 @@ const Api& api() {
 #define PROQA_LT_SYM(field, name) *(void**)&r.field = sym(name)
     PROQA_LT_SYM(create, "hipblasLtCreate");
     PROQA_LT_SYM(destroy, "hipblasLtDestroy");
+    PROQA_LT_SYM(get_version, "hipblasLtGetVersion");
     PROQA_LT_SYM(desc_create, "hipblasLtMatmulDescCreate");
     PROQA_LT_SYM(desc_set, "hipblasLtMatmulDescSetAttribute");
     PROQA_LT_SYM(desc_destroy, "hipblasLtMatmulDescDestroy");
@@ -218,6 +221,26 @@ LtGemm* lt_gemm_create() {
       a.desc_set(g->desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof tb) != HIPBLAS_STATUS_SUCCESS) {
     lt_gemm_destroy(g);
     return nullptr;
+  }
+  // The extension functions are C++ entry points bound by mangled name against the struct layouts of THIS build's headers
+  // (hipblaslt-version.h).  The library in the process may be another build (PyTorch ships its own): another major version
+  // is refused outright (rocblas_gemm_ex runs the layers), another minor / patch is reported once -- the pinned kernel is
+  // validated against rocBLAS on the real shapes by tests/test_encoder_gpu.py either way.
+  int v = 0;
+  const bool have_v = a.get_version && a.get_version(g->handle, &v) == HIPBLAS_STATUS_SUCCESS;
+  const int major = v / 100000, minor = v / 100 % 1000, patch = v % 100;
+  if (have_v && major != HIPBLASLT_VERSION_MAJOR) {
+    fprintf(stderr, "[proqa lt_gemm] hipBLASLt %d.%d.%d in the process, headers %d.%d.%d: extension API not used, dense layers on rocblas_gemm_ex\n",
+            major, minor, patch, HIPBLASLT_VERSION_MAJOR, HIPBLASLT_VERSION_MINOR, HIPBLASLT_VERSION_PATCH);
+    lt_gemm_destroy(g);
+    return nullptr;
+  }
+  if (getenv("PROQA_LT_DEBUG") || (have_v && minor != HIPBLASLT_VERSION_MINOR)) {
+    static bool said = false;
+    if (!said)
+      fprintf(stderr, "[proqa lt_gemm] hipBLASLt %d.%d.%d in the process (headers %d.%d.%d)\n", major, minor, patch, HIPBLASLT_VERSION_MAJOR,
+              HIPBLASLT_VERSION_MINOR, HIPBLASLT_VERSION_PATCH);
+    said = true;
   }
   return g;
 }
