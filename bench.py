@@ -961,7 +961,10 @@ def main():
     line = {
         "metric": "queries/sec top-80 MIPS over 18M x 128 index", "value": qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        # what the timed path computes in: the f16 scan (fp32 accumulate), or int8 MFMA rounds that nominate + the same f16
+        # arithmetic on the nominated rows (the result is the f16 scan's, bit for bit: fp16_scan.ids_equal / scores_equal)
+        "dtype": "int8 nomination + f16 re-scoring" if nominated else "f16",
         "data": "synthetic",
         "config": {"workload": f"top-{k} MIPS, {nq} q x {n} x 128 fp16 rows in HBM (BASELINE configs[2]; x{world} row shards: configs[3])",
                    "rows": n, "queries": nq, "topk": k, "parallelism": f"corpus-row-shard x{world}",
