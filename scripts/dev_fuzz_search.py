@@ -54,10 +54,13 @@ while time.time() < t_end:
     oracle = search_oracle.topk_ip_exact if exact else search_oracle.topk_ip
     Do, Io = oracle(xq, xb, k)
     tq = torch.from_numpy(xq).to(dev)
+    always_nominate = bool(rng.random() < 0.5)
     bounds = np.linspace(0, n, shards + 1).astype(int)
     parts = []
     for lo, hi in zip(bounds[:-1], bounds[1:]):
         ix = IndexFlatIP(128)
+        if always_nominate:
+            ix.configure_nomination("always")       # the int8 nomination rounds on every shard of >= 512 rows (k <= 128)
         if hi > lo:
             if rng.random() < 0.5:
                 ix.add(xb[lo:hi])
