@@ -17,6 +17,7 @@
 // exactly the keys a lane's P registers hold (rows {0-3, 8-11} + 4*half + 16*step of the tile).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "attention.h"
 #include "common.h"
@@ -212,6 +213,172 @@ __global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict_
   }
 }
 
+// Sequences of more than 128 tokens (the reference's default --max_seq_length is 512, retrieval/config.py:25): the
+// all-keys-in-LDS form above needs 157 KB at S = 512 -- ONE workgroup per CU, one wave per SIMD, nothing to overlap the
+// staging, the softmax arithmetic and the MFMAs with (194 us per layer at 64 x 512 x 12 heads, a quarter of the encode
+// step).  Here a workgroup owns 128 QUERIES of one (sequence, head) -- one 32-query block per wave -- and streams the keys
+// through LDS in chunks of 128 (K rows + V^T: 35 KB, four workgroups per CU); the online softmax state lives in registers
+// across chunks, exactly as across the key tiles above.  The workgroups of one (sequence, head) re-read its K / V (128 KB at
+// S = 512) from the L2 of ONE XCD: blockIdx -> (XCD, pair, query chunk) keeps them on the same XCD, adjacent in dispatch
+// order.  Same arithmetic, same operand roles and tile order as attention_fwd: the numbers are the same.
+constexpr int kLongChunk = 128;
+constexpr float kExpScale = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(head_dim)
+__global__ __launch_bounds__(256, 4) void attention_long_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
+                                                          const int* __restrict__ seq_lens, const int* __restrict__ cu_seqlens,
+                                                          int seq_len, int n_heads, int n_pairs, int n_qc,
+                                                          _Float16* __restrict__ ctx) {
+  constexpr int vt_stride = kLongChunk + kVtPad;
+  __shared__ __attribute__((aligned(16))) _Float16 smem[kLongChunk * kKStride + kHeadDim * vt_stride];
+  _Float16* k_lds = smem;                             // [128][kKStride]
+  _Float16* vt_lds = smem + kLongChunk * kKStride;    // [kHeadDim][128 + kVtPad]  (V transposed)
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const int qc = (int)(slot % (unsigned)n_qc);
+  const int pair = (int)(slot / (unsigned)n_qc) * 8 + (int)xcd;
+  if (pair >= n_pairs) return;
+  const int b = pair / n_heads;
+  const int head = pair - b * n_heads;
+  const int hidden = n_heads * kHeadDim;
+  const long long row_stride = 3ll * hidden;
+  const long long tok0 = cu_seqlens ? cu_seqlens[b] : (long long)b * seq_len;
+  const _Float16* base = qkv + tok0 * row_stride + head * kHeadDim;
+  int len = cu_seqlens ? cu_seqlens[b + 1] - cu_seqlens[b] : (seq_lens ? seq_lens[b] : seq_len);
+  len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
+  const int rows_avail = cu_seqlens ? len : seq_len;   // token rows of this sequence that exist in memory
+  if (qc * kLongChunk >= rows_avail) return;           // (the whole workgroup: no barrier has been met)
+  const int n_ktiles = (len + 31) >> 5;
+  const int n_kchunks = (n_ktiles + 3) >> 2;
+  const _Float16* bias_q = qkv_bias ? qkv_bias + head * kHeadDim : nullptr;
+  const _Float16* bias_v = qkv_bias ? qkv_bias + 2 * hidden + head * kHeadDim : nullptr;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int half = lane >> 5;
+  const int qb = qc * 4 + wave;
+  const bool active = qb * 32 < rows_avail;            // wave-uniform: a wave without queries still stages and meets barriers
+  const int q = qb * 32 + li;
+  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  f16x8 qf[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    qf[j] = active && q < rows_avail ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) : zero8;
+    if (bias_q) qf[j] = qf[j] + *(const f16x8*)(bias_q + (2 * j + half) * 8);   // (key bias dropped, value bias on the output: see above)
+  }
+  float m = -__builtin_inff();
+  float l = 0.f;
+  f32x16 o0 = {0}, o1 = {0};
+
+  for (int kc = 0; kc < n_kchunks; ++kc) {
+    if (kc) __syncthreads();                           // every wave is done with the previous chunk
+#pragma unroll
+    for (int it = 0; it < kLongChunk * 8 / 256; ++it) {
+      const int i = tid + it * 256;
+      const int r = i >> 3, c = i & 7;
+      const int row = kc * kLongChunk + r;
+      f16x8 kv = zero8, vv = zero8;
+      if (row < rows_avail) {
+        const _Float16* src = base + row * row_stride + c * 8;
+        kv = *(const f16x8*)(src + hidden);
+        vv = *(const f16x8*)(src + 2 * hidden);
+      }
+      *(f16x8*)(k_lds + r * kKStride + c * 8) = kv;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt_lds[(c * 8 + e) * vt_stride + r] = vv[e];
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int tiles_here = n_ktiles - kc * 4 < 4 ? n_ktiles - kc * 4 : 4;
+    for (int kt = 0; kt < tiles_here; ++kt) {
+      f32x16 st = {0};
+      const _Float16* krow = k_lds + (kt * 32 + li) * kKStride + half * 8;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x8 kf = *(const f16x8*)(krow + j * 16);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j], st, 0, 0, 0);
+      }
+      // the scores stay unscaled: exp((s - m) / 8) = exp2(s c - m c), c = log2(e) / 8 -- one fused multiply-add and one
+      // v_exp_f32 per score (the scaling, the subtraction and __expf's own multiply by log2 e were three)
+      const int key_base = (kc * 4 + kt) * 32;
+      if (key_base + 32 > len) {                       // wave-uniform: only the last tile of a sequence is masked
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key_base + (r & 3) + 8 * (r >> 2) + 4 * half;
+          st[r] = key < len ? st[r] : -__builtin_inff();
+        }
+      }
+      float mt = st[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = __builtin_fmaxf(mt, st[r]);
+      mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = __builtin_fmaxf(m, mt);      // finite: key 0 is always valid
+      const float mc = m_new * kExpScale;
+      float rs = 0.f;
+      f16x8 pf[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], kExpScale, -mc));
+        rs += p;
+        pf[r >> 3][r & 7] = (_Float16)p;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      if (__any(m_new != m)) {                         // the running maximum moved for some query of the wave: rescale
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * kExpScale);
+        l *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          o0[r] *= alpha;
+          o1[r] *= alpha;
+        }
+      }
+      l += rs;
+      m = m_new;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int key0 = kt * 32 + 16 * jj + 4 * half;
+        const _Float16* r0 = vt_lds + li * vt_stride + key0;
+        const _Float16* r1 = vt_lds + (32 + li) * vt_stride + key0;
+        f16x8 v0, v1;
+        const f16x4 a0 = *(const f16x4*)r0, a1 = *(const f16x4*)(r0 + 8);
+        const f16x4 b0 = *(const f16x4*)r1, b1 = *(const f16x4*)(r1 + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v0[e] = a0[e];
+          v0[4 + e] = a1[e];
+          v1[e] = b0[e];
+          v1[4 + e] = b1[e];
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[jj], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[jj], o1, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                     // the last chunk is dead: its K rows become the output staging tiles
+  if (!active) return;
+  _Float16* out_lds = smem + wave * 32 * kOutStride;   // 4 x 32 x 72 fp16 = the K chunk's 18 KB
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f16x4 a, c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = (_Float16)(o0[g * 4 + e] * inv);
+      c[e] = (_Float16)(o1[g * 4 + e] * inv);
+    }
+    *(f16x4*)(out_lds + li * kOutStride + g * 8 + 4 * half) = a;
+    *(f16x4*)(out_lds + li * kOutStride + 32 + g * 8 + 4 * half) = c;
+  }
+  // same wave writes and reads its tile: LDS ops of a wave complete in order
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int row = it * 8 + (lane >> 3), piece = lane & 7;   // 8 lanes x 16 B = one 128-byte row
+    const int qq = qb * 32 + row;
+    f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8);
+    if (bias_v) v = v + *(const f16x8*)(bias_v + piece * 8);
+    if (qq < rows_avail) *(f16x8*)(ctx + (tok0 + qq) * hidden + head * kHeadDim + piece * 8) = v;
+  }
+}
+
 // Attention of the [CLS] query only (row 0 of every sequence): the last encoder layer feeds nothing
 // but h[:, 0] to the pooler (retriever.py:41-42 takes BertModel's pooled output), so its attention
 // output is needed for one query per sequence.  One wave per (sequence, head): lanes own keys for
@@ -311,11 +478,19 @@ int launch_attention(const void* qkv, const void* qkv_bias, const int32_t* seq_l
                      int batch, int seq_len, int n_heads, void* ctx_out, void* stream) {
   if (!qkv || !ctx_out) return fail(PROQA_EINVAL, "attention: NULL argument");
   if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention: bad sizes");
+  if (batch == 0) return PROQA_OK;
+  if (seq_len > kLongChunk && !(getenv("PROQA_ATTENTION_LONG") && atoi(getenv("PROQA_ATTENTION_LONG")) == 0)) {   // (developer A/B switch)
+    const int n_pairs = batch * n_heads, n_qc = (seq_len + kLongChunk - 1) / kLongChunk;
+    const unsigned grid = (unsigned)((n_pairs + 7) / 8 * 8) * (unsigned)n_qc;
+    hipLaunchKernelGGL(attention_long_fwd, dim3(grid), dim3(256), 0, as_stream(stream), (const _Float16*)qkv, (const _Float16*)qkv_bias,
+                       (const int*)seq_lens_dev, (const int*)cu_seqlens_dev, seq_len, n_heads, n_pairs, n_qc, (_Float16*)ctx_out);
+    PROQA_LAUNCH_CHECK();
+    return PROQA_OK;
+  }
   const int s_pad = (seq_len + 31) & ~31;
   const size_t lds = ((size_t)s_pad * kKStride + (size_t)kHeadDim * (s_pad + kVtPad) + 4 * 32 * kOutStride) *
                      sizeof(_Float16);
   if (lds > 160 * 1024) return fail(PROQA_EINVAL, "attention: seq_len=%d needs %zu B of LDS (> 160 KiB)", seq_len, lds);
-  if (batch == 0) return PROQA_OK;
   if (lds > 64 * 1024) {
     PROQA_HIP(hipFuncSetAttribute((const void*)attention_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
