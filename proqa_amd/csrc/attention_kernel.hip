@@ -4,9 +4,8 @@
 // (/root/reference/retrieval/retriever.py:37,41 -> transformers BertModel); the additive key
 // mask comes from the right-padding of em_collate (retrieval/datasets.py:29-45,298-305).
 //
-// One 256-thread workgroup per (sequence, head).  K and V of that head (S x 64 fp16 each) are
-// staged once in LDS with full-line coalesced loads (V transposed on the way in); each wave then
-// owns 32-query blocks.
+// One 256-thread workgroup per (sequence, head, 128 queries): the K and V rows of that head are staged in LDS
+// 128 keys at a time with full-line coalesced loads (V transposed on the way in); each wave owns one 32-query block.
 // Both products run on v_mfma_f32_32x32x16_f16 in the "swapped" orientation so that every lane
 // owns ONE query column of the accumulator:
 //   S^T = K Q^T   : lane (q = lane&31) holds 16 keys of its query per 32-key tile, so the row max
@@ -17,7 +16,6 @@
 // exactly the keys a lane's P registers hold (rows {0-3, 8-11} + 4*half + 16*step of the tile).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <cstdlib>
 
 #include "attention.h"
 #include "common.h"
@@ -49,181 +47,17 @@ __device__ __forceinline__ f16x8 add_bias8(f16x8 v, const _Float16* __restrict__
   return v;
 }
 
-__global__ __launch_bounds__(256) void attention_fwd(const _Float16* __restrict__ qkv,
-                                                     const _Float16* __restrict__ qkv_bias,
-                                                     const int* __restrict__ seq_lens,
-                                                     const int* __restrict__ cu_seqlens, int seq_len,
-                                                     int n_heads, _Float16* __restrict__ ctx) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
-  const int s_pad = (seq_len + 31) & ~31;
-  _Float16* k_lds = smem;                       // [s_pad][kKStride]
-  _Float16* vt_lds = smem + s_pad * kKStride;   // [kHeadDim][s_pad + kVtPad]  (V transposed)
-  const int vt_stride = s_pad + kVtPad;
-  // per-wave output staging tile (aliasing it onto the K rows behind a barrier was measured slower)
-  _Float16* out_lds = vt_lds + kHeadDim * vt_stride + (threadIdx.x >> 6) * 32 * kOutStride;
-  // [query bias (8 pieces of 16 B) | value bias (8 pieces)] of this head, zeros without a bias, kept in the 16
-  // padding bytes at the end of K rows 0..15 (never read by the fragment loads): neither registers nor
-  // dependent global loads sit on the short per-workgroup critical path, and the LDS footprint -- which
-  // decides 3 vs 2 workgroups per CU at S = 128 -- does not grow.  Piece t lives at bias_piece(t).
-  auto bias_piece = [&](int t) { return k_lds + t * kKStride + kHeadDim; };
-
-  const int b = blockIdx.x / n_heads;
-  const int head = blockIdx.x - b * n_heads;
-  const int hidden = n_heads * kHeadDim;
-  const long long row_stride = 3ll * hidden;
-  const long long tok0 = cu_seqlens ? cu_seqlens[b] : (long long)b * seq_len;
-  const _Float16* base = qkv + tok0 * row_stride + head * kHeadDim;
-  int len = cu_seqlens ? cu_seqlens[b + 1] - cu_seqlens[b] : (seq_lens ? seq_lens[b] : seq_len);
-  len = len < 1 ? 1 : (len > seq_len ? seq_len : len);
-  const int n_ktiles = (len + 31) >> 5;
-  const int rows_avail = cu_seqlens ? len : seq_len;   // token rows of this sequence that exist in memory
-  const _Float16* bias_q = qkv_bias ? qkv_bias + head * kHeadDim : nullptr;
-  const _Float16* bias_v = qkv_bias ? qkv_bias + 2 * hidden + head * kHeadDim : nullptr;
-
-  const int tid = threadIdx.x;
-  // stage K and V rows [0, n_ktiles*32): 8 lanes cover one 128-byte row.
-  // The projection bias (qkv_bias) costs nothing here: (q+bq).(k+bk) = (q+bq).k + (q+bq).bk, and the second
-  // term is the same for every key of a query, so the softmax ignores it -- the key bias is dropped; the
-  // probabilities sum to 1, so sum_j p_j (v_j + bv) = sum_j p_j v_j + bv -- the value bias is added to the
-  // finished output; only the query bias is added to the (register-resident) query fragments.
-  const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (tid < 16) {
-    const _Float16* src = tid < 8 ? bias_q : bias_v;
-    *(f16x8*)bias_piece(tid) = src ? *(const f16x8*)(src + (tid & 7) * 8) : zero8;
-  }
-  for (int i = tid; i < n_ktiles * 32 * 8; i += 256) {
-    const int row = i >> 3, c = i & 7;
-    f16x8 kv = zero8, vv = zero8;
-    if (row < rows_avail) {
-      const _Float16* src = base + row * row_stride + c * 8;
-      kv = *(const f16x8*)(src + hidden);
-      vv = *(const f16x8*)(src + 2 * hidden);
-    }
-    *(f16x8*)(k_lds + row * kKStride + c * 8) = kv;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) vt_lds[(c * 8 + e) * vt_stride + row] = vv[e];
-  }
-  __syncthreads();
-
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int li = lane & 31;
-  const int half = lane >> 5;
-  const int n_qblocks = (rows_avail + 31) >> 5;
-
-  auto write_out = [&](int qb, const f32x16& o0, const f32x16& o1, float l) {
-    const float inv = 1.0f / l;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f16x4 a, c;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        a[e] = (_Float16)(o0[g * 4 + e] * inv);
-        c[e] = (_Float16)(o1[g * 4 + e] * inv);
-      }
-      *(f16x4*)(out_lds + li * kOutStride + g * 8 + 4 * half) = a;
-      *(f16x4*)(out_lds + li * kOutStride + 32 + g * 8 + 4 * half) = c;
-    }
-    // same wave writes and reads the tile: LDS ops of a wave complete in order
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + (lane >> 3), piece = lane & 7;   // 8 lanes x 16 B = one 128-byte row
-      const int qq = qb * 32 + row;
-      const f16x8 v = *(const f16x8*)(out_lds + row * kOutStride + piece * 8) + *(const f16x8*)bias_piece(8 + piece);
-      if (qq < rows_avail)
-        *(f16x8*)(ctx + (tok0 + qq) * hidden + head * kHeadDim + piece * 8) = v;
-    }
-  };
-
-  for (int qb = wave; qb < n_qblocks; qb += 4) {
-    const int q = qb * 32 + li;
-    // Q fragments (MFMA B operand): 16-byte pieces 2j+half of the lane's query row
-    f16x8 qf[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      qf[j] = q < rows_avail ? *(const f16x8*)(base + q * row_stride + (2 * j + half) * 8) : z;
-    }
-    // query bias: a separate, unconditional pass (the four global loads above stay back to back; rows past
-    // the sequence get bias-only fragments whose outputs are never stored)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) qf[j] = qf[j] + *(const f16x8*)bias_piece(2 * j + half);
-    float m = -__builtin_inff();
-    float l = 0.f;
-    f32x16 o0 = {0}, o1 = {0};
-
-    for (int kt = 0; kt < n_ktiles; ++kt) {
-      // S^T tile: rows = 32 keys, columns = 32 queries
-      f32x16 st = {0};
-      const _Float16* krow = k_lds + (kt * 32 + li) * kKStride + half * 8;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f16x8 kf = *(const f16x8*)(krow + j * 16);
-        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[j], st, 0, 0, 0);
-      }
-      float mt = -__builtin_inff();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        st[r] = key < len ? st[r] * 0.125f : -__builtin_inff();
-        mt = __builtin_fmaxf(mt, st[r]);
-      }
-      mt = __builtin_fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float m_new = __builtin_fmaxf(m, mt);  // finite: key 0 is always valid
-      const float alpha = __expf(m - m_new);
-      float rs = 0.f;
-      f16x8 pf[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __expf(st[r] - m_new);
-        rs += p;
-        pf[r >> 3][r & 7] = (_Float16)p;
-      }
-      rs += __shfl_xor(rs, 32, 64);
-      l = l * alpha + rs;
-      m = m_new;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        o0[r] *= alpha;
-        o1[r] *= alpha;
-      }
-      // O^T += V^T P^T : A operand = row d of V^T at the keys this lane's P registers hold
-      // (keys {0-3, 8-11} + 4*half + 16*jj of the tile: two 8-byte reads per fragment)
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int key0 = kt * 32 + 16 * jj + 4 * half;
-        const _Float16* r0 = vt_lds + li * vt_stride + key0;
-        const _Float16* r1 = vt_lds + (32 + li) * vt_stride + key0;
-        f16x8 v0, v1;
-        const f16x4 a0 = *(const f16x4*)r0, a1 = *(const f16x4*)(r0 + 8);
-        const f16x4 b0 = *(const f16x4*)r1, b1 = *(const f16x4*)(r1 + 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v0[e] = a0[e];
-          v0[4 + e] = a1[e];
-          v1[e] = b0[e];
-          v1[4 + e] = b1[e];
-        }
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v0, pf[jj], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v1, pf[jj], o1, 0, 0, 0);
-      }
-    }
-
-    write_out(qb, o0, o1, l);
-  }
-}
-
-// Sequences of more than 128 tokens (the reference's default --max_seq_length is 512, retrieval/config.py:25): the
-// all-keys-in-LDS form above needs 157 KB at S = 512 -- ONE workgroup per CU, one wave per SIMD, nothing to overlap the
-// staging, the softmax arithmetic and the MFMAs with (194 us per layer at 64 x 512 x 12 heads, a quarter of the encode
-// step).  Here a workgroup owns 128 QUERIES of one (sequence, head) -- one 32-query block per wave -- and streams the keys
-// through LDS in chunks of 128 (K rows + V^T: 35 KB, four workgroups per CU); the online softmax state lives in registers
-// across chunks, exactly as across the key tiles above.  The workgroups of one (sequence, head) re-read its K / V (128 KB at
-// S = 512) from the L2 of ONE XCD: blockIdx -> (XCD, pair, query chunk) keeps them on the same XCD, adjacent in dispatch
-// order.  Same arithmetic, same operand roles and tile order as attention_fwd: the numbers are the same.
+// A workgroup owns up to 128 QUERIES of one (sequence, head) -- one 32-query block per wave -- and streams the keys of the
+// sequence through LDS in chunks of 128 (K rows + V^T: 35 KB, four workgroups per CU, <= 128 VGPRs); the online softmax
+// state lives in registers across chunks as across the key tiles of a chunk.  At S <= 128 that is one workgroup and one chunk
+// per (sequence, head).  At S = 512 (the reference's default --max_seq_length, retrieval/config.py:25) the four workgroups of a
+// (sequence, head) re-read its K / V (128 KB) from the L2 of ONE XCD: blockIdx -> (XCD, pair, query chunk) keeps them on
+// the same XCD, adjacent in dispatch order.  (Rounds 1-4 kept ALL keys of the sequence in LDS: 157 KB at S = 512 -- one
+// workgroup per CU, one wave per SIMD, nothing to overlap the staging, the softmax arithmetic and the MFMAs with: 194 us per
+// layer at 64 x 512 x 12 heads against 111 us in this form; at S = 128 the two forms are within 1 %.)
 constexpr int kLongChunk = 128;
 constexpr float kExpScale = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(head_dim)
-__global__ __launch_bounds__(256, 4) void attention_long_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
+__global__ __launch_bounds__(256, 4) void attention_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
                                                           const int* __restrict__ seq_lens, const int* __restrict__ cu_seqlens,
                                                           int seq_len, int n_heads, int n_pairs, int n_qc,
                                                           _Float16* __restrict__ ctx) {
@@ -283,8 +117,25 @@ __global__ __launch_bounds__(256, 4) void attention_long_fwd(const _Float16* __r
         vv = *(const f16x8*)(src + 2 * hidden);
       }
       *(f16x8*)(k_lds + r * kKStride + c * 8) = kv;
+      // V^T[d][key]: rows r and r ^ 1 sit in lanes 8 apart (DPP row_ror:8).  The even row's lane writes d = 8c .. 8c+3,
+      // the odd row's d = 8c+4 .. 8c+7, each as four 4-byte stores {key r & ~1, key r | 1} -- half the store instructions
+      // of a 2-byte scatter and a quarter of its bank conflicts
+      {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 w = __builtin_bit_cast(u32x4, vv);
+        const bool odd = (r & 1) != 0;
+        const unsigned s0 = odd ? w[0] : w[2], s1 = odd ? w[1] : w[3];
+        const unsigned g0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0x128, 0xf, 0xf, false);
+        const unsigned g1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0x128, 0xf, 0xf, false);
+        const unsigned lo[2] = {odd ? g0 : w[0], odd ? g1 : w[1]};   // the d values of the EVEN key (low half of the store)
+        const unsigned hi[2] = {odd ? w[2] : g0, odd ? w[3] : g1};   // ... of the odd key
+        _Float16* dst = vt_lds + (c * 8 + (odd ? 4 : 0)) * vt_stride + (r & ~1);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) vt_lds[(c * 8 + e) * vt_stride + r] = vv[e];
+        for (int t = 0; t < 2; ++t) {
+          *(unsigned*)(dst + (2 * t) * vt_stride) = __builtin_amdgcn_perm(hi[t], lo[t], 0x05040100u);
+          *(unsigned*)(dst + (2 * t + 1) * vt_stride) = __builtin_amdgcn_perm(hi[t], lo[t], 0x07060302u);
+        }
+      }
     }
     __syncthreads();
     if (!active) continue;
@@ -479,24 +330,10 @@ int launch_attention(const void* qkv, const void* qkv_bias, const int32_t* seq_l
   if (!qkv || !ctx_out) return fail(PROQA_EINVAL, "attention: NULL argument");
   if (batch < 0 || seq_len <= 0 || n_heads <= 0) return fail(PROQA_EINVAL, "attention: bad sizes");
   if (batch == 0) return PROQA_OK;
-  if (seq_len > kLongChunk && !(getenv("PROQA_ATTENTION_LONG") && atoi(getenv("PROQA_ATTENTION_LONG")) == 0)) {   // (developer A/B switch)
-    const int n_pairs = batch * n_heads, n_qc = (seq_len + kLongChunk - 1) / kLongChunk;
-    const unsigned grid = (unsigned)((n_pairs + 7) / 8 * 8) * (unsigned)n_qc;
-    hipLaunchKernelGGL(attention_long_fwd, dim3(grid), dim3(256), 0, as_stream(stream), (const _Float16*)qkv, (const _Float16*)qkv_bias,
-                       (const int*)seq_lens_dev, (const int*)cu_seqlens_dev, seq_len, n_heads, n_pairs, n_qc, (_Float16*)ctx_out);
-    PROQA_LAUNCH_CHECK();
-    return PROQA_OK;
-  }
-  const int s_pad = (seq_len + 31) & ~31;
-  const size_t lds = ((size_t)s_pad * kKStride + (size_t)kHeadDim * (s_pad + kVtPad) + 4 * 32 * kOutStride) *
-                     sizeof(_Float16);
-  if (lds > 160 * 1024) return fail(PROQA_EINVAL, "attention: seq_len=%d needs %zu B of LDS (> 160 KiB)", seq_len, lds);
-  if (lds > 64 * 1024) {
-    PROQA_HIP(hipFuncSetAttribute((const void*)attention_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  }
-  hipLaunchKernelGGL(attention_fwd, dim3((unsigned)batch * n_heads), dim3(256), lds, as_stream(stream),
-                     (const _Float16*)qkv, (const _Float16*)qkv_bias, (const int*)seq_lens_dev,
-                     (const int*)cu_seqlens_dev, seq_len, n_heads, (_Float16*)ctx_out);
+  const int n_pairs = batch * n_heads, n_qc = (seq_len + kLongChunk - 1) / kLongChunk;
+  const unsigned grid = (unsigned)((n_pairs + 7) / 8 * 8) * (unsigned)n_qc;
+  hipLaunchKernelGGL(attention_fwd, dim3(grid), dim3(256), 0, as_stream(stream), (const _Float16*)qkv, (const _Float16*)qkv_bias,
+                     (const int*)seq_lens_dev, (const int*)cu_seqlens_dev, seq_len, n_heads, n_pairs, n_qc, (_Float16*)ctx_out);
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;
 }
