@@ -57,7 +57,7 @@ __device__ __forceinline__ f16x8 add_bias8(f16x8 v, const _Float16* __restrict__
 // layer at 64 x 512 x 12 heads against 111 us in this form; at S = 128 the two forms are within 1 %.)
 constexpr int kLongChunk = 128;
 constexpr float kExpScale = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(head_dim)
-__global__ __launch_bounds__(256, 4) void attention_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
+__global__ __launch_bounds__(256, 3) void attention_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
                                                           const int* __restrict__ seq_lens, const int* __restrict__ cu_seqlens,
                                                           int seq_len, int n_heads, int n_pairs, int n_qc,
                                                           _Float16* __restrict__ ctx) {
@@ -103,19 +103,32 @@ __global__ __launch_bounds__(256, 4) void attention_fwd(const _Float16* __restri
   float l = 0.f;
   f32x16 o0 = {0}, o1 = {0};
 
+  // the K / V pieces of a chunk travel through registers: chunk kc + 1 is REQUESTED before the arithmetic of chunk kc and
+  // written to LDS after it, so that its memory round trip is not waited for in place
+  constexpr int kIters = kLongChunk * 8 / 256;
+  f16x8 kreg[kIters], vreg[kIters];
+  auto request = [&](int kc) {
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int i = tid + it * 256;
+      const int row = kc * kLongChunk + (i >> 3), c = i & 7;
+      kreg[it] = zero8;
+      vreg[it] = zero8;
+      if (row < rows_avail) {
+        const _Float16* src = base + row * row_stride + c * 8;
+        kreg[it] = *(const f16x8*)(src + hidden);
+        vreg[it] = *(const f16x8*)(src + 2 * hidden);
+      }
+    }
+  };
+  request(0);
   for (int kc = 0; kc < n_kchunks; ++kc) {
     if (kc) __syncthreads();                           // every wave is done with the previous chunk
 #pragma unroll
-    for (int it = 0; it < kLongChunk * 8 / 256; ++it) {
+    for (int it = 0; it < kIters; ++it) {
       const int i = tid + it * 256;
       const int r = i >> 3, c = i & 7;
-      const int row = kc * kLongChunk + r;
-      f16x8 kv = zero8, vv = zero8;
-      if (row < rows_avail) {
-        const _Float16* src = base + row * row_stride + c * 8;
-        kv = *(const f16x8*)(src + hidden);
-        vv = *(const f16x8*)(src + 2 * hidden);
-      }
+      const f16x8 kv = kreg[it], vv = vreg[it];
       *(f16x8*)(k_lds + r * kKStride + c * 8) = kv;
       // V^T[d][key]: rows r and r ^ 1 sit in lanes 8 apart (DPP row_ror:8).  The even row's lane writes d = 8c .. 8c+3,
       // the odd row's d = 8c+4 .. 8c+7, each as four 4-byte stores {key r & ~1, key r | 1} -- half the store instructions
@@ -137,6 +150,7 @@ __global__ __launch_bounds__(256, 4) void attention_fwd(const _Float16* __restri
         }
       }
     }
+    if (kc + 1 < n_kchunks) request(kc + 1);
     __syncthreads();
     if (!active) continue;
     const int tiles_here = n_ktiles - kc * 4 < 4 ? n_ktiles - kc * 4 : 4;
