@@ -48,13 +48,14 @@ __device__ __forceinline__ f16x8 add_bias8(f16x8 v, const _Float16* __restrict__
 }
 
 // A workgroup owns up to 128 QUERIES of one (sequence, head) -- one 32-query block per wave -- and streams the keys of the
-// sequence through LDS in chunks of 128 (K rows + V^T: 35 KB, four workgroups per CU, <= 128 VGPRs); the online softmax
+// sequence through LDS in chunks of 128 (K rows + V^T: 35 KB; 140 VGPRs with the next chunk's pieces in flight: three
+// workgroups per CU); the online softmax
 // state lives in registers across chunks as across the key tiles of a chunk.  At S <= 128 that is one workgroup and one chunk
 // per (sequence, head).  At S = 512 (the reference's default --max_seq_length, retrieval/config.py:25) the four workgroups of a
 // (sequence, head) re-read its K / V (128 KB) from the L2 of ONE XCD: blockIdx -> (XCD, pair, query chunk) keeps them on
 // the same XCD, adjacent in dispatch order.  (Rounds 1-4 kept ALL keys of the sequence in LDS: 157 KB at S = 512 -- one
 // workgroup per CU, one wave per SIMD, nothing to overlap the staging, the softmax arithmetic and the MFMAs with: 194 us per
-// layer at 64 x 512 x 12 heads against 111 us in this form; at S = 128 the two forms are within 1 %.)
+// layer at 64 x 512 x 12 heads against 108 us in this form; 108 against 93 us at 512 x 128.)
 constexpr int kLongChunk = 128;
 constexpr float kExpScale = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(head_dim)
 __global__ __launch_bounds__(256, 3) void attention_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
