@@ -48,17 +48,16 @@ __device__ __forceinline__ f16x8 add_bias8(f16x8 v, const _Float16* __restrict__
 }
 
 // A workgroup owns up to 128 QUERIES of one (sequence, head) -- one 32-query block per wave -- and streams the keys of the
-// sequence through LDS in chunks of 128 (K rows + V^T: 35 KB; 140 VGPRs with the next chunk's pieces in flight: three
-// workgroups per CU); the online softmax
+// sequence through LDS in chunks of 128 (K rows + V^T: 35 KB, 108 VGPRs: four workgroups per CU); the online softmax
 // state lives in registers across chunks as across the key tiles of a chunk.  At S <= 128 that is one workgroup and one chunk
 // per (sequence, head).  At S = 512 (the reference's default --max_seq_length, retrieval/config.py:25) the four workgroups of a
 // (sequence, head) re-read its K / V (128 KB) from the L2 of ONE XCD: blockIdx -> (XCD, pair, query chunk) keeps them on
 // the same XCD, adjacent in dispatch order.  (Rounds 1-4 kept ALL keys of the sequence in LDS: 157 KB at S = 512 -- one
 // workgroup per CU, one wave per SIMD, nothing to overlap the staging, the softmax arithmetic and the MFMAs with: 194 us per
-// layer at 64 x 512 x 12 heads against 108 us in this form; 108 against 93 us at 512 x 128.)
+// layer at 64 x 512 x 12 heads against 106 us in this form; 108 against 91 us at 512 x 128.)
 constexpr int kLongChunk = 128;
 constexpr float kExpScale = 0.125f * 1.4426950408889634f;   // log2(e) / sqrt(head_dim)
-__global__ __launch_bounds__(256, 3) void attention_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
+__global__ __launch_bounds__(256, 4) void attention_fwd(const _Float16* __restrict__ qkv, const _Float16* __restrict__ qkv_bias,
                                                           const int* __restrict__ seq_lens, const int* __restrict__ cu_seqlens,
                                                           int seq_len, int n_heads, int n_pairs, int n_qc,
                                                           _Float16* __restrict__ ctx) {
@@ -104,8 +103,10 @@ __global__ __launch_bounds__(256, 3) void attention_fwd(const _Float16* __restri
   float l = 0.f;
   f32x16 o0 = {0}, o1 = {0};
 
-  // the K / V pieces of a chunk travel through registers: chunk kc + 1 is REQUESTED before the arithmetic of chunk kc and
-  // written to LDS after it, so that its memory round trip is not waited for in place
+  // the K / V pieces of a chunk travel through registers: all eight loads of a thread are requested back to back and waited
+  // for once (written in one loop with the LDS stores, hipcc waited per piece: 102 against 91 us at 512 x 128).  Requesting
+  // chunk kc + 1 before the arithmetic of chunk kc (32 more live registers: three workgroups per CU) measured 2 % SLOWER
+  // than four workgroups per CU hiding each other's round trips (ABLATIONS R5.11)
   constexpr int kIters = kLongChunk * 8 / 256;
   f16x8 kreg[kIters], vreg[kIters];
   auto request = [&](int kc) {
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(256, 3) void attention_fwd(const _Float16* __restri
       }
     }
   };
-  request(0);
   for (int kc = 0; kc < n_kchunks; ++kc) {
+    request(kc);
     if (kc) __syncthreads();                           // every wave is done with the previous chunk
 #pragma unroll
     for (int it = 0; it < kIters; ++it) {
@@ -151,7 +152,6 @@ __global__ __launch_bounds__(256, 3) void attention_fwd(const _Float16* __restri
         }
       }
     }
-    if (kc + 1 < n_kchunks) request(kc + 1);
     __syncthreads();
     if (!active) continue;
     const int tiles_here = n_ktiles - kc * 4 < 4 ? n_ktiles - kc * 4 : 4;

@@ -1024,8 +1024,6 @@ struct ExactCtx {
   unsigned* n_nom;
 };
 
-// INT_SCORES: records of the int8 nomination scan (int32 scores against an int32 threshold word, strict)
-template <bool INT_SCORES = false>
 __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned q, bool inclusive,
                                                  unsigned long long bound, const ExactCtx& ex,
                                                  unsigned long long* keys, unsigned* n_keys, unsigned cap) {
@@ -1037,10 +1035,9 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
   for (int g = 0; g < 4; ++g) {
     const uint4 v = src[1 + g];
     const float sc[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
-    const unsigned raw[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const bool pass = INT_SCORES ? ((float)(int)raw[e] > tau) : (inclusive ? (sc[e] >= tau) : (sc[e] > tau));
+      const bool pass = inclusive ? (sc[e] >= tau) : (sc[e] > tau);
       if (pass && (e + 8 * g) < rows_left) {
         const unsigned row = h.y + (unsigned)(e + 8 * g);
         if (ex.nom) {  // the fp16 score only nominates the row
@@ -1058,14 +1055,13 @@ __device__ __forceinline__ void keep_scores_regs(const uint4 (&src)[5], unsigned
   }
 }
 
-template <bool INT_SCORES = false>
 __device__ __forceinline__ void keep_scores(const WaveRecord* rec, unsigned q, bool inclusive,
                                             unsigned long long bound, const ExactCtx& ex, unsigned long long* keys,
                                             unsigned* n_keys, unsigned cap) {
   uint4 buf[5];
 #pragma unroll
   for (int g = 0; g < 5; ++g) buf[g] = ((const uint4*)rec)[g];
-  keep_scores_regs<INT_SCORES>(buf, q, inclusive, bound, ex, keys, n_keys, cap);
+  keep_scores_regs(buf, q, inclusive, bound, ex, keys, n_keys, cap);
 }
 
 // Append the lanes' items (pred lanes only) to an LDS array: one LDS atomic per wave, ranks by mbcnt.
@@ -1407,7 +1403,7 @@ void topk_merge(MergeArgs a) {
           else if constexpr (NOM)
             keep_nominees(((const uint2*)st.lane_log)[li[e] * lane_cap + s], ex, CAP);
           else
-            keep_scores<false>(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+            keep_scores(st.lane_log + li[e] * lane_cap + s, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
         }
       }
     }
@@ -1421,7 +1417,7 @@ void topk_merge(MergeArgs a) {
         const unsigned n_s = (unsigned)__shfl((int)n_spill, src, 64);
         const size_t slot_s = spill_slot0 + (size_t)((tid & ~63) + src) * spill_stride;
         for (unsigned i = lane; i < n_s; i += 64)
-          keep_scores<false>(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+          keep_scores(st.spill_log + slot_s * kSpillCap + i, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
       }
     }
     __syncthreads();
@@ -1444,8 +1440,8 @@ void topk_merge(MergeArgs a) {
         for (int g = 0; g < 5; ++g) b0[g] = r0[g];
 #pragma unroll
         for (int g = 0; g < 5; ++g) b1[g] = r1[g];
-        keep_scores_regs<false>(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
-        if (two) keep_scores_regs<false>(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+        keep_scores_regs(b0, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
+        if (two) keep_scores_regs(b1, q, inclusive, bound, ex, keys, &s_n_keys, CAP);
       }
     } else if constexpr (NOM) {
       // int8 rounds: 8-byte records, one per thread and trip (a round's ~260 records of a query: one or two trips)
@@ -1487,28 +1483,6 @@ void topk_merge(MergeArgs a) {
               const unsigned pos = atomicAdd(ex.n_nom, 1u);  // LDS
               if (pos < (unsigned)CAP) ex.nom[pos] = row0 + (unsigned)(e + 8 * g);
             }
-          }
-        } else if constexpr (NOM) {   // int8 nomination: int32 scores above the integer threshold name the rows to re-score
-          const int raw[4] = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};   // (tau: the float threshold of the record's block)
-          bool p[4];
-          unsigned long long m[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            p[e] = live && piece != 0 && (float)raw[e] > tau && (e + 8 * g) < rows_left;
-            m[e] = __ballot(p[e]);
-          }
-          const unsigned n0 = (unsigned)__builtin_popcountll(m[0]), n1 = (unsigned)__builtin_popcountll(m[1]),
-                         n2 = (unsigned)__builtin_popcountll(m[2]), n3 = (unsigned)__builtin_popcountll(m[3]);
-          const unsigned total = n0 + n1 + n2 + n3;
-          if (total == 0) return;   // wave-uniform
-          unsigned base = 0;
-          if (lane == 0) base = atomicAdd(ex.n_nom, total);   // LDS
-          base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-          const unsigned off[4] = {base, base + n0, base + n0 + n1, base + n0 + n1 + n2};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned pos = off[e] + __builtin_amdgcn_mbcnt_hi((unsigned)(m[e] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m[e], 0u));
-            if (p[e] && pos < (unsigned)CAP) ex.nom[pos] = row0 + (unsigned)(e + 8 * g);
           }
         } else {
           // Branch-free per lane: the four scores of a piece are tested, the survivors of the WAVE are counted by ballot
