@@ -90,6 +90,21 @@ __device__ __forceinline__ float max16_f32(const float (&v)[16]) {
   return r;
 }
 
+// bit i set <=> v[i] > thr: a compare into VCC and an add-with-carry per value (mask = 2 mask + carry, i = 15 .. 0), no
+// branches and no temporaries.  The values must be complete in their registers (no MFMA result in flight).
+__device__ __forceinline__ unsigned gt_mask16_f32(const f32x16& v, float thr) {
+  unsigned mask = 0u;
+#define PROQA_BIT(n) "v_cmp_gt_f32 vcc, %" #n ", %17\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+  asm volatile(PROQA_BIT(16) PROQA_BIT(15) PROQA_BIT(14) PROQA_BIT(13) PROQA_BIT(12) PROQA_BIT(11) PROQA_BIT(10) PROQA_BIT(9)
+               PROQA_BIT(8) PROQA_BIT(7) PROQA_BIT(6) PROQA_BIT(5) PROQA_BIT(4) PROQA_BIT(3) PROQA_BIT(2) PROQA_BIT(1)
+               : "+v"(mask)
+               : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+                 "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]), "v"(thr)
+               : "vcc");
+#undef PROQA_BIT
+  return mask;
+}
+
 __device__ __forceinline__ float max2_f32(float a, float b) {
   float r;
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -276,6 +291,41 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 #pragma unroll
     for (int blk = 0; blk < QW; ++blk) {
       unsigned long long* list = (unsigned long long*)lane_list[blk];
+      if (!kCheckRows && !(a.flags & 128u)) {   // (flag 128, A/B: the per-register test everywhere)
+        // Every unit but the chunk's last stage: ONE wave-wide branch per query block (the column maximum), then straight-line
+        // code -- the 16-bit set of the lane's scores above its threshold (32 VALU operations, no branch); a lane with ONE such
+        // score (almost every hit) appends (its maximum, the row of the set bit); lanes with several take the per-register
+        // loop below under a second, rarely taken, branch.  (The per-register form tests 4 quads + the registers of a passing
+        // quad: ~10 dependent wave-wide branches per block and unit, which is what a hit costs: ABLATIONS R4.3, R5.12.)
+        float sc16[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc16[r] = pend[blk][r];
+        const float m = max16_f32(sc16);
+        if (__builtin_expect(__any(m > tau[blk]), 1)) {
+          const unsigned mask = gt_mask16_f32(pend[blk], tau[blk]);
+          const unsigned n = (unsigned)__builtin_popcount(mask);
+          if (n == 1u) {
+            const int b = __builtin_ctz(mask);
+            const int rel = pend_rel0 + 4 * half + (b & 3) + 8 * (b >> 2);
+            list[lane_n[blk] & (kCompactKeys - 1)] = pack_key(m, row_begin32 + (unsigned)rel);
+            ++lane_n[blk];
+          }
+          if (__builtin_expect(__any(n > 1u), 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool h = n > 1u && ((mask >> r) & 1u);
+              if (__any(h)) {
+                if (h) {
+                  const int rel = pend_rel0 + 4 * half + (r & 3) + 8 * (r >> 2);
+                  list[lane_n[blk] & (kCompactKeys - 1)] = pack_key(pend[blk][r], row_begin32 + (unsigned)rel);
+                  ++lane_n[blk];
+                }
+              }
+            }
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {   // registers 4g .. 4g+3 behind ONE pre-test of their maximum (a third of the quads pass it)
         const float m4 = max4_f32(pend[blk][4 * g], pend[blk][4 * g + 1], pend[blk][4 * g + 2], pend[blk][4 * g + 3]);
@@ -2357,13 +2407,6 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
 }
 
 hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st) {
-  if (!(a.flags & 64u)) {   // the shipped form: one barrier per two stages (flag 64: the stage-wise kernel, for A/B runs and cut experiments)
-    if (qw == 2)
-      hipLaunchKernelGGL((mips_filter_i8<2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
-    else
-      hipLaunchKernelGGL((mips_filter_i8<1>), dim3(grid), dim3(kFilterThreads), 0, st, a);
-    return hipGetLastError();
-  }
   if (qw == 2)   // (flag 256, experiment: 24 KiB of unused dynamic LDS leave room for ONE workgroup per CU)
     hipLaunchKernelGGL((mips_filter_i8<2>), dim3(grid), dim3(kFilterThreads), (a.flags & 256u) ? 24576 : 0, st, a);
   else if (qw == 1)
