@@ -19,14 +19,14 @@ while time.time() < t_end:
     layers = int(rng.choice([1, 2, 3])) if heads < 12 else 1
     inter = int(rng.choice([64, 256, 520]))
     cfg = config_from_dict({"vocab_size": 300, "hidden_size": heads * 64, "num_hidden_layers": layers,
-                            "num_attention_heads": heads, "intermediate_size": inter, "max_position_embeddings": 200,
+                            "num_attention_heads": heads, "intermediate_size": inter, "max_position_embeddings": 520,
                             "layer_norm_eps": 1e-12, "hidden_act": "gelu"})
     sd = {k: v.half().float() for k, v in random_state_dict(cfg, seed=int(rng.integers(1 << 30)), std=0.05).items()}
     model = BertForRetriever(cfg, device=dev)
     model.load_state_dict(sd)
     sd_np = {k: v.numpy() for k, v in sd.items()}
     for _ in range(4):
-        B, S = int(rng.integers(1, 41)), int(rng.choice([1, 2, 17, 31, 32, 33, 64, 100, 128, 160, 200]))
+        B, S = int(rng.integers(1, 25)), int(rng.choice([1, 2, 17, 31, 32, 33, 64, 100, 128, 129, 160, 200, 257, 300, 512, 520]))
         lens = rng.integers(1, S + 1, B)
         lens[rng.integers(0, B)] = S
         ids = np.zeros((B, S), np.int64); mask = np.zeros((B, S), bool)
