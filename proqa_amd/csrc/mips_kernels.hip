@@ -1870,7 +1870,7 @@ __global__ __launch_bounds__(kBootWaves * 64) void bootstrap_scores(const char* 
 }
 
 // bootstrap_select: one workgroup per query over S[q][0, n_rows).  Thread t packs the keys of elements
-// t, t+256, ... and keeps the largest; the k-th largest of the 256 thread maxima bounds the k-th best key from
+// 4t .. 4t+3, + 1024, ... (16-byte loads) and keeps the largest; the k-th largest of the 256 thread maxima bounds the k-th best key from
 // below (k threads hold a key at least that large), so only the keys >= that bound -- usually between k and 3k
 // of them -- are collected and sorted.  More than kMaxSortKeys survivors (an adversarial order) raise the
 // overflow flag; the host then repeats the page without the bootstrap.
@@ -1889,12 +1889,20 @@ __global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* _
   const float* row = S + (size_t)q * s_stride;
   unsigned long long mine[E];
   unsigned long long best = 0ull;
+  // (four consecutive scores per 16-byte load: n_rows and the row stride are multiples of 32)
+  static_assert(E % 4 == 0, "keys per thread");
 #pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const int i = e * kMergeThreads + tid;
-    const float sc = i < n_rows ? row[i] : -__builtin_inff();
-    mine[e] = sc > -__builtin_inff() ? pack_key(sc, (unsigned)i) : 0ull;   // like the filter: -inf / NaN never qualify
-    best = mine[e] > best ? mine[e] : best;
+  for (int e4 = 0; e4 < E / 4; ++e4) {
+    const int i0 = (e4 * kMergeThreads + tid) * 4;
+    const f32x4 neg = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    const f32x4 sc4 = i0 < n_rows ? *(const f32x4*)(row + i0) : neg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int e = e4 * 4 + c;
+      // like the filter: -inf / NaN never qualify (nor do the padding columns of the last 32-row tile)
+      mine[e] = sc4[c] > -__builtin_inff() && i0 + c < n_rows ? pack_key(sc4[c], (unsigned)(i0 + c)) : 0ull;
+      best = mine[e] > best ? mine[e] : best;
+    }
   }
   if (tid == 0) s_n_keys = 0;
   unsigned long long bound = 1ull;   // fewer than k rows: every valid row is kept

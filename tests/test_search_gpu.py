@@ -734,14 +734,14 @@ def test_bootstrap_rows_give_the_same_result(gpu_device, n, nq, k, rows):
 
 @pytest.mark.gpu
 def test_bootstrap_overflow_repeats_without_it(gpu_device):
-    """The select keeps the keys above the k-th largest of its 256 thread maxima (thread t owns rows t, t+256, ...).
+    """The select keeps the keys above the k-th largest of its 256 thread maxima (thread t owns rows 4t .. 4t+3, + 1024, ...).
     If the good rows all sit in the strides of k-1 threads, that bound is low and (k-1)*rows/256 + 1 keys pass: more
     than one sort holds at 8192 rows.  The page is then repeated without the bootstrap."""
     from proqa_amd.index import IndexFlatIP
     n, nq, k, rows = 40000, 5, 80, 8192
     xb = np.zeros((n, 128), dtype=np.float16)
     xb[:, 0] = 1.0
-    good = (np.arange(n) % 256 < k - 1) & (np.arange(n) < rows)
+    good = ((np.arange(n) // 4) % 256 < k - 1) & (np.arange(n) < rows)
     xb[good, 0] = 10.0
     xb[:, 1] = (np.arange(n) % 7).astype(np.float16)       # some variety below the good rows
     xq = np.zeros((nq, 128), dtype=np.float16)
