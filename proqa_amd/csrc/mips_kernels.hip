@@ -598,7 +598,7 @@ __device__ __forceinline__ float block_threshold(const LaneThreshold& t, float G
 // integer scores themselves are not kept: 8 bytes and one store instead of 80 and five.  (float)acc > thr <=> acc >
 // floor(thr) for integers (|acc| < 2^24 converts exactly); thr is finite and below 2^21 on this path (the column maximum
 // exceeded it) or -inf.
-__device__ __forceinline__ unsigned nominee_mask(const i32x16& acc, float thr, int rows_left) {
+__device__ __forceinline__ unsigned nominee_mask(const i32x16& acc, float thr) {
   const int ti = thr < -2147483000.f ? (int)0x80000000 : (int)__builtin_floorf(thr);
   // mask = 2 mask + (acc[i] > ti), i = 15 .. 0: a compare into VCC and an add-with-carry per accumulator, no temporaries
   // (the plain C++ form costs ten more registers than the kernel's 128 allow).  The accumulators were read by the
@@ -612,16 +612,17 @@ __device__ __forceinline__ unsigned nominee_mask(const i32x16& acc, float thr, i
                  "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15]), "v"(ti)
                : "vcc");
 #undef PROQA_BIT
-  if (rows_left < 28) {   // the slab ends inside this column (the last unit of the last chunk)
-    unsigned valid = 0u;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c = rows_left - 8 * g;
-      valid |= (c >= 4 ? 0xFu : (c > 0 ? (1u << c) - 1u : 0u)) << (4 * g);
-    }
-    mask &= valid;
-  }
   return mask;
+}
+// the bits of a column whose rows lie inside the slab: rows_left = rows of the chunk from the column's first row on
+__device__ __forceinline__ unsigned column_rows_mask(int rows_left) {
+  unsigned valid = 0u;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int c = rows_left - 8 * g;
+    valid |= (c >= 4 ? 0xFu : (c > 0 ? (1u << c) - 1u : 0u)) << (4 * g);
+  }
+  return valid;
 }
 
 // Same tiling as mips_filter_f16 -- 8 waves, wave w keeps its QW x 32 queries as MFMA B fragments for its lifetime, the
@@ -818,7 +819,11 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
             st_cur += 1;
             if (hit[blk]) {
               const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
-              lane_list[blk][slot] = make_uint2(row_begin32 + (unsigned)rel, nominee_mask(acc[blk], tb[blk], n_rows - rel));
+              unsigned mask = nominee_mask(acc[blk], tb[blk]);
+              // (scalar condition: only the chunk's last unit can reach past its rows -- hipcc turned a per-lane form of this
+              // test into ~40 unconditional VALU operations in every hit path)
+              if ((2 * p * 4 + u + 1) * kSubRows > n_rows) mask &= column_rows_mask(n_rows - rel);
+              lane_list[blk][slot] = make_uint2(row_begin32 + (unsigned)rel, mask);
               ++lane_n[blk];
             }
           }
