@@ -265,7 +265,9 @@ def encode_leg(args, device, world, rank):
             if len(keep) > 2:
                 keep.pop(0)
 
-        dt2 = timed(step2, args.encode_steps, 2, world, device)
+        # (the better of two runs of K steps: one run of 8 steps of ~7.5 ms is at the mercy of a single host hiccup --
+        # a collection of this round read 29 k passages/s here between four that read 37-40 k)
+        dt2 = min(timed(step2, args.encode_steps, 2, world, device), timed(step2, args.encode_steps, 0, world, device))
         ptl = 2 * 768 * 2304 + 2 * 768 * 768 + 4 * 768 * 3072 + 4 * S2 * 768
         ex2 = (12 * S2 * ptl - (S2 - 1) * (ptl - 2 * 768 * 2304)) / 1e9
         tf2 = B2 * args.encode_steps / dt2 * ex2 / 1e3
