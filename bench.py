@@ -13,10 +13,12 @@ Rank 0 prints ONE JSON line of at most ~6 KB (the driver keeps the tail of stdou
 five significant digits, no prose.  What the keys mean:
 
   value / ms_per_step      whole-job queries/s of the timed steps (default scan: the int8 nomination rounds + exact re-scoring)
-  roofline                 dominant kernel of the timed search: ALGORITHMIC fp16 flops 2 Q N d over the HIP-event time of its
-                           filter launches, against the dense fp16 MFMA peak; .executed = the same work as int8 operations
-                           against the int8 peak; .traffic = HBM bytes of those launches from the committed PMC pass
-                           (profiles/pmc_traffic.json, stamped with its commit), null when that pass measured the other scan
+  roofline                 dominant kernel of the timed search: the ALGORITHMIC 2 Q N d multiply-add flops over the HIP-event time
+                           of its filter launches, against the dense peak of the instruction the kernel issues (int8 MFMA for
+                           the nomination scan, fp16 MFMA for the fp16 scan); .fp16_equivalent_frac = the same flops against
+                           the fp16 peak; .traffic = HBM bytes of those launches from the committed PMC pass
+                           (profiles/pmc_traffic.json, stamped with its commit), null when that pass measured the other scan;
+                           .rescore_gather_bytes = fp16 rows the merges gather for the exact re-scoring
   fp16_scan                the same search with the nomination switched off (mips_filter_f16), digests compared
   scan_small_batch         32 queries over the same rows: the HBM-bound regime (algorithmic bytes = rows x 256 B)
   shard_sweep              N=1 timing of the per-rank search of a G-rank job (first N/G rows, no collective)
@@ -918,7 +920,6 @@ def main():
     flops = 2.0 * nq * (hi - lo) * D
     filter_s = st["filter_ms"] / 1e3
     tflops = flops / filter_s / 1e12
-    hbm_gbs = (hi - lo) * D * 2 / filter_s / 1e9
     nominated = bool(st.get("nomination"))
     fp16_scan = None
     if nominated:
@@ -950,16 +951,27 @@ def main():
         _lib.check(_lib.load().proqa_comm_info(sharded._comm, ctypes.byref(ws_), ctypes.byref(rk_)))
         comm_info = {"world_size": ws_.value, "rank": rk_.value}
 
-    roofline = {"bound": "mfma", "achieved": tflops, "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / PEAK_MFMA_F16_TFLOPS, "traffic": pmc_traffic((hi - lo) / n, nominated),
+    # The roofline is that of the instruction the dominant kernel ISSUES: v_mfma_i32_32x32x32_i8 against the dense int8 peak
+    # when the rounds scanned the int8 copy (the 2 Q N d multiply-adds are executed as int8 operations), the fp16 MFMA peak
+    # for the fp16 scan.  `fp16_equivalent_frac` prices the same algorithmic flops against the fp16 peak (the inner products
+    # the result is made of): a secondary figure, not a fraction of the kernel's roofline.  filter_ms_per_search is the scan
+    # alone; the exact re-scoring of the nominated rows runs inside the topk_merge launches and is part of
+    # `chain_ms_per_search` (step - filter: bootstrap, merges incl. re-scoring, finalize, launch gaps, the host wait).
+    row_bytes_scanned = D * (1 if nominated else 2)
+    hbm_gbs = (hi - lo) * row_bytes_scanned / filter_s / 1e9
+    peak = PEAK_MFMA_I8_TOPS if nominated else PEAK_MFMA_F16_TFLOPS
+    roofline = {"bound": "mfma", "achieved": tflops, "peak": peak, "unit": "TOP/s" if nominated else "TFLOP/s",
+                "frac": tflops / peak, "traffic": pmc_traffic((hi - lo) / n, nominated),
                 "traffic_commit": pmc_traffic_commit(), "traffic_age_commits": pmc_traffic_age(),
                 "kernel": "mips_filter_i8" if nominated else "mips_filter_f16", "nomination": "int8" if nominated else None,
-                "filter_ms_per_search": st["filter_ms"], "hbm_achieved_GBs": hbm_gbs, "hbm_frac": hbm_gbs / PEAK_HBM_GBS}
+                "instruction": "v_mfma_i32_32x32x32_i8" if nominated else "v_mfma_f32_32x32x16_f16",
+                "filter_ms_per_search": st["filter_ms"], "chain_ms_per_search": dt / args.steps * 1e3 - st["filter_ms"],
+                "hbm_bytes_per_row_scanned": row_bytes_scanned, "hbm_achieved_GBs": hbm_gbs}
     if nominated:
-        # the same work as executed int8 multiply-adds against the int8 peak; rows re-scored exactly per query
-        roofline["executed"] = {"achieved": tflops, "peak": PEAK_MFMA_I8_TOPS, "unit": "TOP/s", "frac": tflops / PEAK_MFMA_I8_TOPS,
-                                "hbm_bytes_algorithmic": (hi - lo) * D}
+        roofline["fp16_equivalent_frac"] = tflops / PEAK_MFMA_F16_TFLOPS
         roofline["nominated_per_query"] = st["nominated"] / max(nq, 1)
+        # what the exact re-scoring gathers beside the scan: one 256-byte fp16 row per nominated row (in the merges)
+        roofline["rescore_gather_bytes"] = float(st["nominated"]) * D * 2
     line = {
         "metric": "queries/sec top-80 MIPS over 18M x 128 index", "value": qps, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -1117,8 +1129,8 @@ def main():
 
 LINE_BYTES = 6000   # the printed line stays below this (tests/test_bench_gpu.py)
 LINE_TRIM_ORDER = [("encode", "cli_text_non_ascii"), ("search_cli_eval", "loader"), ("encode", "cli_text", "tokenise_only"),
-                   ("kmeans", "cpu_baseline"), ("peak_measured",), ("search_cli_eval", "host_api_search"), ("online",),
-                   ("encode", "corpus_1m"), ("encode", "cli_text"), ("kmeans",), ("float32_index",), ("large_k",)]
+                   ("kmeans", "cpu_baseline"), ("search_cli_eval", "host_api_search"), ("online",),
+                   ("encode", "corpus_1m"), ("encode", "cli_text"), ("kmeans",), ("float32_index",), ("large_k",), ("peak_measured",)]
 MAX_STRING = 96   # longer strings are prose: they live in the docstring above / DESIGN.md, not in the line
 # keys of the unabridged record (gpurun_out/bench_full.json) that the printed line leaves out below its top level: prose,
 # restatements of the command line, intermediate timings a stage split already covers
@@ -1143,6 +1155,8 @@ def compact(obj, depth=0, parent=None):
             if k == "workload" and parent != "config":
                 continue
             if isinstance(v, str) and len(v) > MAX_STRING and k not in ("workload", "sample"):
+                continue
+            if v is None and depth > 0 and k != "traffic":   # "not applicable" below the top level: the key's absence says it
                 continue
             out[k] = compact(v, depth + 1, k)
         return out
@@ -1172,12 +1186,16 @@ def measured_peaks(device):
         _lib.check(lib.proqa_microbench_stream(buf.data_ptr(), nbytes, kind, 5, st, ctypes.byref(v)))
         out[name] = v.value
     del buf
-    for name, ms, zero in (("mfma_f16_TFLOPs_8ms_random_operands", 8.0, 0), ("mfma_f16_TFLOPs_8ms_zero_operands", 8.0, 1),
-                           ("mfma_f16_TFLOPs_0.3ms_random_operands", 0.3, 0)):
+    for name, ms, zero in (("mfma_f16_TFLOPs_8ms_random_operands", 8.0, 0), ("mfma_f16_TFLOPs_8ms_zero_operands", 8.0, 1)):
         _lib.check(lib.proqa_microbench_mfma(ms, zero, st, ctypes.byref(v)))
         out[name] = v.value
-    out["note"] = ("float4 grid-stride copy / read of 2 GiB; 4 independent v_mfma_f32_32x32x16_f16 chains per wave from "
-                   "registers, 8 waves per CU; best of repeated launches")
+    # the int8 instruction the nomination scan issues, and the 16x16x64 shape the guide quotes its int8 ceiling for
+    for name, zero, shape in (("mfma_i8_TOPs_8ms_random_operands", 0, 0), ("mfma_i8_TOPs_8ms_zero_operands", 1, 0),
+                              ("mfma_i8_16x16x64_TOPs_8ms_random", 0, 1)):
+        _lib.check(lib.proqa_microbench_mfma_i8_shape(8.0, zero, shape, st, ctypes.byref(v)))
+        out[name] = v.value
+    out["note"] = ("float4 grid-stride copy / read of 2 GiB; 4 independent v_mfma_f32_32x32x16_f16 (v_mfma_i32_32x32x32_i8, "
+                   "_16x16x64_i8) chains per wave from registers, 8 waves per CU; best of repeated launches")
     return out
 
 

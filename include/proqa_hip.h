@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROQA_ABI_VERSION 5
+#define PROQA_ABI_VERSION 6
 
 /* element types of embedding matrices (the .npy index is '<f2' under --fp16, else '<f4':
  * retrieval/get_embed.py:139) */
@@ -93,8 +93,23 @@ int proqa_index_add_npy(proqa_index* idx, const char* path, int64_t row0, int64_
 /* same, source already in HBM (used by the synthetic benchmark and the sharded path) */
 int proqa_index_add_device(proqa_index* idx, const void* xb_dev, int64_t n, int dtype, void* stream);
 /* adopt caller-owned fp16 rows already in HBM without copying; the caller keeps them alive
- * until proqa_index_free/reset */
+ * until proqa_index_free/reset.  IMMUTABILITY: searches of k <= 128 over >= 65536 rows scan an int8 copy of the rows
+ * (+128 B per row of HBM, see proqa_index_configure_nomination) that the library builds once and keys on the row set; a
+ * caller that overwrites adopted rows in place calls proqa_index_rows_changed afterwards (or switches the copy off with
+ * proqa_index_configure_nomination(idx, 0)) -- otherwise rows whose new score qualifies are searched against the stale
+ * copy and can be missing from the result, silently. */
 int proqa_index_adopt_device(proqa_index* idx, const void* xb_dev_f16, int64_t n);
+/* the rows of the index were modified in place (adopted memory): whatever the library derived from them (the int8 copy
+ * and its statistics) is rebuilt before it is used again.  Not available once the index has switched to exact-float32
+ * mode (its float32 copies are the data: reset and add again). */
+int proqa_index_rows_changed(proqa_index* idx);
+/* Build now what the first search would otherwise build: the int8 copy of the rows for the nomination scan (an
+ * allocation of 128 B per row, two passes over the rows, one host read).  Synchronises `stream`.  Optional: a
+ * proqa_index_search / _search_device call builds the copy itself when it is missing or stale; an ENQUEUED search
+ * (proqa_index_search_begin_device) never allocates or waits -- without a current copy it scans the fp16 rows and its
+ * _finish builds the copy -- so a caller that wants its first enqueued search on the int8 copy calls this after add /
+ * adopt / rows_changed.  No-op for indexes the nomination scan does not apply to. */
+int proqa_index_prepare(proqa_index* idx, void* stream);
 /* 1 once the index has switched to exact-float32 mode (see above) */
 int proqa_index_is_exact_f32(const proqa_index* idx, int* enabled);
 int proqa_index_allow_rounding(proqa_index* idx, int allow);
@@ -112,8 +127,11 @@ int proqa_index_search_device(proqa_index* idx, const void* xq_dev, int64_t nq, 
 
 /* Two-step form of proqa_index_search_device for a caller that has more work to put on the stream behind the search
  * (the sharded search enqueues its all-gather and merge there).  _begin enqueues the whole search and returns WITHOUT
- * synchronising whenever it can (k <= 1024 outside the one-pass range; other searches run to completion inside
- * _begin).  Once the stream reaches that point D_dev / I_dev hold the result, provided no round overflowed its candidate
+ * synchronising or allocating whenever it can (k <= 1024 outside the one-pass range, float16 queries or float32 queries
+ * of an index already in exact-float32 mode, a workspace that fits -- i.e. not the first search of its size on the
+ * handle; other searches run to completion inside _begin).  It never builds the int8 copy of the rows: when that copy is
+ * missing or stale the search scans the fp16 rows (same result) and _finish builds the copy after its host wait
+ * (proqa_index_prepare builds it ahead of time).  Once the stream reaches that point D_dev / I_dev hold the result, provided no round overflowed its candidate
  * lists (a data-dependent, rare event): status_dev (optional device word, written on the stream) is then 0; 1 means
  * _finish is going to rewrite D_dev / I_dev.  _finish synchronises the stream, runs the overflow-safe re-scan if it is
  * needed (*rewritten = 1; D_dev / I_dev are final when it returns) and completes proqa_index_last_stats.  xq_dev, D_dev,
@@ -141,7 +159,9 @@ typedef struct proqa_search_stats {
   float total_ms;            /* HIP-event time of the whole search on the stream */
   int64_t nominated;         /* rows the int8 nomination rounds handed to the exact re-scoring (0 for an fp16 scan) */
   int32_t nomination;        /* 1 if the rounds of this search scanned the int8 copy of the rows, else 0 */
-  int32_t reserved;
+  int32_t nomination_state;  /* of the index after this search: 0 off (mode 0 / exact-float32), 1 on (the copy is, or will
+                                be, scanned by the searches it applies to), 2 suspended (the rows do not quantise, or a
+                                search over-nominated: fp16 scan until a re-probe succeeds or the rows change) */
 } proqa_search_stats;
 int proqa_index_last_stats(const proqa_index* idx, proqa_search_stats* out);
 /* bracket every mips_filter launch with HIP events on the search stream (bench.py roofline) */
@@ -157,9 +177,12 @@ int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
  * rounds scan an int8 copy of the centred, per-dimension-scaled rows at twice the fp16 MFMA rate, nominate every row whose
  * integer score exceeds the running threshold lowered by a rigorous bound on the quantisation error, and re-score the
  * nominated rows from the fp16 rows -- the result is the fp16 scan's, bit for bit.  mode 0: never (fp16 scan);
- * 1 (default): unless the first such search shows that the data does not quantise (then fp16 until the rows change);
- * 2: always.  The copy (+128 B per row) is built by the first search that uses it.  Rows adopted with
- * proqa_index_adopt_device must not be modified while the index holds them. */
+ * 1 (default, automatic): a search that re-scores more than max(4096, rows / 2048) rows per query or needs the
+ * overflow-safe path SUSPENDS the int8 rounds (fp16 scan); the 8th eligible search after that probes them again, a
+ * failed probe doubles the distance (16, 32, 64, 64, ...), a successful one resumes; a change of the rows starts afresh;
+ * every switch is one line on stderr when PROQA_LOG is set, and proqa_search_stats.nomination_state reports the state;
+ * 2: always.  The copy (+128 B per row) is built by proqa_index_prepare, or by the first search that wants it.  Rows
+ * adopted with proqa_index_adopt_device: see the immutability note there. */
 int proqa_index_configure_nomination(proqa_index* idx, int mode);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
@@ -444,6 +467,9 @@ int proqa_microbench_stream(void* buf_dev, size_t bytes, int kind, int reps, voi
 int proqa_microbench_mfma(double ms_target, int zero_operands, void* stream, double* tflops);
 /* the same loop on v_mfma_i32_32x32x32_i8 (the nomination scan's instruction); dense TOP/s */
 int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, double* tops);
+/* the same with the instruction shape as an argument: 0 = v_mfma_i32_32x32x32_i8 (the nomination scan's), 1 =
+ * v_mfma_i32_16x16x64_i8 (the shape MI355X_MICROARCH.md quotes its int8 ceiling for) */
+int proqa_microbench_mfma_i8_shape(double ms_target, int zero_operands, int shape, void* stream, double* tops);
 
 #ifdef __cplusplus
 }

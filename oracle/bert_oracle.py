@@ -49,38 +49,66 @@ def gelu_erf(x):
     return (0.5 * x * (1.0 + _erf(x / np.float32(math.sqrt(2.0))))).astype(np.float32)
 
 
-def bert_tower(sd, prefix, input_ids, input_mask, n_layers, n_heads, eps=1e-12, return_hidden=False):
-    """Pooled output [B, H] of one BertModel tower; sd maps HF key names to arrays."""
+def _round_f16(x):
+    """float32 -> nearest fp16 -> float32: what storing a tensor in fp16 does to it"""
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
+def _note(probe, key, x):
+    if probe is not None:
+        probe[key] = max(probe.get(key, 0.0), float(np.abs(x).max()))
+
+
+def bert_tower(sd, prefix, input_ids, input_mask, n_layers, n_heads, eps=1e-12, return_hidden=False, storage="fp32", probe=None):
+    """Pooled output [B, H] of one BertModel tower; sd maps HF key names to arrays.
+
+    storage="fp16": the same float32 arithmetic, but every tensor a mixed-precision run (apex O1: get_embed.py:122-129)
+    keeps in fp16 between two operations is rounded to fp16 there -- LayerNorm outputs, the Q / K / V projections, the
+    softmax weights entering the second attention product, the context rows, every dense layer's output, the GELU output.
+    Comparing a fp16 implementation with THIS variant separates the storage format's error (shared) from an
+    implementation's own.  probe (a dict): receives the largest |pre-softmax logit|, |FFN activation| (after GELU) and
+    |pre-LayerNorm dense output + residual| met on the way."""
+    if storage not in ("fp32", "fp16"):
+        raise ValueError(storage)
+    r = _round_f16 if storage == "fp16" else (lambda t: t)
     ids = np.asarray(input_ids)
     mask = np.asarray(input_mask).astype(bool)
     B, S = ids.shape
     e = prefix + ".embeddings."
     x = (_f32(sd[e + "word_embeddings.weight"])[ids] + _f32(sd[e + "token_type_embeddings.weight"])[0]
          + _f32(sd[e + "position_embeddings.weight"])[:S][None])
-    h = layer_norm(x, _f32(sd[e + "LayerNorm.weight"]), _f32(sd[e + "LayerNorm.bias"]), eps)
+    h = r(layer_norm(x, _f32(sd[e + "LayerNorm.weight"]), _f32(sd[e + "LayerNorm.bias"]), eps))
     H = h.shape[-1]
     dh = H // n_heads
     add_mask = np.where(mask, np.float32(0), np.finfo(np.float32).min).astype(np.float32)[:, None, None, :]
     hidden = [h]
+    zero = np.float32(0)
     for i in range(n_layers):
         p = f"{prefix}.encoder.layer.{i}."
 
         def heads(name):
-            y = linear(h, sd[p + f"attention.self.{name}.weight"], sd[p + f"attention.self.{name}.bias"])
+            # (fp16 storage: the projection is stored without its bias, the bias joins it in one more fp16 rounding)
+            y = r(r(linear(h, sd[p + f"attention.self.{name}.weight"], zero)) + _f32(sd[p + f"attention.self.{name}.bias"]))
             return y.reshape(B, S, n_heads, dh).transpose(0, 2, 1, 3)
 
         q, k, v = heads("query"), heads("key"), heads("value")
-        scores = (q @ k.transpose(0, 1, 3, 2)) * np.float32(1.0 / math.sqrt(dh)) + add_mask
+        scores = (q @ k.transpose(0, 1, 3, 2)) * np.float32(1.0 / math.sqrt(dh))
+        _note(probe, "max_abs_logit", np.where(mask[:, None, None, :], scores, zero))
+        scores = scores + add_mask
         scores = scores - scores.max(axis=-1, keepdims=True)
         probs = np.exp(scores, dtype=np.float32)
-        probs /= probs.sum(axis=-1, keepdims=True, dtype=np.float32)
-        ctx = (probs @ v).transpose(0, 2, 1, 3).reshape(B, S, H)
-        a = linear(ctx, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
-        h1 = layer_norm(a + h, _f32(sd[p + "attention.output.LayerNorm.weight"]),
-                        _f32(sd[p + "attention.output.LayerNorm.bias"]), eps)
-        f = gelu_erf(linear(h1, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
-        o = linear(f, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
-        h = layer_norm(o + h1, _f32(sd[p + "output.LayerNorm.weight"]), _f32(sd[p + "output.LayerNorm.bias"]), eps)
+        denom = probs.sum(axis=-1, keepdims=True, dtype=np.float32)
+        # (fp16 storage: the un-normalised weights are the fp16 operand of the second product, the sum stays float32)
+        ctx = r(((r(probs) @ v) / denom).transpose(0, 2, 1, 3).reshape(B, S, H))
+        a = r(linear(ctx, sd[p + "attention.output.dense.weight"], zero)) + _f32(sd[p + "attention.output.dense.bias"])
+        _note(probe, "max_abs_pre_layernorm", a + h)
+        h1 = r(layer_norm(a + h, _f32(sd[p + "attention.output.LayerNorm.weight"]),
+                          _f32(sd[p + "attention.output.LayerNorm.bias"]), eps))
+        f = r(gelu_erf(linear(h1, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"])))
+        _note(probe, "max_abs_ffn_activation", f)
+        o = r(linear(f, sd[p + "output.dense.weight"], zero)) + _f32(sd[p + "output.dense.bias"])
+        _note(probe, "max_abs_pre_layernorm", o + h1)
+        h = r(layer_norm(o + h1, _f32(sd[p + "output.LayerNorm.weight"]), _f32(sd[p + "output.LayerNorm.bias"]), eps))
         hidden.append(h)
     pooled = np.tanh(linear(h[:, 0], sd[prefix + ".pooler.dense.weight"], sd[prefix + ".pooler.dense.bias"]))
     if return_hidden:
@@ -88,8 +116,9 @@ def bert_tower(sd, prefix, input_ids, input_mask, n_layers, n_heads, eps=1e-12, 
     return pooled.astype(np.float32)
 
 
-def get_embed(sd, input_ids, input_mask, is_query_embed, n_layers, n_heads, eps=1e-12):
-    """{'embed': [B,128]} of retriever.py:33-43, as a bare array."""
+def get_embed(sd, input_ids, input_mask, is_query_embed, n_layers, n_heads, eps=1e-12, storage="fp32", probe=None):
+    """{'embed': [B,128]} of retriever.py:33-43, as a bare array (storage / probe: see bert_tower)."""
     tower, proj = ("bert_q", "proj_q") if is_query_embed else ("bert_c", "proj_c")
-    pooled = bert_tower(sd, tower, input_ids, input_mask, n_layers, n_heads, eps)
-    return linear(pooled, sd[proj + ".weight"], sd[proj + ".bias"])
+    pooled = bert_tower(sd, tower, input_ids, input_mask, n_layers, n_heads, eps, storage=storage, probe=probe)
+    out = linear(pooled, sd[proj + ".weight"], sd[proj + ".bias"])
+    return _round_f16(out) if storage == "fp16" else out

@@ -34,7 +34,7 @@ class ProqaError(RuntimeError):
 class SearchStats(ctypes.Structure):
     _fields_ = [("rounds", ctypes.c_int32), ("fallback_rounds", ctypes.c_int32),
                 ("candidates", ctypes.c_int64), ("filter_ms", c_float), ("total_ms", c_float),
-                ("nominated", ctypes.c_int64), ("nomination", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("nominated", ctypes.c_int64), ("nomination", ctypes.c_int32), ("nomination_state", ctypes.c_int32)]
 
 
 class BertLayer(ctypes.Structure):
@@ -73,6 +73,8 @@ SIGNATURES = {
     "proqa_index_add_npy": (c_int, [c_void_p, c_char_p, c_int64, c_int64, c_int]),
     "proqa_index_add_device": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "proqa_index_adopt_device": (c_int, [c_void_p, c_void_p, c_int64]),
+    "proqa_index_rows_changed": (c_int, [c_void_p]),
+    "proqa_index_prepare": (c_int, [c_void_p, c_void_p]),
     "proqa_index_allow_rounding": (c_int, [c_void_p, c_int]),
     "proqa_index_is_exact_f32": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "proqa_index_ntotal": (c_int, [c_void_p, ctypes.POINTER(c_int64)]),
@@ -151,6 +153,7 @@ SIGNATURES = {
     "proqa_microbench_stream": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "proqa_microbench_mfma": (c_int, [ctypes.c_double, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "proqa_microbench_mfma_i8": (c_int, [ctypes.c_double, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "proqa_microbench_mfma_i8_shape": (c_int, [ctypes.c_double, c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lock = threading.Lock()
@@ -211,7 +214,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.proqa_abi_version() != 5:
+        if lib.proqa_abi_version() != 6:
             raise RuntimeError("libproqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
         return lib

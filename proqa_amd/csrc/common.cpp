@@ -1,6 +1,7 @@
 // Error plumbing and device queries for libproqa_hip.so.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <random>
 #include <utility>
@@ -18,6 +19,24 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(error_buffer(), 512, fmt, ap);
   va_end(ap);
   return code;
+}
+
+bool log_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("PROQA_LOG");
+    return e && e[0] && !(e[0] == '0' && !e[1]);
+  }();
+  return on;
+}
+
+void log_line(const char* fmt, ...) {
+  if (!log_enabled()) return;
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "[proqa] %s\n", buf);
 }
 
 int device_cu_count() {

@@ -13,6 +13,10 @@ namespace proqa {
 // thread-local last-error message, surfaced through proqa_last_error()
 char* error_buffer();
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// one line on stderr ("[proqa] ...") when the environment variable PROQA_LOG is set to anything but "" / "0": decisions the
+// library takes on its own (which scan a search ran on, a suspended / resumed int8 copy); silent otherwise
+bool log_enabled();
+void log_line(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 
 inline int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return fail(PROQA_EHIP, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);

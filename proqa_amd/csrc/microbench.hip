@@ -94,6 +94,27 @@ __global__ __launch_bounds__(256) void mfma_loop_i8(int iters, int zero, int* __
   if (t == 0x12345678) *sink = t;
 }
 
+// the 16x16x64 form of the int8 instruction (v_mfma_i32_16x16x64_i8: 8 passes, the shape MI355X_MICROARCH.md quotes the
+// >= 3944 TOPS ceiling for): 4 chains of 4 accumulator registers each
+__global__ __launch_bounds__(256) void mfma_loop_i8_16x16x64(int iters, int zero, int* __restrict__ sink) {
+  i32x4 a, b;
+  for (int e = 0; e < 4; ++e) {
+    const unsigned h = (threadIdx.x * 2654435761u + e * 40503u + blockIdx.x * 97u);
+    a[e] = zero ? 0 : (int)(h * 2246822519u);
+    b[e] = zero ? 0 : (int)(h * 3266489917u + 12345u);
+  }
+  i32x4 c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c3, 0, 0, 0);
+  }
+  const i32x4 s = c0 + c1 + c2 + c3;
+  const int t = s[0] + s[1] + s[2] + s[3];
+  if (t == 0x12345678) *sink = t;
+}
+
 }  // namespace
 }  // namespace proqa
 
@@ -167,8 +188,9 @@ int proqa_microbench_mfma(double ms_target, int zero_operands, void* stream, dou
 }
 
 // the int8 rate of the same kind of loop (the nomination scan's instruction).  Result in TOP/s (2 x MAC).
-int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, double* tops) {
-  if (!tops || !(ms_target > 0)) return fail(PROQA_EINVAL, "microbench_mfma_i8: bad argument");
+// shape 0: v_mfma_i32_32x32x32_i8 (what mips_filter_i8 issues), 1: v_mfma_i32_16x16x64_i8.
+int proqa_microbench_mfma_i8_shape(double ms_target, int zero_operands, int shape, void* stream, double* tops) {
+  if (!tops || !(ms_target > 0) || shape < 0 || shape > 1) return fail(PROQA_EINVAL, "microbench_mfma_i8: bad argument");
   hipStream_t st = as_stream(stream);
   hipEvent_t e0, e1;
   PROQA_HIP(hipEventCreate(&e0));
@@ -176,12 +198,16 @@ int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, 
   int* sink = nullptr;
   PROQA_HIP(hipMalloc((void**)&sink, 4));
   const unsigned grid = (unsigned)device_cu_count() * 2;
-  int iters = (int)(ms_target * 1e-3 * 2.4e9 / (4 * 2 * 32));
+  // (a 16x16x64 instruction is half the passes of a 32x32x32 one: twice the iterations for the same launch length)
+  int iters = (int)(ms_target * 1e-3 * 2.4e9 / (4 * 2 * 32)) * (shape == 1 ? 2 : 1);
   if (iters < 64) iters = 64;
   float best = 1e30f;
   for (int r = 0; r < 4; ++r) {
     PROQA_HIP(hipEventRecord(e0, st));
-    hipLaunchKernelGGL(mfma_loop_i8, dim3(grid), dim3(256), 0, st, iters, zero_operands, sink);
+    if (shape == 1)
+      hipLaunchKernelGGL(mfma_loop_i8_16x16x64, dim3(grid), dim3(256), 0, st, iters, zero_operands, sink);
+    else
+      hipLaunchKernelGGL(mfma_loop_i8, dim3(grid), dim3(256), 0, st, iters, zero_operands, sink);
     PROQA_HIP(hipEventRecord(e1, st));
     PROQA_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -191,9 +217,13 @@ int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, 
   (void)hipFree(sink);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  const double ops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*chains*/ * 2.0 * 32 * 32 * 32;
+  const double ops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*chains*/ * 2.0 * (shape == 1 ? 16.0 * 16 * 64 : 32.0 * 32 * 32);
   *tops = ops / (best * 1e-3) / 1e12;
   return PROQA_OK;
+}
+
+int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, double* tops) {
+  return proqa_microbench_mfma_i8_shape(ms_target, zero_operands, 0, stream, tops);
 }
 
 }  // extern "C"

@@ -101,7 +101,12 @@ struct proqa_index {
   uint64_t rows_epoch = 1;                 // bumped by every change of the rows
   uint64_t q8_epoch = 0;                   // rows_epoch the int8 copy was built for (0: never)
   bool q8_usable = false;                  // that copy can be scanned (finite statistics)
-  bool q8_unprofitable = false;            // a search on this copy nominated far too many rows: fp16 scan until the rows change
+  bool q8_unprofitable = false;            // a search on this copy nominated far too many rows: the int8 rounds are SUSPENDED (fp16 scan)
+  // ... until a re-probe succeeds: the q8_probe_after-th eligible search after the suspension runs the int8 rounds again;
+  // a probe that fails doubles the distance (8, 16, 32, 64, 64, ...), one that succeeds lifts the suspension
+  int q8_suspended_searches = 0;           // eligible searches that ran on the fp16 rows since the suspension / the last failed probe
+  int q8_probe_after = 0;
+  bool q8_build_due = false;               // an enqueued (begin / finish) search wanted the int8 copy: _finish builds it
   int nominate_mode = 1;                   // 0 off, 1 automatic, 2 always (no profitability check); proqa_index_configure_nomination
   bool q8_active = false;                  // the search being enqueued runs its rounds on the int8 copy
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
@@ -241,10 +246,18 @@ int ensure_stage(proqa_index* idx, size_t bytes) {
 constexpr int64_t kNominateMinRows = 65536;   // smaller shards are launch-bound either way
 constexpr int kNominateMaxK = 128;            // nominations of a round (~3 x its candidates) must fit one merge
 constexpr unsigned kNominateLaneCap = 32;     // records per lane list of an int8 round (no spill log: a full list re-scans the round)
+// may the rounds of a top-k search of this index scan an int8 copy at all (mode, precision mode, k, shard size)?
+bool nomination_eligible(const proqa_index* idx, int k) {
+  const bool always = idx->nominate_mode == 2;
+  return idx->nominate_mode != 0 && !idx->exact && k <= kNominateMaxK && idx->n >= (always ? 4 * kStageRows : kNominateMinRows);
+}
 int ensure_q8(proqa_index* idx, hipStream_t st) {
   if (idx->q8_epoch == idx->rows_epoch) return PROQA_OK;
   idx->q8_usable = false;
   idx->q8_unprofitable = false;
+  idx->q8_suspended_searches = 0;
+  idx->q8_probe_after = 0;
+  idx->q8_build_due = false;
   if (!idx->col) {
     PROQA_HIP(hipMalloc((void**)&idx->col, 3 * kDim * sizeof(float)));
     PROQA_HIP(hipMalloc((void**)&idx->col_partial, (size_t)kColStatGroups * 3 * kDim * sizeof(float)));
@@ -1126,13 +1139,38 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
 // after the host sync of a search whose rounds ran on the int8 copy: statistics, and the profitability check -- a corpus
 // whose scores the eight bits cannot separate (nominations per query and row far above what pays for the halved scan) goes
 // back to the fp16 scan until its rows change.  Exactness never depends on this: every nominated row is re-scored.
+constexpr int kProbeAfterFirst = 8, kProbeAfterMost = 64;
+int nomination_state_of(const proqa_index* idx) {   // proqa_search_stats::nomination_state
+  if (idx->nominate_mode == 0 || idx->exact) return 0;
+  if (idx->q8_epoch == idx->rows_epoch && (!idx->q8_usable || (idx->q8_unprofitable && idx->nominate_mode != 2))) return 2;
+  return 1;
+}
 void note_nomination(proqa_index* idx, int64_t nq) {
+  idx->stats.nomination_state = nomination_state_of(idx);
   if (!idx->q8_active) return;
   idx->q8_active = false;
   idx->stats.nomination = 1;
   idx->stats.nominated = (int64_t)idx->mirror->nominated;
   const double per_query = (double)idx->stats.nominated / (double)std::max<int64_t>(nq, 1);
-  if (per_query > std::max(4096.0, (double)idx->n / 2048.0) || idx->stats.fallback_rounds > 0) idx->q8_unprofitable = true;
+  const double limit = std::max(4096.0, (double)idx->n / 2048.0);
+  const bool bad = per_query > limit || idx->stats.fallback_rounds > 0;
+  if (bad) {
+    // One such batch may be an outlier (an adversarial or degenerate set of queries) on rows that quantise well: the
+    // suspension is lifted by a later search that passes.  First probe after 8 eligible searches, then 16, 32, 64, 64, ...
+    idx->q8_probe_after = idx->q8_unprofitable ? std::min(2 * std::max(idx->q8_probe_after, kProbeAfterFirst), kProbeAfterMost)
+                                               : kProbeAfterFirst;
+    idx->q8_suspended_searches = 0;
+    log_line("index %p: int8 nomination scan %s (%.0f rows re-scored per query against a limit of %.0f, %d overflow-safe rounds): "
+             "fp16 scan for the next %d eligible searches", (void*)idx, idx->q8_unprofitable ? "stays suspended" : "suspended", per_query,
+             limit, idx->stats.fallback_rounds, idx->q8_probe_after - 1);
+    idx->q8_unprofitable = true;
+  } else if (idx->q8_unprofitable && idx->nominate_mode != 2) {
+    log_line("index %p: int8 nomination scan resumed (%.0f rows re-scored per query)", (void*)idx, per_query);
+    idx->q8_unprofitable = false;
+    idx->q8_suspended_searches = 0;
+    idx->q8_probe_after = 0;
+  }
+  idx->stats.nomination_state = nomination_state_of(idx);
 }
 
 int finish_pending(proqa_index* idx, int* rewritten);
@@ -1170,6 +1208,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   if (dtype != PROQA_F16 && dtype != PROQA_F32) return fail(PROQA_EINVAL, "search: bad dtype %d", dtype);
   if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
   idx->stats = {};
+  idx->stats.nomination_state = nomination_state_of(idx);
   idx->q8_active = false;
   if (nq == 0) return PROQA_OK;
   PROQA_ON_DEVICE(idx->device);
@@ -1228,11 +1267,25 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
     // Batches of <= 256 queries (one query block per wave: the HBM-bound regime) take it too -- the int8 rows are half the
     // bytes of the stream (one question over 18M rows: 0.89 -> 0.65 ms, 256 queries 1.48 -> 1.01 ms).
     // (mode 2, "always", also takes small shards: tests and experiments)
-    const bool always = idx->nominate_mode == 2;
-    if (idx->nominate_mode == 0 || idx->exact || k > kNominateMaxK || idx->n < (always ? 4 * kStageRows : kNominateMinRows))
-      return PROQA_OK;
-    if (int rc = ensure_q8(idx, st)) return rc;
-    if (!idx->q8_usable || (idx->q8_unprofitable && idx->nominate_mode != 2)) return PROQA_OK;
+    if (!nomination_eligible(idx, k)) return PROQA_OK;
+    if (idx->q8_epoch != idx->rows_epoch) {
+      // the int8 copy is missing or stale.  A search that runs to completion in this call builds it here (allocation, two
+      // passes over the rows, one host read).  An ENQUEUED search (_begin) must not synchronise or allocate: it scans
+      // the fp16 rows and leaves the build to its _finish, i.e. to the host wait the caller pays anyway
+      // (proqa_index_prepare does the same ahead of time).
+      if (defer) {
+        idx->q8_build_due = true;
+        return PROQA_OK;
+      }
+      if (int rc = ensure_q8(idx, st)) return rc;
+    }
+    if (!idx->q8_usable) return PROQA_OK;
+    if (idx->q8_unprofitable && idx->nominate_mode != 2) {
+      // suspended (note_nomination): every q8_probe_after-th eligible search tries the int8 rounds again
+      if (++idx->q8_suspended_searches < idx->q8_probe_after) return PROQA_OK;
+      log_line("index %p: re-probing the int8 nomination scan after %d searches on the fp16 rows", (void*)idx,
+               idx->q8_suspended_searches);
+    }
     PROQA_HIP(launch_prep_queries_i8(idx->xq_pad, idx->ws_nq_pad, idx->col, idx->qstats, idx->xq8, idx->qparams, idx->stat_nom, st));
     idx->q8_active = true;
     return PROQA_OK;
@@ -1349,6 +1402,14 @@ int finish_pending(proqa_index* idx, int* rewritten) {
   (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
   note_nomination(idx, pe.nq);
   if (rewritten) *rewritten = fallback != 0;
+  // the enqueued search found no current int8 copy of the rows and ran on the fp16 rows: build the copy now, behind the
+  // host wait this call is anyway, so that the next search scans it
+  if (idx->q8_build_due) {
+    idx->q8_build_due = false;
+    if (nomination_eligible(idx, pe.k))
+      if (int rc = ensure_q8(idx, pe.st)) return rc;
+    idx->stats.nomination_state = nomination_state_of(idx);
+  }
   return PROQA_OK;
 }
 
@@ -1464,6 +1525,27 @@ int proqa_index_configure_nomination(proqa_index* idx, int mode) {
   if (!idx) return fail(PROQA_EINVAL, "index_configure_nomination: NULL handle");
   if (mode < 0 || mode > 2) return fail(PROQA_EINVAL, "index_configure_nomination: mode=%d (0 off, 1 automatic, 2 always)", mode);
   idx->nominate_mode = mode;
+  return PROQA_OK;
+}
+
+int proqa_index_prepare(proqa_index* idx, void* stream) {
+  if (!idx) return fail(PROQA_EINVAL, "index_prepare: NULL handle");
+  if (idx->pending.active) return fail(PROQA_EINVAL, "index_prepare: a search begun on this handle has not been finished");
+  PROQA_ON_DEVICE(idx->device);
+  hipStream_t st = as_stream(stream);
+  idx->q8_build_due = false;
+  if (nomination_eligible(idx, 1))
+    if (int rc = ensure_q8(idx, st)) return rc;
+  PROQA_HIP(hipStreamSynchronize(st));
+  return PROQA_OK;
+}
+
+int proqa_index_rows_changed(proqa_index* idx) {
+  if (!idx) return fail(PROQA_EINVAL, "index_rows_changed: NULL handle");
+  if (idx->pending.active) return fail(PROQA_EINVAL, "index_rows_changed: a search begun on this handle has not been finished");
+  if (idx->exact) return fail(PROQA_EINVAL, "index_rows_changed: the index keeps float32 copies of its rows (exact-float32 mode); "
+                                            "reset it and add the rows again");
+  ++idx->rows_epoch;
   return PROQA_OK;
 }
 

@@ -757,25 +757,24 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
       a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
     return;
   }
-  // The block constants {G_b, X_b} of a pair's eight units are wave-uniform: ONE scalar load of 64 bytes per pair, issued a
-  // pair ahead (hipcc turns `a.blk[i]` into a vector load per unit -- a memory round trip inside every unit, and one more
-  // operation in the counted vmcnt).  The load is asynchronous (lgkmcnt): the wait that makes it readable is the
-  // `lgkmcnt(0)` below, tied to the registers by an in/out operand so that no use is scheduled above it.  (An outstanding
-  // scalar load only makes hipcc's own counted lgkmcnt waits for the fragment reads stricter, never laxer.)
+  // The block constants {G_b, X_b} of a pair's eight units are wave-uniform: ONE scalar load of 64 bytes per pair (hipcc
+  // turns `a.blk[i]` into a vector load per unit -- a memory round trip inside every unit, and one more operation in the
+  // counted vmcnt).  It is an ordinary load through a wave-uniform pointer into the constant address space, so the
+  // compiler emits s_load_dwordx16 AND owns its lgkmcnt accounting (an inline-asm s_load left the wait to a hand-placed
+  // s_waitcnt and the destination SGPRs to register allocation's good will: advisor finding, round 5).  Requested right
+  // before the pair's barrier: scalar loads return out of order with LDS reads, so any lgkmcnt wait for a fragment read is
+  // a wait for this load too -- at the barrier the wave waits anyway, mid-pair (the former place) every wave stalled for
+  // the scalar round trip behind its unit 2.
   auto load_blocks = [&](int p) {
     const unsigned long long addr = (unsigned long long)(a.blk + (row_begin >> 5) + 8ll * p);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)addr);
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(addr >> 32));
     const unsigned long long uaddr = ((unsigned long long)hi << 32) | lo;
-    f32x16 v;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(v) : "s"(uaddr) : "memory");
-    return v;
+    return *(const __attribute__((address_space(4))) f32x16*)uaddr;
   };
-  f32x16 bc_next = load_blocks(0);
   for (int p = 0; p < npairs; ++p) {
+    const f32x16 bc = load_blocks(p);
     publish();
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(bc_next)::"memory");
-    const f32x16 bc = bc_next;
     if (p + 1 < npairs) issue_pair(p + 1);
     const char* base = lds + (p & 1) * 2 * kStageBytesI8;
     const int nunits = (nstages - 2 * p >= 2 ? 2 : 1) * (kStageRows / kSubRows);
@@ -785,9 +784,6 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (u == 4 && nunits <= 4) break;   // (the chunk's last pair may hold one stage)
-      // (the next pair's constants: requested mid-pair, not next to the first fragment reads behind the barrier, whose
-      // lgkmcnt(0) would wait for the scalar load as well)
-      if (u == 2 && p + 1 < npairs) bc_next = load_blocks(p + 1);
       const char* nxt = base + (u + 1 < nunits ? u + 1 : u) * kSubBytesI8;
       i32x16 acc[QW];
 #pragma unroll
@@ -1046,7 +1042,10 @@ __global__ __launch_bounds__(256) void prep_queries_i8(const _Float16* __restric
     // offset, i.e. taken off the threshold.  (No term for fp16 subnormal operands: v_mfma_f32_32x32x16_f16 multiplies them as
     // their values on gfx950 -- scripts/native/mfma_f16_subnormal_probe.cpp -- so the exact score is the sum the bound is
     // about; with the term the exact-float32 mode carries for that case, corpora of values around 1e-3 nominated every row.)
-    const float delta = 0x1p-16f * n_q * Xf + 0x1p-20f * abs_off;
+    // 2^-14 ||q|| max||x||: four times the round-to-nearest worst case of the 127 additions and of the products' own
+    // roundings (2^-17 sum |q_d x_d| each, Cauchy-Schwarz) -- the matrix unit's internal accumulation is not documented as
+    // round-to-nearest per step; if it truncates, the worst case doubles.  ~0.01 score units against a margin of ~2.4.
+    const float delta = 0x1p-14f * n_q * Xf + 0x1p-20f * abs_off;
     NominateParams p;
     p.off = (float)off + delta + __builtin_fabsf((float)off) * 0x1p-22f;
     p.inv_unit = inv;                                          // (0 for a zero query: A = 0, every row with acc = 0 > -B passes)

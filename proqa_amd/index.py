@@ -108,7 +108,11 @@ class IndexFlatIP:
                                                         _lib.current_stream_ptr()))
 
     def adopt_device(self, xb):
-        """Search caller-owned fp16 rows in place (no copy); the tensor is kept alive here."""
+        """Search caller-owned fp16 rows in place (no copy); the tensor is kept alive here.
+
+        The rows must not change while adopted: searches of k <= 128 over >= 65536 rows scan an int8 copy of them
+        (+128 B per row) that is built once.  After writing into the tensor call `rows_changed()` -- or switch the copy
+        off with `configure_nomination("off")`; otherwise results can silently miss rows."""
         import torch
         if not (xb.is_cuda and xb.dtype == torch.float16 and xb.is_contiguous() and xb.dim() == 2
                 and xb.shape[1] == self.d):
@@ -116,6 +120,17 @@ class IndexFlatIP:
         torch.cuda.current_stream().synchronize()
         _lib.check(self._lib.proqa_index_adopt_device(self._h, xb.data_ptr(), xb.shape[0]))
         self._adopted = xb
+
+    def rows_changed(self):
+        """The adopted tensor was modified in place: the int8 copy of the rows is rebuilt before its next use."""
+        _lib.check(self._lib.proqa_index_rows_changed(self._h))
+
+    def prepare(self):
+        """Build now what the first search would otherwise build (the int8 copy of the rows: 128 B per row, ~3 ms per
+        18M rows, one host wait).  Optional; `search` / `search_device` build it on demand, the enqueued search of
+        ShardedIndexFlatIP leaves it to the end of its first step."""
+        import torch
+        _lib.check(self._lib.proqa_index_prepare(self._h, _lib.current_stream_ptr() if torch.cuda.is_available() else None))
 
     def search_device(self, xq, k, idx_offset=0, out=None):
         """CUDA tensor in, CUDA tensors out: (D float32 [nq,k], I int64 [nq,k]); `out` = (D, I) to write into."""
@@ -165,7 +180,8 @@ class IndexFlatIP:
         _lib.check(self._lib.proqa_index_last_stats(self._h, ctypes.byref(st)))
         return {"rounds": st.rounds, "fallback_rounds": st.fallback_rounds, "candidates": st.candidates,
                 "filter_ms": st.filter_ms, "total_ms": st.total_ms, "nominated": st.nominated,
-                "nomination": bool(st.nomination)}
+                "nomination": bool(st.nomination),
+                "nomination_state": ("off", "on", "suspended")[st.nomination_state] if 0 <= st.nomination_state <= 2 else None}
 
     def set_profiling(self, enable=True):
         _lib.check(self._lib.proqa_index_set_profiling(self._h, 1 if enable else 0))
@@ -194,7 +210,9 @@ class IndexFlatIP:
 
     def configure_nomination(self, mode):
         """The int8 nomination scan of the k <= 128 rounds (see proqa_hip.h): 0 / "off" = fp16 scan only, 1 / "auto"
-        (default), 2 / "always".  The result is the fp16 scan's either way."""
+        (default: a search that over-nominates suspends the int8 rounds, later searches re-probe them; `last_stats()
+        ["nomination_state"]`, one stderr line per switch under PROQA_LOG=1), 2 / "always".  The result is the fp16
+        scan's either way."""
         mode = {"off": 0, "auto": 1, "always": 2}.get(mode, mode)
         _lib.check(self._lib.proqa_index_configure_nomination(self._h, int(mode)))
 
@@ -307,12 +325,19 @@ class ShardedIndexFlatIP:
         self._index.add_npy(path, self.lo, self.hi - self.lo, readers)
 
     def adopt_local(self, xb_local):
-        """Search this rank's rows [lo, hi) in place: a contiguous CUDA fp16 tensor, not copied."""
+        """Search this rank's rows [lo, hi) in place: a contiguous CUDA fp16 tensor, not copied (and not to be modified
+        while adopted: see IndexFlatIP.adopt_device / rows_changed)."""
         if self._index is None:
             raise RuntimeError("adopt_local is only available with the built-in HIP searcher")
         if xb_local.shape[0] != self.hi - self.lo:
             raise ValueError(f"rank {self.rank} holds rows [{self.lo}, {self.hi}), got {xb_local.shape[0]} rows")
         self._index.adopt_device(xb_local)
+
+    def prepare(self):
+        """Every rank builds the int8 copy of its shard now (IndexFlatIP.prepare) instead of at the end of its first
+        search step."""
+        if self._index is not None:
+            self._index.prepare()
 
     @property
     def local_index(self):

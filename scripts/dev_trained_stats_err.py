@@ -24,8 +24,12 @@ for seed in [int(v) for v in sys.argv[1:]] or [0, 1, 2]:
     mask = np.ones((512, 128), bool)
     batch = {"input_ids": torch.from_numpy(ids).to(dev), "input_mask": torch.from_numpy(mask).to(dev)}
     ref = bert_oracle.get_embed(sd_np, ids[:n_ref], mask[:n_ref], False, 12, 12)
+    ref16 = bert_oracle.get_embed(sd_np, ids[:n_ref], mask[:n_ref], False, 12, 12, storage="fp16")
+    print(f"seed {seed}: fp16-storage oracle vs fp32 oracle {np.abs(ref16 - ref).max() / np.abs(ref).max():.2e}")
     for cls_only, packed in ((True, True), (False, False)):
         model.cls_only_last_layer, model.pack_tokens = cls_only, packed
         got = model.get_embed(batch, False)["embed"].float().cpu().numpy()
         rel = np.abs(got[:n_ref] - ref).max() / np.abs(ref).max()
-        print(f"seed {seed} cls_only {cls_only} packed {packed}: max rel err {rel:.2e}  worst cosine {cosine(got[:n_ref], ref).min():.6f}")
+        rel16 = np.abs(got[:n_ref] - ref16).max() / np.abs(ref).max()
+        print(f"seed {seed} cls_only {cls_only} packed {packed}: max rel err {rel:.2e} (vs the fp16-storage oracle {rel16:.2e})  "
+              f"worst cosine {cosine(got[:n_ref], ref).min():.6f}")

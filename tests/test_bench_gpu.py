@@ -58,6 +58,17 @@ def test_the_full_line_fits_the_drivers_tail(gpu_device):
                 "float32_index", "encode", "recall_parity"):
         assert key in line, key
     assert line["roofline"]["nomination"] == "int8" and line["fp16_scan"]["ids_equal"] and line["fp16_scan"]["scores_equal"]
+    # the headline fraction is priced against the peak of the instruction that ran (int8 MFMA), the fp16-equivalent figure
+    # beside it; the re-scoring gather and the non-filter part of the step are reported
+    rf = line["roofline"]
+    assert rf["peak"] == 5000.0 and rf["unit"] == "TOP/s" and rf["instruction"] == "v_mfma_i32_32x32x32_i8"
+    assert abs(rf["frac"] - rf["achieved"] / 5000.0) < 1e-3 * rf["frac"]
+    assert abs(rf["fp16_equivalent_frac"] - 2.0 * rf["frac"]) < 1e-3 * rf["fp16_equivalent_frac"]
+    assert rf["hbm_bytes_per_row_scanned"] == 128 and rf["rescore_gather_bytes"] > 0 and rf["chain_ms_per_search"] > 0
+    assert line["fp16_scan"]["frac"] > 0
+    for key in ("mfma_i8_TOPs_8ms_random_operands", "mfma_i8_TOPs_8ms_zero_operands", "mfma_i8_16x16x64_TOPs_8ms_random",
+                "mfma_f16_TFLOPs_8ms_random_operands"):
+        assert line["peak_measured"][key] > 100.0, key
     assert line["encode"]["gemm_kernel"]
 
 

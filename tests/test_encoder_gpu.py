@@ -365,11 +365,19 @@ def trained_like_state_dict(seed=0):
     return {k: v.half().float() for k, v in sd.items()}
 
 
+# max |kernels - fp16-storage oracle| / max |oracle| under trained-model statistics (see the test below)
+TRAINED_STATS_REL16 = 2e-3
+
+
 def test_trained_model_statistics_do_not_break_fp16(gpu_device):
     """Encoder parity where fp16 storage could bite (every other encoder test runs N(0, 0.02) weights, activations O(1)):
     outlier channels, attention logits of +-60, FFN activations in the hundreds, pre-LayerNorm GEMM outputs beyond 1e3.
     A full 512 x 128 batch and a packed variable-length batch against oracle/bert_oracle.py (float32) on their first rows:
-    cosine >= 0.9999 AND max relative error <= 1e-2 (an absolute tolerance says nothing at these magnitudes), all finite.
+    cosine >= 0.9999 AND max relative error <= 1e-2 (an absolute tolerance says nothing at these magnitudes), all finite --
+    and <= 2e-3 against the SAME oracle with every stored activation rounded to fp16 (bert_oracle storage="fp16": apex O1's
+    storage format, float32 arithmetic): the gap between the two bounds is the format's error, not the kernels'.  The probe
+    asserts that the regime is reached inside the oracle: logits beyond +-60, GELU outputs beyond 200, pre-LayerNorm sums
+    beyond 1e3.
     The relative error of this regime is a noisy quantity: 1.5e-3 .. 4.9e-3 over four weight seeds (scripts/dev_trained_stats_err.py;
     1.8e-3 .. 8.2e-3 with the all-keys-in-LDS attention kernel of rounds 1-4, worst cosine 0.99995), so the bound sits above
     the range, not on one seed's value.
@@ -387,8 +395,12 @@ def test_trained_model_statistics_do_not_break_fp16(gpu_device):
     # what the statistics do inside the oracle: the regime the docstring promises is really reached
     ids_probe = rng.integers(1000, 30522, (2, 128))
     ids_probe[:, 0], ids_probe[:, -1] = 101, 102
-    hidden = bert_oracle.bert_tower(sd_np, "bert_c", ids_probe, np.ones((2, 128), bool), 12, 12, return_hidden=True)[1]
+    probe = {}
+    hidden = bert_oracle.bert_tower(sd_np, "bert_c", ids_probe, np.ones((2, 128), bool), 12, 12, return_hidden=True, probe=probe)[1]
     assert max(float(np.abs(h).max()) for h in hidden) > 20.0                       # outlier channels after LayerNorm
+    assert probe["max_abs_logit"] > 60.0, probe                                      # pre-softmax attention logits
+    assert probe["max_abs_ffn_activation"] > 200.0, probe                            # GELU outputs
+    assert probe["max_abs_pre_layernorm"] > 1000.0, probe                            # dense output + residual entering a LayerNorm
     for B, S, lens in ((512, 128, None), (64, 128, rng.integers(9, 129, 64))):
         ids = rng.integers(1000, 30522, (B, S))
         mask = np.ones((B, S), bool)
@@ -402,13 +414,21 @@ def test_trained_model_statistics_do_not_break_fp16(gpu_device):
             ids[:, -1] = 102
         batch = {"input_ids": torch.from_numpy(ids).to(gpu_device), "input_mask": torch.from_numpy(mask).to(gpu_device)}
         ref = bert_oracle.get_embed(sd_np, ids[:n_ref], mask[:n_ref], False, 12, 12)
+        # the same float32 arithmetic with every stored activation rounded to fp16 (apex O1's storage): the error the FORMAT
+        # causes is shared with it, what is left against it is the kernels' own
+        ref16 = bert_oracle.get_embed(sd_np, ids[:n_ref], mask[:n_ref], False, 12, 12, storage="fp16")
+        fmt = np.abs(ref16 - ref).max() / np.abs(ref).max()
         for cls_only, packed in ((True, True), (False, False)):
             model.cls_only_last_layer, model.pack_tokens = cls_only, packed
             got = model.get_embed(batch, False)["embed"].float().cpu().numpy()
             assert np.isfinite(got).all()
             rel = np.abs(got[:n_ref] - ref).max() / np.abs(ref).max()
+            rel16 = np.abs(got[:n_ref] - ref16).max() / np.abs(ref).max()
+            print(f"trained statistics B={B} cls_only={cls_only} packed={packed}: vs fp32 oracle {rel:.2e}, vs fp16-storage oracle "
+                  f"{rel16:.2e}, fp16-storage vs fp32 oracle {fmt:.2e}")
             assert cosine(got[:n_ref], ref).min() >= 0.9999, (B, cls_only, packed, cosine(got[:n_ref], ref).min())
             assert rel <= 1e-2, (B, cls_only, packed, rel)
+            assert rel16 <= TRAINED_STATS_REL16, (B, cls_only, packed, rel16, fmt)
 
 
 @pytest.mark.parametrize("lens", [[9], [30], [5, 17, 30, 12], [20] * 6 + [8], [33, 31, 32, 32]])

@@ -149,6 +149,7 @@ def test_data_that_does_not_quantise_goes_back_to_the_fp16_scan(gpu_device):
         stats.append(ix.last_stats())
     assert stats[0]["nomination"] and (stats[0]["fallback_rounds"] > 0 or stats[0]["nominated"] > nq * 4096)
     assert not stats[1]["nomination"] and stats[1]["fallback_rounds"] == 0
+    assert stats[0]["nomination_state"] == stats[1]["nomination_state"] == "suspended"
     ix.add(xb[:1000])                                        # the rows changed: the copy is rebuilt, the verdict forgotten
     D, I = ix.search_device(tq, k)
     assert ix.last_stats()["nomination"]
@@ -272,3 +273,200 @@ def test_automatic_mode_picks_the_scan_by_shape(gpu_device):
     assert f32.exact_f32
     f32.search_device(torch.from_numpy(_int_corpus(rng, 300)).cuda(), 80)
     assert not f32.last_stats()["nomination"]
+
+
+def _zero_queries(nq):
+    return np.zeros((nq, 128), np.float16)
+
+
+def test_a_suspended_scan_is_probed_again_and_resumes(gpu_device):
+    """Automatic mode is not sticky: ONE batch that over-nominates (all-zero queries: every row's integer score ties with the
+    threshold, every row is nominated, the lists overflow) suspends the int8 rounds -- the next seven eligible searches run
+    on the fp16 rows, the eighth probes the int8 rounds again and, the rows being perfectly quantisable, resumes them.  A
+    probe that fails doubles the distance to the next one (8, 16, ...).  Every result is the oracle's either way."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(53)
+    n, nq, k = 70000, 300, 80
+    xb = _int_corpus(rng, n)
+    ix = IndexFlatIP(128)
+    ix.add(xb)
+    bad = torch.from_numpy(_zero_queries(nq)).cuda()
+    Dz, Iz = search_oracle.topk_ip(_zero_queries(nq), xb, k)
+
+    def search_bad():
+        D, I = ix.search_device(bad, k)
+        np.testing.assert_array_equal(I.cpu().numpy(), Iz)
+        np.testing.assert_array_equal(D.cpu().numpy(), Dz)
+        return ix.last_stats()
+
+    def search_good(seed):
+        xq = _int_corpus(np.random.default_rng(seed), nq)
+        D, I = ix.search_device(torch.from_numpy(xq).cuda(), k)
+        Do, Io = search_oracle.topk_ip(xq, xb, k)
+        np.testing.assert_array_equal(I.cpu().numpy(), Io)
+        np.testing.assert_array_equal(D.cpu().numpy(), Do)
+        return ix.last_stats()
+
+    st = search_good(0)
+    assert st["nomination"] and st["nomination_state"] == "on" and st["fallback_rounds"] == 0
+    st = search_bad()
+    assert st["nomination"] and st["nomination_state"] == "suspended"
+    assert st["fallback_rounds"] > 0 or st["nominated"] > nq * 4096
+    seen = [search_good(100 + i) for i in range(20)]
+    # searches 1-7 after the suspension: fp16 rows; the 8th probes and resumes; from then on the int8 rounds again
+    assert [s["nomination"] for s in seen] == [False] * 7 + [True] * 13
+    assert [s["nomination_state"] for s in seen] == ["suspended"] * 7 + ["on"] * 13
+    assert all(s["fallback_rounds"] == 0 for s in seen)
+    # a probe that fails: suspended again, the next probe twice as far away
+    assert search_bad()["nomination_state"] == "suspended"
+    pattern = [search_bad()["nomination"] for _ in range(8 + 16)]
+    assert pattern == [False] * 7 + [True] + [False] * 15 + [True]
+    # ... and the rows changing starts afresh
+    ix.add(xb[:1000])
+    xq = _int_corpus(np.random.default_rng(7), nq)
+    D, I = ix.search_device(torch.from_numpy(xq).cuda(), k)
+    assert ix.last_stats()["nomination"] and ix.last_stats()["nomination_state"] == "on"
+    np.testing.assert_array_equal(I.cpu().numpy(), search_oracle.topk_ip(xq, np.concatenate([xb, xb[:1000]]), k)[1])
+
+
+def test_the_switches_of_the_automatic_mode_are_logged(gpu_device):
+    """PROQA_LOG=1: one stderr line when the int8 rounds are suspended, one when a probe starts, one when they resume."""
+    import subprocess
+    import sys
+    import os
+    code = r"""
+import numpy as np, torch
+from proqa_amd.index import IndexFlatIP
+rng = np.random.default_rng(1)
+xb = rng.integers(-4, 5, (70000, 128)).astype(np.float16)
+ix = IndexFlatIP(128); ix.add(xb)
+good = torch.from_numpy(rng.integers(-4, 5, (300, 128)).astype(np.float16)).cuda()
+ix.search_device(good, 80)
+ix.search_device(torch.zeros((300, 128), dtype=torch.float16, device="cuda"), 80)
+for _ in range(8):
+    ix.search_device(good, 80)
+print(ix.last_stats()["nomination_state"])
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PROQA_LOG="1", PYTHONPATH=root), capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.strip().splitlines()[-1] == "on"
+    lines = [ln for ln in p.stderr.splitlines() if ln.startswith("[proqa] ")]
+    assert sum("int8 nomination scan suspended" in ln for ln in lines) == 1, lines
+    assert sum("re-probing the int8 nomination scan" in ln for ln in lines) == 1, lines
+    assert sum("int8 nomination scan resumed" in ln for ln in lines) == 1, lines
+    q = subprocess.run([sys.executable, "-c", code], env=dict({k_: v for k_, v in os.environ.items() if k_ != "PROQA_LOG"},
+                                                             PYTHONPATH=root), capture_output=True, text=True, timeout=600, cwd=root)
+    assert q.returncode == 0 and "[proqa]" not in q.stderr
+
+
+def test_an_enqueued_search_never_builds_the_copy_its_finish_does(gpu_device):
+    """proqa_index_search_begin_device keeps its contract on a fresh index: it returns while the stream is still busy with
+    the work enqueued before it (no synchronisation, no allocation of the int8 copy), the search runs on the fp16 rows with
+    status word 0, and _finish -- the host wait the caller pays anyway -- builds the copy: the second enqueued search scans
+    it.  proqa_index_prepare builds it ahead of time instead."""
+    import ctypes
+    import torch
+    from proqa_amd import _lib
+    from proqa_amd.index import IndexFlatIP
+    lib = _lib.load()
+    rng = np.random.default_rng(59)
+    n, nq, k = 70000, 300, 80
+    xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    tq = torch.from_numpy(xq).cuda()
+    busy_a = torch.randn((8192, 8192), device="cuda")
+
+    def begin_finish(ix, expect_busy):
+        D = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+        I = torch.zeros((nq, k), dtype=torch.int64, device="cuda")
+        status = torch.full((4,), 77, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(12):                      # ~100 ms of work ahead of the search on its stream
+            busy_a @ busy_a
+        _lib.check(lib.proqa_index_search_begin_device(ix._h, tq.data_ptr(), nq, 0, k, 0, D.data_ptr(), I.data_ptr(),
+                                                       status.data_ptr(), _lib.current_stream_ptr()))
+        still_busy = not torch.cuda.current_stream().query()
+        _lib.check(lib.proqa_index_search_finish(ix._h, None))
+        np.testing.assert_array_equal(I.cpu().numpy(), Io)
+        np.testing.assert_array_equal(D.cpu().numpy(), Do)
+        assert status[0].item() == 0
+        if expect_busy:
+            assert still_busy, "search_begin_device waited for the stream"
+        return ix.last_stats()
+
+    ix = IndexFlatIP(128)
+    ix.add(torch.from_numpy(xb).cuda())
+    ix.configure_nomination("off")
+    ix.search_device(tq, k)                      # the workspace of this batch size exists from here on
+    ix.configure_nomination("auto")
+    st = begin_finish(ix, True)
+    assert not st["nomination"] and st["nomination_state"] == "on" and st["fallback_rounds"] == 0
+    st = begin_finish(ix, False)                 # the copy was built by the first _finish (this search's candidate store
+    assert st["nomination"] and st["nominated"] > 0   # may still grow: the first int8 search of its size on the handle)
+    st = begin_finish(ix, True)
+    assert st["nomination"]
+    # the explicit form: prepare() right after the rows are in place
+    ix2 = IndexFlatIP(128)
+    ix2.add(torch.from_numpy(xb).cuda())
+    ix2.configure_nomination("off")
+    ix2.search_device(tq, k)
+    ix2.configure_nomination("auto")
+    ix2.prepare()
+    ix2.prepare()                                # idempotent
+    assert begin_finish(ix2, False)["nomination"]
+    assert begin_finish(ix2, True)["nomination"]
+    # a small shard / nomination off: prepare is a no-op
+    small = IndexFlatIP(128)
+    small.add(xb[:5000])
+    small.prepare()
+    small.search_device(tq, k)
+    assert not small.last_stats()["nomination"]
+
+
+def test_rows_changed_after_writing_into_adopted_rows(gpu_device):
+    """Adopted rows are searched in place and the int8 copy is keyed on them: a caller that overwrites rows says so
+    (rows_changed) and the next search rebuilds the copy -- a planted row that only exists after the write is found."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(61)
+    n, nq, k = 80000, 300, 80
+    xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq)
+    t = torch.from_numpy(xb).cuda()
+    tq = torch.from_numpy(xq).cuda()
+    ix = IndexFlatIP(128)
+    ix.adopt_device(t)
+    D, I = ix.search_device(tq, k)
+    assert ix.last_stats()["nomination"]
+    np.testing.assert_array_equal(I.cpu().numpy(), search_oracle.topk_ip(xq, xb, k)[1])
+    xb2 = xb.copy()
+    xb2[40001] = xq[0] * 4                      # the best match of query 0 by far, and a row far outside the old scales
+    xb2[123] = 0
+    t.copy_(torch.from_numpy(xb2))
+    ix.rows_changed()
+    D, I = ix.search_device(tq, k)
+    Do, Io = search_oracle.topk_ip(xq, xb2, k)
+    assert ix.last_stats()["nomination"] and Io[0, 0] == 40001
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    np.testing.assert_array_equal(D.cpu().numpy(), Do)
+
+
+def test_near_ties_at_large_magnitude_are_the_fp16_scans_bits(gpu_device):
+    """Scores of ~1e6 whose gaps are of the order of the fp32 accumulation's own rounding (2^-24 x 1e6 = 0.06): a common
+    component of ~90 per dimension plus perturbations of a few fp16 ulps.  The nomination threshold's slack must cover the
+    exact score's rounding (advisor finding, round 5: 2^-16 ||q|| max||x|| left no headroom; now 2^-14): ids and score bits of
+    the int8 path equal the fp16 scan's."""
+    rng = np.random.default_rng(67)
+    n, nq, k = 150000, 300, 80
+    base = rng.uniform(60, 120, 128).astype(np.float32)
+    xb = (base + rng.integers(-3, 4, (n, 128)) * 0.0625).astype(np.float16)      # fp16 spacing at 64..128 is 0.0625
+    xq = (base + rng.integers(-8, 9, (nq, 128)) * 0.0625).astype(np.float16)
+    (D0, I0, st0, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    assert st1["nomination"] and not st0["nomination"]
+    assert float(np.abs(D0).min()) > 3e5
+    np.testing.assert_array_equal(I1, I0)
+    np.testing.assert_array_equal(D1.view(np.int32), D0.view(np.int32))
+    # the exact scores really are near-tied at that magnitude: neighbouring results differ by less than 1e-5 relative
+    assert float(np.median((D0[:, :-1] - D0[:, 1:]) / D0[:, :-1])) < 1e-5

@@ -351,22 +351,35 @@ def test_full_size_properties(gpu_device):
     index = IndexFlatIP(128)
     index.adopt_device(xb)
     D, I = index.search_device(xq, k)
-    assert index.last_stats()["fallback_rounds"] == 0
+    # the headline's own path: the rounds ran on the int8 copy, no list overflowed, the scan stays on
+    st = index.last_stats()
+    assert st["nomination"] and st["nomination_state"] == "on" and st["fallback_rounds"] == 0 and st["nominated"] > 0
     assert torch.equal(I[:, 0], plant)
     assert (D[:, 1:] <= D[:, :-1]).all()
     assert (I >= 0).all() and (I < n).all()
     assert all(len(set(row.tolist())) == k for row in I[:64].cpu())
+    # the fp16 scan of the same adopted rows: ids AND score bits of all 2032 x 80 results are equal
+    index.configure_nomination("off")
+    D16, I16 = index.search_device(xq, k)
+    st16 = index.last_stats()
+    assert not st16["nomination"] and st16["nomination_state"] == "off" and st16["fallback_rounds"] == 0
+    assert torch.equal(I16, I) and torch.equal(D16.view(torch.int32), D.view(torch.int32))
+    index.configure_nomination("auto")
+    del D16, I16
     # re-score the reported ids in fp32 on the GPU: D must be the true inner products
     rows = xb[I[:32].reshape(-1)].float().reshape(32, k, 128)
     ref = torch.einsum("qkd,qd->qk", rows, xq[:32].float())
     assert torch.allclose(D[:32], ref, rtol=1e-5, atol=1e-3)
-    # no row outside the list may beat the k-th score (checked exhaustively for 8 queries)
-    S = xq[:8].float() @ xb[:6_000_000].float().T
+    # no row outside the list may beat the k-th score: exhaustively over ALL 18M rows for 8 queries, in 6M-row pieces
     kth = D[:8, -1:]
-    n_better = (S > kth).sum(dim=1)
-    in_list = torch.stack([(I[q] < 6_000_000).sum() for q in range(8)])
-    assert (n_better <= in_list).all()
-    del S
+    for p0 in range(0, n, 6_000_000):
+        S = xq[:8].float() @ xb[p0:p0 + 6_000_000].float().T
+        n_better = (S > kth).sum(dim=1)
+        in_list = torch.stack([((I[q] >= p0) & (I[q] < p0 + 6_000_000)).sum() for q in range(8)])
+        assert (n_better <= in_list).all(), p0
+        # ... and every listed row of the piece really is at or above the k-th score
+        assert ((S >= kth).sum(dim=1) >= in_list).all(), p0
+        del S
     # sharded == unsharded, bit for bit
     parts = []
     for lo, hi in [(0, 7_000_000), (7_000_000, n)]:
