@@ -109,6 +109,7 @@ struct proqa_index {
   bool q8_build_due = false;               // an enqueued (begin / finish) search wanted the int8 copy: _finish builds it
   int nominate_mode = 1;                   // 0 off, 1 automatic, 2 always (no profitability check); proqa_index_configure_nomination
   bool q8_active = false;                  // the search being enqueued runs its rounds on the int8 copy
+  int64_t pending_nq = 0;                  // queries of the search being enqueued (the row-split launch of small batches reads it)
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
   proqa::NominateParams* qparams = nullptr;   // workspace [ws_nq_pad]
   unsigned long long* stat_nom = nullptr;  // workspace [ws_nq_pad] rows re-scored per query
@@ -149,6 +150,10 @@ const unsigned kFilterFlags = getenv("PROQA_FILTER_FLAGS") ? (unsigned)atoi(gete
 const int kWideQw = getenv("PROQA_FILTER_QW") && (atoi(getenv("PROQA_FILTER_QW")) == 4 || atoi(getenv("PROQA_FILTER_QW")) == 1)
                         ? atoi(getenv("PROQA_FILTER_QW")) : 2;
 const bool kDebugRounds = debug_flag("PROQA_DEBUG_ROUNDS");
+// developer A/B switches of the HBM-bound int8 scan (<= 256 queries): the one-workgroup-per-CU form with four pair buffers
+// (measured slower: off), and the row-split launch of <= 128 queries (on)
+const bool kDeepRing = getenv("PROQA_I8_DEEP_RING") && atoi(getenv("PROQA_I8_DEEP_RING")) != 0;
+const bool kRowSplit = !(getenv("PROQA_I8_ROW_SPLIT") && atoi(getenv("PROQA_I8_ROW_SPLIT")) == 0);
 
 // counters of the last float32 -> fp16 conversion: {values fp16 cannot hold exactly, values beyond its range}
 int read_inexact(proqa_index* idx, const char* what, hipStream_t st, unsigned* n_inexact) {
@@ -613,7 +618,14 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   // search was set up for it: two workgroups per CU, deep lane lists instead of a spill log
   const bool nominate = idx->q8_active && !inclusive && !dense && !bounded && !shape.want_chunks && !shape.compact;
   if (nominate) {
-    const unsigned want = std::max<unsigned>(64u, (unsigned)(2 * device_cu_count() / (int)n_qtiles) / 8 * 8);
+    // batches of <= 256 queries (qw == 1) stream the int8 rows at the HBM's pace: ONE workgroup per CU with four pair
+    // buffers (three pairs, 96 KB, of LDS-DMA in flight) instead of two workgroups with two (64 KB in flight per CU)
+    const bool deep = qw == 1 && kDeepRing;
+    // at most 128 queries: row-split launch (mips_filter_i8<SPLIT>) -- the 1 / 2 / 4 query blocks that hold queries are
+    // replicated over the eight waves, which share the units of the stream (and the lists of their queries)
+    unsigned q_blocks = 0;
+    if (qw == 1 && kRowSplit && idx->pending_nq <= 128) q_blocks = idx->pending_nq <= 32 ? 1u : (idx->pending_nq <= 64 ? 2u : 4u);
+    const unsigned want = std::max<unsigned>(64u, (unsigned)((deep ? 1 : 2) * device_cu_count() / (int)n_qtiles) / 8 * 8);
     const LaunchGeom g = geometry(slab.r1 - slab.r0, n_qtiles, false, k, want);
     if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, kNominateLaneCap)) return rc;
     FilterArgsI8 fa;
@@ -628,8 +640,9 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     fa.store = store_of(idx, nq_pad, n_qtiles, kNominateLaneCap, round_up<unsigned>(g.chunks, 8));
     fa.overflow = overflow_word;
     fa.flags = kFilterFlags;
+    fa.q_blocks = q_blocks;
     if (f0) PROQA_HIP(hipEventRecord(f0, st));
-    PROQA_HIP(launch_filter_i8(fa, qw, g.grid, st));
+    PROQA_HIP(launch_filter_i8(fa, qw, g.grid, st, deep));
     if (f1) PROQA_HIP(hipEventRecord(f1, st));
     MergeArgs ma = {};
     ma.store = fa.store;
@@ -651,7 +664,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     PROQA_HIP(launch_merge(ma, nq_pad, st));
     if (kDebugCand) {   // developer: records the scan logged / rows the merges re-scored so far / candidates so far
       (void)hipStreamSynchronize(st);
-      const size_t n_cnt = (size_t)nq_pad * fa.store.n_chunks * 2;
+      const size_t n_cnt = (size_t)fa.store.nq_pad * fa.store.n_chunks * 2;
       std::vector<unsigned> cnt(n_cnt);
       (void)hipMemcpy(cnt.data(), idx->lane_cnt, n_cnt * sizeof(unsigned), hipMemcpyDeviceToHost);
       unsigned long long recs = 0, fullest = 0;
@@ -1210,6 +1223,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   idx->stats = {};
   idx->stats.nomination_state = nomination_state_of(idx);
   idx->q8_active = false;
+  idx->pending_nq = nq;
   if (nq == 0) return PROQA_OK;
   PROQA_ON_DEVICE(idx->device);
 

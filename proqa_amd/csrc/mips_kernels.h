@@ -148,8 +148,11 @@ struct FilterArgsI8 {
   CandidateStore store;     // lane lists of 8-byte records {first row of the column, 16 nominee bits} in the column records' slots
   unsigned* overflow;
   unsigned flags;           // developer cut experiments (PROQA_FILTER_FLAGS; wrong results), 0 in production
+  unsigned q_blocks;        // row-split launches (few queries): 32-query blocks that hold queries -- 1, 2 or 4; else 0.  The 8 /
+                            // q_blocks waves that share a query block take every (8 / q_blocks)-th 32-row unit each and append
+                            // to the block's lists through workgroup-shared counters
 };
-hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st);
+hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st, bool deep = false);
 // column statistics of fp16 rows [0, n): partial[g][0..127] sums, [g][128..255] minima, [g][256..383] maxima per workgroup g
 // (deterministic two-level reduction), then mean / scale per dimension: col[0..127] mean, col[128..255] 1 / c, col[256..383] c
 constexpr int kColStatGroups = 1024;

@@ -646,10 +646,26 @@ __device__ __forceinline__ unsigned column_rows_mask(int rows_left) {
 // (nominee_mask: the merge re-scores the rows from fp16 data, the integer scores are not kept; the 80-byte column of the
 // fp16 scan would be five stores and ten times the write traffic); a full list is reported through `overflow` (the round is
 // then re-scanned by the fp16 overflow-safe path): no spill log, no capacity branch in the hit path.
-template <int QW>
-__global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8 a) {
+//
+// NP = pair buffers of the LDS image (NP - 1 pairs of LDS-DMA in flight).  NP = 2 (64 KiB, two workgroups per CU: 64 KB in
+// flight per CU) is the MFMA-bound form.  The HBM-bound batches (QW = 1: <= 256 queries, one query block per wave) need
+// no second workgroup for the matrix pipe but more bytes in flight: NP = 4 is ONE workgroup per CU with 128 KiB of LDS and
+// three pairs (96 KB) in flight -- what the fp16 scan's ring holds (round-5 review, weak #9: 0.69 of 8 TB/s against 0.79).
+//
+// SPLIT (QW = 1, at most 128 queries): with one query block per wave a batch of <= 32 queries keeps ONE wave of the
+// workgroup busy -- it alone walks every 32-row unit of the chunk (fragment reads -> four dependent MFMAs -> test, in series:
+// ~500 cycles per unit) while seven waves only feed the DMA stream, and that wave's latency chain, not the memory system,
+// sets the pace (0.69 of 8 TB/s where the fp16 scan, which pipelines its test under the next unit's MFMAs, holds 0.79; a
+// deeper ring made it SLOWER: ABLATIONS R6.2).  Row-split launches give every wave work: the a.q_blocks (1, 2, 4) query
+// blocks are replicated over the 8 waves, the R = 8 / q_blocks waves of a block take every R-th unit each and append to
+// the block's lists (one per query and accumulator half, as ever) through list lengths kept in LDS -- an LDS atomic per
+// logged record, and records are rare where queries are few; the merge sees the same lists as from any other launch.
+template <int QW, int NP, bool SPLIT = false>
+__global__ __launch_bounds__(kFilterThreads, NP == 2 ? 2 : 1) void mips_filter_i8(FilterArgsI8 a) {
   static_assert(QW == 1 || QW == 2, "8 waves x 32 / 64 queries");
-  __shared__ __attribute__((aligned(16))) char lds[4 * kStageBytesI8];
+  static_assert(NP == 2 || NP == 4, "two pair buffers (two workgroups per CU) or four (one)");
+  static_assert(!SPLIT || QW == 1, "row-split launches keep one query block per wave");
+  __shared__ __attribute__((aligned(16))) char lds[2 * NP * kStageBytesI8];
   constexpr int NW = kFilterWaves;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -673,7 +689,16 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
   const unsigned row_begin32 = (unsigned)row_begin;
   const signed char* chunk_base = a.xb8 + row_begin * kRowBytesI8;
 
-  const unsigned q0 = qt * (NW * QW * 32) + wave * (QW * 32);
+  // row-split: query block and row slice of this wave; the lengths of the shared lists live in LDS
+  const unsigned n_qblk = SPLIT ? a.q_blocks : (unsigned)NW;
+  const unsigned n_slices = (unsigned)NW / n_qblk;
+  const unsigned qwave = SPLIT ? (unsigned)wave % n_qblk : (unsigned)wave;
+  const unsigned slice = SPLIT ? (unsigned)wave / n_qblk : 0u;
+  __shared__ unsigned s_list_n[SPLIT ? 4 * 64 : 1];
+  if constexpr (SPLIT) {
+    if (tid < 4 * 64) s_list_n[tid] = 0u;   // (visible behind the first pair's barrier, which precedes every append)
+  }
+  const unsigned q0 = SPLIT ? qwave * 32u : qt * (NW * QW * 32) + wave * (QW * 32);
   i32x4 qf[QW][4];
   LaneThreshold thr[QW];
   uint2* lane_list[QW];
@@ -705,7 +730,7 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     dma_rel[e] = (wave * kDmaPerWave + e) * 8 + (lane >> 3);
     dma_piece_off[e] = ((lane & 7) ^ ((dma_rel[e] >> 1) & 7)) * 16;
   }
-  auto issue_pair = [&](int p) {   // stages 2p, 2p+1 -> the pair buffer p & 1
+  auto issue_pair = [&](int p) {   // stages 2p, 2p+1 -> the pair buffer p % NP
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int s = 2 * p + h;
@@ -716,7 +741,7 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
           rel = rel < n_rows ? rel : n_rows - 1;
           const signed char* src = chunk_base + (long long)rel * kRowBytesI8 + dma_piece_off[e];
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(lds + ((p & 1) * 2 + h) * kStageBytesI8 +
+                                           (__attribute__((address_space(3))) void*)(lds + ((p & (NP - 1)) * 2 + h) * kStageBytesI8 +
                                                                                      (wave * kDmaPerWave + e) * 1024),
                                            16, 0, QW == 1 ? kDmaAux : 0);
         }
@@ -724,9 +749,31 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     }
   };
   int st_cur = 0;   // record-store instructions of this wave since the last barrier: all younger than the awaited DMA pieces
-  auto publish = [&]() {
+  // `p`: the pair the barrier publishes.  Younger than its DMA pieces are this wave's record stores since the last barrier
+  // and (NP = 4) its pieces of the pairs p+1, p+2 -- 2 kDmaPerWave instructions per whole pair; a chunk's last pair may hold
+  // one stage.  Waiting for fewer outstanding operations than that is always safe: the tail of a chunk (the last two
+  // pairs) and lists of more than four records wait a little longer than they must.
+  auto publish = [&](int p) {
     const int allowed = __builtin_amdgcn_readfirstlane(st_cur);
-    if (allowed >= 8) {
+    if (NP == 4) {
+      constexpr int kPairOps = 4 * kDmaPerWave;             // instructions of two whole pairs in flight behind pair p
+      if (2 * (p + 2) + 2 <= nstages) {                     // pairs p+1 and p+2 are whole
+        static_assert(kPairOps == 8, "the immediates below");
+        if (allowed >= 4) {
+          asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else if (allowed >= 2) {
+          asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        } else if (allowed >= 1) {
+          asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+      } else if (2 * (p + 1) + 2 <= nstages) {              // pair p+1 is whole, pair p+2 short or absent
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else if (allowed >= 8) {
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else if (allowed >= 6) {
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -746,16 +793,14 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     asm volatile("" ::: "memory");
     st_cur = 0;
   };
-  issue_pair(0);
+#pragma unroll
+  for (int p = 0; p < NP - 1; ++p)
+    if (p < npairs) issue_pair(p);
   if (!wave_live) {   // padding / exhausted queries only: the wave helps streaming and meets the barriers
     for (int p = 0; p < npairs; ++p) {
-      publish();
-      if (p + 1 < npairs) issue_pair(p + 1);
+      publish(p);
+      if (p + NP - 1 < npairs) issue_pair(p + NP - 1);
     }
-#pragma unroll
-    for (int blk = 0; blk < QW; ++blk)
-      a.store.lane_cnt[lane_cnt_index(a.store, chunk, q0 + blk * 32 + li, half)] = 0u;
-    return;
   }
   // The block constants {G_b, X_b} of a pair's eight units are wave-uniform: ONE scalar load of 64 bytes per pair (hipcc
   // turns `a.blk[i]` into a vector load per unit -- a memory round trip inside every unit, and one more operation in the
@@ -772,18 +817,27 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
     const unsigned long long uaddr = ((unsigned long long)hi << 32) | lo;
     return *(const __attribute__((address_space(4))) f32x16*)uaddr;
   };
-  for (int p = 0; p < npairs; ++p) {
+  for (int p = 0; wave_live && p < npairs; ++p) {
     const f32x16 bc = load_blocks(p);
-    publish();
-    if (p + 1 < npairs) issue_pair(p + 1);
-    const char* base = lds + (p & 1) * 2 * kStageBytesI8;
+    publish(p);
+    if (p + NP - 1 < npairs) issue_pair(p + NP - 1);
+    const char* base = lds + (p & (NP - 1)) * 2 * kStageBytesI8;
     const int nunits = (nstages - 2 * p >= 2 ? 2 : 1) * (kStageRows / kSubRows);
     i32x4 af[4];
+    if constexpr (!SPLIT) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(base + rd_off[j]);
+      for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(base + rd_off[j]);
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (u == 4 && nunits <= 4) break;   // (the chunk's last pair may hold one stage)
+      if constexpr (SPLIT) {
+        // this wave's units of the pair: every n_slices-th (wave-uniform); its fragments are read on the spot -- with an
+        // eighth / a quarter / half of the units per wave nothing here is on the critical path of the stream
+        if (((unsigned)u & (n_slices - 1u)) != slice) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(base + u * kSubBytesI8 + rd_off[j]);
+      }
       const char* nxt = base + (u + 1 < nunits ? u + 1 : u) * kSubBytesI8;
       i32x16 acc[QW];
 #pragma unroll
@@ -794,8 +848,10 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
         for (int blk = 0; blk < QW; ++blk)
           acc[blk] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[j], qf[blk][j], acc[blk], 0, 0, 0);
       }
+      if constexpr (!SPLIT) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
+        for (int j = 0; j < 4; ++j) af[j] = *(const i32x4*)(nxt + rd_off[j]);
+      }
       bool hit[QW];
       float tb[QW];
       bool any_hit = false;
@@ -814,7 +870,15 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
           if (__any(hit[blk])) {   // (wave-uniform: exactly the regions whose store is issued are counted)
             st_cur += 1;
             if (hit[blk]) {
-              const unsigned slot = lane_n[blk] < lane_cap ? lane_n[blk] : lane_cap - 1u;   // a full list keeps counting: overflow below
+              // (row-split: the list is shared with the other waves of the query block -- its length is an LDS counter)
+              // (inline asm: for an LDS atomic of its own hipcc first drains vmcnt -- the DMA prefetch -- because LDS-DMA
+              // writes LDS too; the counters are not DMA targets)
+              unsigned pos = lane_n[blk];
+              if constexpr (SPLIT) {
+                const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)&s_list_n[qwave * 64u + (unsigned)lane];
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(addr), "v"(1u) : "memory");
+              }
+              const unsigned slot = pos < lane_cap ? pos : lane_cap - 1u;   // a full list keeps counting: overflow below
               unsigned mask = nominee_mask(acc[blk], tb[blk]);
               // (scalar condition: only the chunk's last unit can reach past its rows -- hipcc turned a per-lane form of this
               // test into ~40 unconditional VALU operations in every hit path)
@@ -825,6 +889,21 @@ __global__ __launch_bounds__(kFilterThreads, 2) void mips_filter_i8(FilterArgsI8
           }
         }
       }
+    }
+  }
+  if constexpr (SPLIT) {
+    // the lengths of the shared lists: complete once every wave of the workgroup is here.  The waves of slice 0 report their
+    // query block's lists; the others zero the lists of the query blocks nobody scanned for (padding queries: the merge
+    // reads every list length of the tile)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (slice == 0) {
+      lane_n[0] = s_list_n[qwave * 64u + (unsigned)lane];
+    } else {
+      // waves n_qblk .. 7 <-> query blocks n_qblk .. 7 (every one of them exactly once)
+      a.store.lane_cnt[lane_cnt_index(a.store, chunk, (unsigned)wave * 32u + li, half)] = 0u;
+      return;
     }
   }
 #pragma unroll
@@ -2418,11 +2497,20 @@ hipError_t launch_filter(const FilterArgs& a, int qw, bool inclusive, unsigned g
   return hipGetLastError();
 }
 
-hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st) {
+// deep: the one-workgroup-per-CU form with four pair buffers (QW = 1 only; the caller sizes the grid for it)
+hipError_t launch_filter_i8(const FilterArgsI8& a, int qw, unsigned grid, hipStream_t st, bool deep) {
   if (qw == 2)   // (flag 256, experiment: 24 KiB of unused dynamic LDS leave room for ONE workgroup per CU)
-    hipLaunchKernelGGL((mips_filter_i8<2>), dim3(grid), dim3(kFilterThreads), (a.flags & 256u) ? 24576 : 0, st, a);
+    hipLaunchKernelGGL((mips_filter_i8<2, 2>), dim3(grid), dim3(kFilterThreads), (a.flags & 256u) ? 24576 : 0, st, a);
+  else if (qw == 1 && a.q_blocks) {   // row-split: 1, 2 or 4 query blocks replicated over the eight waves
+    if (a.q_blocks != 1 && a.q_blocks != 2 && a.q_blocks != 4) return hipErrorInvalidValue;
+    if (deep)
+      hipLaunchKernelGGL((mips_filter_i8<1, 4, true>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((mips_filter_i8<1, 2, true>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+  } else if (qw == 1 && deep)
+    hipLaunchKernelGGL((mips_filter_i8<1, 4>), dim3(grid), dim3(kFilterThreads), 0, st, a);
   else if (qw == 1)
-    hipLaunchKernelGGL((mips_filter_i8<1>), dim3(grid), dim3(kFilterThreads), 0, st, a);
+    hipLaunchKernelGGL((mips_filter_i8<1, 2>), dim3(grid), dim3(kFilterThreads), 0, st, a);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -365,19 +365,20 @@ def trained_like_state_dict(seed=0):
     return {k: v.half().float() for k, v in sd.items()}
 
 
-# max |kernels - fp16-storage oracle| / max |oracle| under trained-model statistics (see the test below)
-TRAINED_STATS_REL16 = 2e-3
-
-
 def test_trained_model_statistics_do_not_break_fp16(gpu_device):
     """Encoder parity where fp16 storage could bite (every other encoder test runs N(0, 0.02) weights, activations O(1)):
     outlier channels, attention logits of +-60, FFN activations in the hundreds, pre-LayerNorm GEMM outputs beyond 1e3.
     A full 512 x 128 batch and a packed variable-length batch against oracle/bert_oracle.py (float32) on their first rows:
-    cosine >= 0.9999 AND max relative error <= 1e-2 (an absolute tolerance says nothing at these magnitudes), all finite --
-    and <= 2e-3 against the SAME oracle with every stored activation rounded to fp16 (bert_oracle storage="fp16": apex O1's
-    storage format, float32 arithmetic): the gap between the two bounds is the format's error, not the kernels'.  The probe
-    asserts that the regime is reached inside the oracle: logits beyond +-60, GELU outputs beyond 200, pre-LayerNorm sums
-    beyond 1e3.
+    cosine >= 0.9999 AND max relative error <= 1e-2 (an absolute tolerance says nothing at these magnitudes), all finite.
+    Whose error is it?  bert_oracle storage="fp16" is the SAME float32 arithmetic with every stored activation rounded to
+    fp16 (apex O1's storage format).  Measured over four weight seeds (scripts/dev_trained_stats_err.py, round 6): that
+    oracle differs from the fp32 one by 1.4e-3 .. 4.8e-3, the kernels by 1.5e-3 .. 4.9e-3 -- the same size, seed by seed
+    (4.17 / 4.14, 1.43 / 1.50-2.00, 3.04 / 2.21, 4.81 / 4.58-4.88 e-3) -- and the kernels differ from the fp16-storage
+    oracle by 1.5e-3 .. 7.5e-3: two fp16 evaluations with different summation orders round differently and their errors
+    add like independent noise, so a bound BELOW the format's own error against the fp16-storage oracle (the round-5 review
+    proposed 2e-3) cannot hold for any implementation.  What is asserted instead: the kernels' error against fp32 is at most
+    twice the format's own (+1e-3), i.e. it is the storage format's error, not the kernels'.  The probe asserts that the
+    regime is reached inside the oracle: logits beyond +-60, GELU outputs beyond 200, pre-LayerNorm sums beyond 1e3.
     The relative error of this regime is a noisy quantity: 1.5e-3 .. 4.9e-3 over four weight seeds (scripts/dev_trained_stats_err.py;
     1.8e-3 .. 8.2e-3 with the all-keys-in-LDS attention kernel of rounds 1-4, worst cosine 0.99995), so the bound sits above
     the range, not on one seed's value.
@@ -428,7 +429,10 @@ def test_trained_model_statistics_do_not_break_fp16(gpu_device):
                   f"{rel16:.2e}, fp16-storage vs fp32 oracle {fmt:.2e}")
             assert cosine(got[:n_ref], ref).min() >= 0.9999, (B, cls_only, packed, cosine(got[:n_ref], ref).min())
             assert rel <= 1e-2, (B, cls_only, packed, rel)
-            assert rel16 <= TRAINED_STATS_REL16, (B, cls_only, packed, rel16, fmt)
+            # the kernels' error is of the size of the FORMAT's: at most twice what fp16 storage alone does to the fp32 oracle
+            assert rel <= 2.0 * fmt + 1e-3, (B, cls_only, packed, rel, fmt)
+            # and two fp16 evaluations differ from each other by no more than the sum of their distances from fp32
+            assert rel16 <= rel + fmt + 1e-3, (B, cls_only, packed, rel16, rel, fmt)
 
 
 @pytest.mark.parametrize("lens", [[9], [30], [5, 17, 30, 12], [20] * 6 + [8], [33, 31, 32, 32]])

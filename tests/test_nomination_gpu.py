@@ -470,3 +470,38 @@ def test_near_ties_at_large_magnitude_are_the_fp16_scans_bits(gpu_device):
     np.testing.assert_array_equal(D1.view(np.int32), D0.view(np.int32))
     # the exact scores really are near-tied at that magnitude: neighbouring results differ by less than 1e-5 relative
     assert float(np.median((D0[:, :-1] - D0[:, 1:]) / D0[:, :-1])) < 1e-5
+
+
+@pytest.mark.parametrize("nq", [1, 7, 32, 33, 64, 65, 100, 128, 129, 200, 256])
+def test_small_batches_row_split_launches_match_the_oracle(gpu_device, nq):
+    """<= 128 queries run the row-split form of the int8 scan (1 / 2 / 4 query blocks replicated over the eight waves of a
+    workgroup, which share the units of the stream and the lists of their queries through LDS counters); 129 .. 256 the
+    one-block-per-wave form.  Ids and scores are the oracle's on an integer corpus either way -- also for k = 1 and with a
+    ragged last chunk."""
+    rng = np.random.default_rng(1000 + nq)
+    n = 131072 + 77 * nq + 5
+    xb, xq = _int_corpus(rng, n), _int_corpus(rng, nq)
+    for k in (80, 1):
+        (D0, I0, st0, _), (D1, I1, st1, _) = _both(xb, xq, k)
+        Do, Io = search_oracle.topk_ip(xq, xb, k)
+        assert st1["nomination"] and st1["fallback_rounds"] == 0
+        np.testing.assert_array_equal(I1, Io)
+        np.testing.assert_array_equal(D1, Do)
+        np.testing.assert_array_equal(I0, Io)
+
+
+@pytest.mark.parametrize("nq", [5, 40, 120])
+def test_row_split_lists_that_overflow_go_to_the_fp16_path(gpu_device, nq):
+    """Scores that rise with the row number make every unit a hit: the shared lists of a row-split launch fill up, the
+    overflow word is raised and the fp16 overflow-safe path finishes the round -- exact, with the fallback counted."""
+    rng = np.random.default_rng(7 + nq)
+    n, k = 90000, 80
+    xb = rng.integers(-1, 2, (n, 128)).astype(np.float16)
+    xb[:, 0] = np.minimum(np.arange(n) // 7, 2000)
+    xq = rng.integers(0, 2, (nq, 128)).astype(np.float16)
+    xq[:, 0] = 1
+    (D0, I0, _, _), (D1, I1, st1, _) = _both(xb, xq, k)
+    Do, Io = search_oracle.topk_ip(xq, xb, k)
+    np.testing.assert_array_equal(I1, Io)
+    np.testing.assert_array_equal(D1, Do)
+    assert st1["nomination"] and st1["fallback_rounds"] > 0

@@ -371,14 +371,15 @@ def test_full_size_properties(gpu_device):
     ref = torch.einsum("qkd,qd->qk", rows, xq[:32].float())
     assert torch.allclose(D[:32], ref, rtol=1e-5, atol=1e-3)
     # no row outside the list may beat the k-th score: exhaustively over ALL 18M rows for 8 queries, in 6M-row pieces
+    # (S is a float32 GEMM with its own summation order: 1e-3 of slack on scores of ~30-45, fp32 round-off is ~1e-5)
     kth = D[:8, -1:]
     for p0 in range(0, n, 6_000_000):
         S = xq[:8].float() @ xb[p0:p0 + 6_000_000].float().T
-        n_better = (S > kth).sum(dim=1)
+        n_better = (S > kth + 1e-3).sum(dim=1)
         in_list = torch.stack([((I[q] >= p0) & (I[q] < p0 + 6_000_000)).sum() for q in range(8)])
         assert (n_better <= in_list).all(), p0
         # ... and every listed row of the piece really is at or above the k-th score
-        assert ((S >= kth).sum(dim=1) >= in_list).all(), p0
+        assert ((S >= kth - 1e-3).sum(dim=1) >= in_list).all(), p0
         del S
     # sharded == unsharded, bit for bit
     parts = []
