@@ -21,7 +21,8 @@ five significant digits, no prose.  What the keys mean:
                            .rescore_gather_bytes = fp16 rows the merges gather for the exact re-scoring
   fp16_scan                the same search with the nomination switched off (mips_filter_f16), digests compared
   scan_small_batch         32 queries over the same rows: the HBM-bound regime (algorithmic bytes = rows x 256 B)
-  shard_sweep              N=1 timing of the per-rank search of a G-rank job (first N/G rows, no collective)
+  shard_sweep              N=1 timing of the per-rank search of a G-rank job (first N/G rows, no collective); .pipelined_ms_per_search:
+                           the same searches as a stream of batches on two handles / two streams (PipelinedSearcher)
   large_k                  the reference's large-k callers (trec_process.py:76, online_sampler.py:113) on the same rows
   search_cli_eval          the eval_retrieval.py command line end to end (index file -> printed Recall lines), stage split
   peak_measured            stream / MFMA micro-benchmarks of this box (float4 copy / read of 2 GiB; register-resident MFMA loops)
@@ -1047,9 +1048,28 @@ def main():
             ms_g = dt_g / max(5, args.steps // 2) * 1e3
             sweep.append((g_, rows_g, ms_g))
             ix.close()
+        # the same per-rank searches as a STREAM of batches: two index handles on two streams, the next search enqueued
+        # before the host waits for the current one (proqa_amd.index.PipelinedSearcher) -- a throughput figure for callers
+        # with many batches; the headline and ms_per_search above stay one search at a time
+        from proqa_amd.index import PipelinedSearcher
+        piped = []
+        for g_ in (1, 2, 4, 8):
+            ps = PipelinedSearcher(xb[:n // g_])
+            n_b = max(10, args.steps)
+            for _ in ps.search_batches([xq] * 4, k):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in ps.search_batches([xq] * n_b, k):
+                pass
+            torch.cuda.synchronize()
+            piped.append((time.perf_counter() - t0) / n_b * 1e3)
+            ps.close()
+            del ps
+        torch.cuda.empty_cache()
         # N=1 timing of the per-rank search of a G-rank job (no collective): parallel arrays
         line["shard_sweep"] = {"ranks": [p_[0] for p_ in sweep], "rows_per_rank": [p_[1] for p_ in sweep],
-                               "ms_per_search": [p_[2] for p_ in sweep]}
+                               "ms_per_search": [p_[2] for p_ in sweep], "pipelined_ms_per_search": piped}
         # the reference's large-k callers on the same index: retrieval/trec_process.py:76 (6980 MS MARCO dev queries,
         # top-10000 of 8.8M passages) and qa/online_sampler.py:113 (one question, k = 5000)
         large = {}

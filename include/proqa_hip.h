@@ -470,6 +470,10 @@ int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, 
 /* the same with the instruction shape as an argument: 0 = v_mfma_i32_32x32x32_i8 (the nomination scan's), 1 =
  * v_mfma_i32_16x16x64_i8 (the shape MI355X_MICROARCH.md quotes its int8 ceiling for) */
 int proqa_microbench_mfma_i8_shape(double ms_target, int zero_operands, int shape, void* stream, double* tops);
+/* what VALU work beside the matrix instructions costs: the int8 rate (random operands) of a loop of 8 x
+ * v_mfma_i32_32x32x32_i8 + n_valu x v_xad_u32 per wave and trip, four waves per SIMD (the shape of mips_filter_i8's unit);
+ * n_valu in {0, 8, 16, 24, 32, 48, 64} */
+int proqa_microbench_mfma_i8_valu(double ms_target, int n_valu, void* stream, double* tops);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,38 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return __builtin_fmaf(-a, u, __builtin_fmaxf(x, 0.0f));
 }
 
+// The same on packed fp32 (v_pk_fma_f32 / v_pk_add_f32: two elements per instruction at the scalar forms' rate): the seven
+// fused multiply-adds and the bias add of an element pair become eight instructions instead of sixteen (~1200 instead of
+// ~1600 VALU instructions per wave and 256 x 256 tile).  Same operations in the same order per element: bit-identical to
+// gelu_erf.
+typedef float f32x4e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4e splat4(float v) { return f32x4e{v, v, v, v}; }
+// FOUR elements per call: every Horner step is applied to all four before the next one, i.e. two independent v_pk_fma_f32
+// per step (eight at a time spill: the kernel sits at 252 VGPRs) -- written element pair by element pair, hipcc ran each pair's seven dependent
+// instructions through one register pair back to back (the kernel sits at 252 VGPRs) and the epilogue stayed latency-bound:
+// packed arithmetic alone measured -1 % (ABLATIONS R6.7).
+// Written in an = -a = max(-|x|, -6) (one v_max_f32 with source modifiers): the Horner steps of q alternate in sign -- every
+// odd intermediate is the exact negative of gelu_erf's, fused multiply-adds round symmetrically -- and the last step is
+// fma(an, u, m) without a negation (hipcc turns a negated four-vector into 128 v_xor_b32 per tile).
+__device__ __forceinline__ f32x4e gelu_erf4(f32x4e x) {
+  f32x4e an;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) an[e] = __builtin_fmaxf(-__builtin_fabsf(x[e]), -6.0f);
+  f32x4e q = __builtin_elementwise_fma(splat4(2.299005791428499e-05f), an, splat4(0.000611100229434669f));   // -t1
+  q = __builtin_elementwise_fma(q, an, splat4(0.007195569109171629f));                                        //  t2
+  q = __builtin_elementwise_fma(q, an, splat4(0.05118535831570625f));                                         // -t3
+  q = __builtin_elementwise_fma(q, an, splat4(-0.46127188205718994f));                                        //  t4
+  q = __builtin_elementwise_fma(q, an, splat4(1.1501742601394653f));                                          // -t5
+  q = __builtin_elementwise_fma(q, an, splat4(-1.000064730644226f));                                          //  q(a)
+  f32x4e u, m;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    u[e] = __builtin_amdgcn_exp2f(q[e]);   // Phi(-a)
+    m[e] = __builtin_fmaxf(x[e], 0.0f);
+  }
+  return __builtin_elementwise_fma(an, u, m);
+}
+
 // The main loop runs the two waves of every SIMD in ANTI-PHASE ("ping-pong").  (Rounds 1-3 had all eight waves read their
 // fragments at the same time and then all issue MFMAs at the same time, one barrier per K-step: the matrix pipe of a SIMD
 // idled while its two waves waited for LDS; bit-identical results, 3-4 % slower.)  Waves 0-3 (group X, one per SIMD) and waves 4-7
@@ -98,7 +130,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // that data start in phase 3, one barrier later for X and two for Y.  Barriers are raw s_barrier (no vmcnt drain).
 //   At the end of an output tile X takes one extra barrier (the groups fall in step), both run the epilogue at the same
 // time, then Y takes one extra barrier (anti-phase again).
-template <int EPI, int DBG = 0>   // DBG (timing experiments, wrong results): bit 0 = no fragment reads after the first step, bit 1 = no DMA after the prologue, bit 2 = no epilogue, bit 3 = every DMA from the same 64 KiB
+template <int EPI, int DBG = 0, bool PK = true>   // PK: packed-fp32 epilogue arithmetic (false: the scalar form, developer A/B).  DBG (timing experiments, wrong results): bit 0 = no fragment reads after the first step, bit 1 = no DMA after the prologue, bit 2 = no epilogue, bit 3 = every DMA from the same 64 KiB
 __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __restrict__ X, const _Float16* __restrict__ W,
                                                              const _Float16* __restrict__ bias, _Float16* __restrict__ Y,
                                                              int M, int N, int K) {
@@ -367,12 +399,28 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_tn_f16(const _Float16* __res
 #pragma unroll
           for (int c = 0; c < 2; ++c) {
             f16x8 o;
+            if constexpr (PK) {   // packed fp32, four elements side by side
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float x = v[8 * c + e];
-              if (EPI != EPI_NONE) x += bv[16 * j + 8 * c + e];
-              if (EPI == EPI_BIAS_GELU) x = gelu_erf(x);
-              o[e] = (_Float16)x;
+              for (int e0 = 0; e0 < 8; e0 += 4) {
+                f32x4e x, b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  x[e] = v[8 * c + e0 + e];
+                  b4[e] = EPI != EPI_NONE ? bv[16 * j + 8 * c + e0 + e] : 0.f;
+                }
+                if (EPI != EPI_NONE) x += b4;
+                if (EPI == EPI_BIAS_GELU) x = gelu_erf4(x);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e0 + e] = (_Float16)x[e];
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float x = v[8 * c + e];
+                if (EPI != EPI_NONE) x += bv[16 * j + 8 * c + e];
+                if (EPI == EPI_BIAS_GELU) x = gelu_erf(x);
+                o[e] = (_Float16)x;
+              }
             }
             const int piece = 4 * half + 2 * j + c;
             *(f16x8*)(stage + li * 128 + ((piece ^ wr_sw) << 4)) = o;
@@ -431,9 +479,16 @@ int proqa_gemm_tn_f16(const void* x, const void* w, const void* bias, void* y, i
       hipLaunchKernelGGL(gemm_tn_f16<EPI_BIAS>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w, (const _Float16*)bias,
                          (_Float16*)y, (int)m, n, k);
       break;
-    default:
-      hipLaunchKernelGGL(gemm_tn_f16<EPI_BIAS_GELU>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w,
-                         (const _Float16*)bias, (_Float16*)y, (int)m, n, k);
+    default: {
+      // developer A/B switch: PROQA_GEMM_EPI_SCALAR=1 runs the scalar-fp32 epilogue of rounds 2-5 (same results)
+      static const bool kScalarEpi = getenv("PROQA_GEMM_EPI_SCALAR") && atoi(getenv("PROQA_GEMM_EPI_SCALAR")) != 0;
+      if (kScalarEpi)
+        hipLaunchKernelGGL((gemm_tn_f16<EPI_BIAS_GELU, 0, false>), g, b, 0, st, (const _Float16*)x, (const _Float16*)w,
+                           (const _Float16*)bias, (_Float16*)y, (int)m, n, k);
+      else
+        hipLaunchKernelGGL(gemm_tn_f16<EPI_BIAS_GELU>, g, b, 0, st, (const _Float16*)x, (const _Float16*)w,
+                           (const _Float16*)bias, (_Float16*)y, (int)m, n, k);
+    }
   }
   PROQA_LAUNCH_CHECK();
   return PROQA_OK;

@@ -115,6 +115,43 @@ __global__ __launch_bounds__(256) void mfma_loop_i8_16x16x64(int iters, int zero
   if (t == 0x12345678) *sink = t;
 }
 
+// What does VALU work beside the matrix instructions cost?  The int8 scan's unit is 8 MFMAs (two accumulator chains of 4)
+// followed by the examination of the 32 accumulators (~24 plain VALU instructions); here: the same 8 MFMAs followed by NV
+// three-operand VALU instructions over the accumulators (two dependency chains, as the scan's two query blocks), no branch, no memory, FOUR
+// waves per SIMD (1024 threads per CU) like the scan's two 8-wave workgroups.  The rate over NV = 0, 8, 16, ... separates
+// "the other waves' VALU hides under a wave's MFMAs" (flat) from "VALU issue and matrix issue share the SIMD" (falling).
+template <int NV>
+__global__ __launch_bounds__(512, 2) void mfma_i8_valu_loop(int iters, int* __restrict__ sink) {
+  i32x4 a, b;
+  for (int e = 0; e < 4; ++e) {
+    const unsigned h = (threadIdx.x * 2654435761u + e * 40503u + blockIdx.x * 97u);
+    a[e] = (int)(h * 2246822519u);
+    b[e] = (int)(h * 3266489917u + 12345u);
+  }
+  int m0 = 0, m1 = 0;
+  for (int i = 0; i < iters; ++i) {
+    i32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(b, a, c1, 0, 0, 0);
+    }
+    if (NV == 0) {   // keep the results alive with one instruction per chain
+      m0 ^= c0[0];
+      m1 ^= c1[0];
+    }
+#pragma unroll
+    for (int v = 0; v < NV / 2; ++v) {
+      const int x0 = c0[(2 * v) & 15], y0 = c0[(2 * v + 1) & 15], x1 = c1[(2 * v) & 15], y1 = c1[(2 * v + 1) & 15];
+      // (plain C++: hipcc makes each line ONE three-operand VALU instruction, v_xad_u32, and inserts the MFMA -> VALU wait
+      // states itself; a max tree would be folded -- the maximum is idempotent -- whatever NV says)
+      m0 = (m0 ^ x0) + y0;
+      m1 = (m1 ^ x1) + y1;
+    }
+  }
+  if (m0 + m1 == 0x12345678) *sink = m0;
+}
+
 }  // namespace
 }  // namespace proqa
 
@@ -224,6 +261,44 @@ int proqa_microbench_mfma_i8_shape(double ms_target, int zero_operands, int shap
 
 int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, double* tops) {
   return proqa_microbench_mfma_i8_shape(ms_target, zero_operands, 0, stream, tops);
+}
+
+// int8 MFMA rate (TOP/s, random operands) of a loop of 8 MFMAs + n_valu plain VALU instructions per wave, four waves per
+// SIMD: n_valu in {0, 8, 16, 24, 32, 48, 64}
+int proqa_microbench_mfma_i8_valu(double ms_target, int n_valu, void* stream, double* tops) {
+  if (!tops || !(ms_target > 0)) return fail(PROQA_EINVAL, "microbench_mfma_i8_valu: bad argument");
+  hipStream_t st = as_stream(stream);
+  hipEvent_t e0, e1;
+  PROQA_HIP(hipEventCreate(&e0));
+  PROQA_HIP(hipEventCreate(&e1));
+  int* sink = nullptr;
+  PROQA_HIP(hipMalloc((void**)&sink, 4));
+  const unsigned grid = (unsigned)device_cu_count() * 2;   // two 8-wave workgroups per CU: four waves per SIMD
+  int iters = (int)(ms_target * 1e-3 * 2.4e9 / (8 * 4 * 32));
+  if (iters < 64) iters = 64;
+  float best = 1e30f;
+  for (int r = 0; r < 4; ++r) {
+    PROQA_HIP(hipEventRecord(e0, st));
+    switch (n_valu) {
+#define PROQA_CASE(N) case N: hipLaunchKernelGGL(mfma_i8_valu_loop<N>, dim3(grid), dim3(512), 0, st, iters, sink); break;
+      PROQA_CASE(0) PROQA_CASE(8) PROQA_CASE(16) PROQA_CASE(24) PROQA_CASE(32) PROQA_CASE(48) PROQA_CASE(64)
+#undef PROQA_CASE
+      default:
+        (void)hipFree(sink);
+        return fail(PROQA_EINVAL, "microbench_mfma_i8_valu: n_valu=%d is not built (0, 8, 16, 24, 32, 48, 64)", n_valu);
+    }
+    PROQA_HIP(hipEventRecord(e1, st));
+    PROQA_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PROQA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  (void)hipFree(sink);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  const double ops = (double)grid * 8 /*waves*/ * (double)iters * 8 /*MFMAs*/ * 2.0 * 32 * 32 * 32;
+  *tops = ops / (best * 1e-3) / 1e12;
+  return PROQA_OK;
 }
 
 }  // extern "C"

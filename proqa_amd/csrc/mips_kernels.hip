@@ -882,7 +882,17 @@ __global__ __launch_bounds__(kFilterThreads, NP == 2 ? 2 : 1) void mips_filter_i
               unsigned mask = nominee_mask(acc[blk], tb[blk]);
               // (scalar condition: only the chunk's last unit can reach past its rows -- hipcc turned a per-lane form of this
               // test into ~40 unconditional VALU operations in every hit path)
+              // (the empty asm keeps the region a BRANCH: without it hipcc hoists and if-converts it -- the ~40 VALU instructions
+              // of column_rows_mask ran at the head of every hit path, selected away by a v_cndmask at the end: ABLATIONS R6.8)
+#ifdef PROQA_TAILMASK_HOISTED   // developer A/B build: the round-5 form
               if ((2 * p * 4 + u + 1) * kSubRows > n_rows) mask &= column_rows_mask(n_rows - rel);
+#else
+              if ((2 * p * 4 + u + 1) * kSubRows > n_rows) {
+                int rows_left = n_rows - rel;
+                asm volatile("" : "+v"(rows_left));   // (an opaque value born inside the region: nothing of it can be hoisted)
+                mask &= column_rows_mask(rows_left);
+              }
+#endif
               lane_list[blk][slot] = make_uint2(row_begin32 + (unsigned)rel, mask);
               ++lane_n[blk];
             }

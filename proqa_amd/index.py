@@ -233,6 +233,68 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+class PipelinedSearcher:
+    """A STREAM of query batches over one set of rows, two searches in flight.
+
+    One search is a chain of ~20 dependent launches (bootstrap, rounds of scan + merge, finalize) and a host wait; at the
+    shard sizes of a multi-GPU job the chain is a third of the step.  Two IndexFlatIP handles over the same adopted rows,
+    each on its own stream, take the batches in turn: batch i+1 is enqueued (proqa_index_search_begin_device) before the
+    host waits for batch i (proqa_index_search_finish), so one search's small launches run beside the other's large
+    scans.  Results are those of the one-call search, in order.  Cost: every handle builds its own int8 copy of the rows
+    (+128 B per row each) and its own workspace.  Measured: 1.08 x the call-by-call rate at 18M rows, 1.19 x at 2.25M
+    (2032 queries, k = 80; profiles/ABLATIONS.md R6.3).  The reference searches once (eval_retrieval.py:102-104); this is
+    for callers that have many batches (an evaluation loop over several query files, the online sampler)."""
+
+    def __init__(self, xb, d=EMBED_DIM):
+        import torch
+        self.handles = [IndexFlatIP(d), IndexFlatIP(d)]
+        self.streams = [torch.cuda.Stream(device=xb.device), torch.cuda.Stream(device=xb.device)]
+        for h in self.handles:
+            h.adopt_device(xb)
+            h.prepare()
+        self.d = d
+
+    def search_batches(self, batches, k, idx_offset=0):
+        """Generator: for every CUDA tensor [nq, d] of `batches` one (D float32 [nq,k], I int64 [nq,k]), in order; a batch's
+        result is complete (host-synchronised) when it is yielded."""
+        import torch
+        lib = _lib.load()
+        k = int(k)
+        pending = []
+        for n, xq in enumerate(batches):
+            slot = n & 1
+            if len(pending) == 2:
+                yield self._finish(pending.pop(0))
+            if not xq.is_cuda or xq.dim() != 2 or xq.shape[1] != self.d:
+                raise ValueError(f"batches must be CUDA tensors of shape [nq, {self.d}]")
+            if xq.shape[0] > QUERY_BATCH:
+                raise ValueError(f"at most {QUERY_BATCH} queries per batch")
+            xq = xq.contiguous()
+            nq = xq.shape[0]
+            D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+            I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+            st = self.streams[slot]
+            st.wait_stream(torch.cuda.current_stream(xq.device))      # the batch may still be on its way on the caller's stream
+            with torch.cuda.device(xq.device):
+                _lib.check(lib.proqa_index_search_begin_device(self.handles[slot]._h, xq.data_ptr(), nq, _torch_dtype_code(xq), k,
+                                                               int(idx_offset), D.data_ptr(), I.data_ptr(), None, st.cuda_stream))
+            pending.append((slot, xq, D, I))
+        while pending:
+            yield self._finish(pending.pop(0))
+
+    def _finish(self, item):
+        slot, _xq, D, I = item
+        _lib.check(_lib.load().proqa_index_search_finish(self.handles[slot]._h, None))
+        return D, I
+
+    def last_stats(self):
+        return [h.last_stats() for h in self.handles]
+
+    def close(self):
+        for h in self.handles:
+            h.close()
+
+
 def merge_topk_device(D_parts, I_parts):
     """Merge [n_parts, nq, k] per-shard lists (ascending shard order) into [nq, k] on the GPU.  The parts need not be
     sorted inside (this entry point sorts); slots with I = -1 are missing rows wherever they sit."""

@@ -22,8 +22,8 @@ for r0 in range(0, n, 2_000_000):
     xb[r0:r0 + m] = torch.randn((m, 128), generator=g, device=dev).to(torch.float16)
 ix = IndexFlatIP(128)
 ix.adopt_device(xb)
-tag = f"deep_ring={os.environ.get('PROQA_I8_DEEP_RING', 'default')}"
-for nq in (1, 32, 128, 256):
+tag = f"row_split={os.environ.get('PROQA_I8_ROW_SPLIT', 'default')} deep_ring={os.environ.get('PROQA_I8_DEEP_RING', 'default')}"
+for nq in (1, 32, 64, 128, 256):
     xq = torch.randn((nq, 128), generator=g, device=dev).to(torch.float16)
     for _ in range(3):
         D, I = ix.search_device(xq, k)

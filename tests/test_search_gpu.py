@@ -1050,3 +1050,34 @@ def test_add_npy_streams_the_file_like_np_load_plus_add(gpu_device, tmp_path):
     np.testing.assert_array_equal(I, Ie)
     np.testing.assert_array_equal(D, De)
     index.close()
+
+
+@pytest.mark.gpu
+def test_pipelined_searcher_returns_the_one_call_results_in_order(gpu_device):
+    """PipelinedSearcher (two handles over the same rows, two streams, the next batch enqueued before the host waits for the
+    current one): every batch's result equals the oracle's / the one-call search's, in order -- batches of different sizes,
+    an empty stream, a single batch, k beyond the deferred kind (it completes inside begin)."""
+    import torch
+    from proqa_amd.index import IndexFlatIP, PipelinedSearcher
+    rng = np.random.default_rng(77)
+    xb = _int_corpus(rng, 90000)
+    t = torch.from_numpy(xb).cuda()
+    ps = PipelinedSearcher(t)
+    assert list(ps.search_batches([], 10)) == []
+    sizes = [300, 1, 64, 300, 700, 5, 300]
+    batches = [_int_corpus(rng, m) for m in sizes]
+    got = list(ps.search_batches([torch.from_numpy(b).cuda() for b in batches], 80, idx_offset=7))
+    assert len(got) == len(batches)
+    for b, (D, I) in zip(batches, got):
+        Do, Io = search_oracle.topk_ip(b, xb, 80)
+        np.testing.assert_array_equal(I.cpu().numpy(), Io + 7)
+        np.testing.assert_array_equal(D.cpu().numpy(), Do)
+    assert all(s_["nomination"] for s_ in ps.last_stats())       # both handles scanned their own int8 copy
+    (D, I), = list(ps.search_batches([torch.from_numpy(batches[0]).cuda()], 2000))
+    Do, Io = search_oracle.topk_ip(batches[0], xb, 2000)
+    np.testing.assert_array_equal(I.cpu().numpy(), Io)
+    ref = IndexFlatIP(128)
+    ref.adopt_device(t)
+    D1, I1 = ref.search_device(torch.from_numpy(batches[4]).cuda(), 80, idx_offset=7)
+    assert torch.equal(I1, got[4][1]) and torch.equal(D1, got[4][0])
+    ps.close()
