@@ -107,6 +107,12 @@ struct proqa_index {
   int q8_suspended_searches = 0;           // eligible searches that ran on the fp16 rows since the suspension / the last failed probe
   int q8_probe_after = 0;
   bool q8_build_due = false;               // an enqueued (begin / finish) search wanted the int8 copy: _finish builds it
+  // an index whose rows change between searches (add, search, add, search, ...) would pay three passes over all rows per
+  // search for a copy that serves one: after two builds in a row that served at most one search each, automatic mode
+  // leaves the first search after a change on the fp16 rows and rebuilds when a second search finds the rows unchanged
+  int q8_searches_on_copy = 0;             // searches that scanned the current copy
+  int q8_short_lived_builds = 0;           // consecutive builds whose copy served <= 1 search
+  uint64_t q8_seen_epoch = 0;              // rows_epoch of the last search that found the copy stale
   int nominate_mode = 1;                   // 0 off, 1 automatic, 2 always (no profitability check); proqa_index_configure_nomination
   bool q8_active = false;                  // the search being enqueued runs its rounds on the int8 copy
   int64_t pending_nq = 0;                  // queries of the search being enqueued (the row-split launch of small batches reads it)
@@ -263,6 +269,8 @@ int ensure_q8(proqa_index* idx, hipStream_t st) {
   idx->q8_suspended_searches = 0;
   idx->q8_probe_after = 0;
   idx->q8_build_due = false;
+  if (idx->q8_epoch != 0) idx->q8_short_lived_builds = idx->q8_searches_on_copy <= 1 ? idx->q8_short_lived_builds + 1 : 0;
+  idx->q8_searches_on_copy = 0;
   if (!idx->col) {
     PROQA_HIP(hipMalloc((void**)&idx->col, 3 * kDim * sizeof(float)));
     PROQA_HIP(hipMalloc((void**)&idx->col_partial, (size_t)kColStatGroups * 3 * kDim * sizeof(float)));
@@ -1283,6 +1291,16 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
     // (mode 2, "always", also takes small shards: tests and experiments)
     if (!nomination_eligible(idx, k)) return PROQA_OK;
     if (idx->q8_epoch != idx->rows_epoch) {
+      // rows that keep changing between searches (see q8_short_lived_builds): the first search after a change scans the fp16
+      // rows, the copy is rebuilt once a second search finds the same rows (mode "always" rebuilds at once)
+      if (idx->q8_searches_on_copy > 1) idx->q8_short_lived_builds = 0;   // the stale copy earned its build
+      if (idx->nominate_mode == 1 && idx->q8_short_lived_builds >= 2 && idx->q8_seen_epoch != idx->rows_epoch) {
+        idx->q8_seen_epoch = idx->rows_epoch;
+        log_line("index %p: rows changed again after an int8 copy that served %d search(es): this search scans the fp16 rows, the "
+                 "copy is rebuilt when the rows stay", (void*)idx, idx->q8_searches_on_copy);
+        return PROQA_OK;
+      }
+      idx->q8_seen_epoch = idx->rows_epoch;
       // the int8 copy is missing or stale.  A search that runs to completion in this call builds it here (allocation, two
       // passes over the rows, one host read).  An ENQUEUED search (_begin) must not synchronise or allocate: it scans
       // the fp16 rows and leaves the build to its _finish, i.e. to the host wait the caller pays anyway
@@ -1302,6 +1320,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
     }
     PROQA_HIP(launch_prep_queries_i8(idx->xq_pad, idx->ws_nq_pad, idx->col, idx->qstats, idx->xq8, idx->qparams, idx->stat_nom, st));
     idx->q8_active = true;
+    ++idx->q8_searches_on_copy;
     return PROQA_OK;
   };
   // ~670 <= k <= ~11700 on a shard much larger than k: one pass against sampled thresholds (search_one_pass)

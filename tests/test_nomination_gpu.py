@@ -505,3 +505,35 @@ def test_row_split_lists_that_overflow_go_to_the_fp16_path(gpu_device, nq):
     np.testing.assert_array_equal(I1, Io)
     np.testing.assert_array_equal(D1, Do)
     assert st1["nomination"] and st1["fallback_rounds"] > 0
+
+
+def test_rows_that_change_between_all_searches_stop_rebuilding_the_copy(gpu_device):
+    """add, search, add, search, ...: the int8 copy (two passes over ALL rows + an allocation) would be rebuilt for every
+    single search.  After two copies in a row that served one search each, automatic mode leaves the first search after a
+    change on the fp16 rows and rebuilds only when a second search finds the rows unchanged.  Exact either way."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(71)
+    nq, k = 300, 40
+    xq = _int_corpus(rng, nq)
+    tq = torch.from_numpy(xq).cuda()
+    parts = [_int_corpus(rng, 70000)] + [_int_corpus(rng, 3000) for _ in range(6)]
+    ix = IndexFlatIP(128)
+    seen = []
+    for i, part in enumerate(parts):
+        ix.add(part)
+        D, I = ix.search_device(tq, k)
+        Do, Io = search_oracle.topk_ip(xq, np.concatenate(parts[:i + 1]), k)
+        np.testing.assert_array_equal(I.cpu().numpy(), Io)
+        np.testing.assert_array_equal(D.cpu().numpy(), Do)
+        seen.append(ix.last_stats()["nomination"])
+    # builds 1-3 happen (the third finds two short-lived predecessors), from then on a changed index is searched on fp16 rows
+    assert seen == [True, True, True, False, False, False, False], seen
+    D, I = ix.search_device(tq, k)                      # the rows stayed: now the copy is rebuilt
+    assert ix.last_stats()["nomination"]
+    np.testing.assert_array_equal(I.cpu().numpy(), search_oracle.topk_ip(xq, np.concatenate(parts), k)[1])
+    for _ in range(3):                                  # ... and a copy that serves several searches resets the verdict
+        ix.search_device(tq, k)
+    ix.add(parts[1])
+    ix.search_device(tq, k)
+    assert ix.last_stats()["nomination"]
