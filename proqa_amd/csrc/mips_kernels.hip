@@ -1393,13 +1393,18 @@ __device__ __forceinline__ void keep_nominees(uint2 rec, const ExactCtx& ex, uns
 //        with five (28.5 KiB) the 2032 merges of a round ran as 1.6 waves of workgroups, which is what an L2-resident early
 //        round's merge is bound by; a 64-VGPR form (eight per CU, rows gathered in two halves) measured slower (ABLATIONS R5.5)
 constexpr int kMergeF16 = 0, kMergeExactF32 = 1, kMergeNominatedI8 = 2;
+// keys the merge of a nominating round holds when k <= 128: k running keys + at most 512 passing ones (a round yields
+// ~1.6 k of them), 1024 nominated rows; 8.6 KiB of LDS and <= 64 VGPRs: eight workgroups per CU
+constexpr int kNominatedSortKeys = 1024;
 template <int MODE, int CAP, int T = kMergeThreads>
-__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE == 1 ? 4 : (MODE == 2 ? 7 : 8))))
+__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE == 1 ? 4 : (MODE == 2 && CAP > kNominatedSortKeys ? 7 : 8))))
 void topk_merge(MergeArgs a) {
   constexpr bool EXACT = MODE == kMergeExactF32;   // nominated rows are re-scored from the float32 rows in double
   constexpr bool NOM = MODE == kMergeNominatedI8;  // ... from the fp16 rows on the fp16 filter's MFMA sequence
   constexpr bool LEAN = NOM;                       // its lists live inside keys[]
   constexpr bool RESCORE = EXACT || NOM;
+  constexpr bool QLDS = NOM && CAP <= kNominatedSortKeys;   // the query row of the re-scoring in LDS (see there)
+  __shared__ __attribute__((aligned(16))) char s_qrow[QLDS ? kRowBytes : 16];
   __shared__ __attribute__((aligned(16))) unsigned long long keys[CAP];
   // records to gather, (list within the pass << 4) | slot: queued so that their fetches are independent and evenly
   // spread over the threads (LDS is budgeted for 8 workgroups per CU: records beyond the queue are fetched on the spot)
@@ -1440,6 +1445,9 @@ void topk_merge(MergeArgs a) {
     __shared__ unsigned s_nom_own[LEAN ? 1 : CAP];
     __shared__ unsigned s_n_nom;
     if (tid == 0) s_n_nom = 0;   // visible after the first barrier below
+    if constexpr (QLDS) {
+      if (tid < kRowBytes / 16) ((uint4*)s_qrow)[tid] = ((const uint4*)((const char*)a.xq16 + (size_t)q * kRowBytes))[tid];
+    }
     ex.nom = LEAN ? (unsigned*)(keys + CAP / 2) : s_nom_own;   // lean: CAP row ids in the upper half of keys[]
     ex.n_nom = &s_n_nom;
   }
@@ -1733,10 +1741,16 @@ void topk_merge(MergeArgs a) {
     const float tau_exact = a.tau[q];
     const int lane = tid & 63, w = tid >> 6, li = lane & 31, half = lane >> 5;
     if (n_nom) {   // workgroup-uniform
-      f16x8 qf[8];
+      // The query's B fragments: resident in 32 VGPRs -- or, in the eight-workgroups-per-CU form (<= 64 VGPRs), read from
+      // the copy of the query row in LDS right in front of every MFMA (all lanes of a half read the same 16 bytes: a
+      // broadcast).  With the fragments resident at 64 VGPRs hipcc ran the eight row pieces of a batch through ONE register
+      // quad: eight dependent memory round trips per batch instead of one (what made the 64-VGPR form of R5.10 slow).
+      f16x8 qf[QLDS ? 1 : 8];
       const char* qrow = (const char*)a.xq16 + (size_t)q * kRowBytes;
+      if constexpr (!QLDS) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[j] = *(const f16x8*)(qrow + (2 * j + half) * 16);
+        for (int j = 0; j < 8; ++j) qf[j] = *(const f16x8*)(qrow + (2 * j + half) * 16);
+      }
       for (unsigned c0 = (unsigned)w * 32; c0 < n_nom; c0 += (T / 64) * 32) {   // wave-uniform trip count
         const unsigned mine = c0 + (unsigned)li < n_nom ? c0 + (unsigned)li : c0;
         const unsigned row = ex.nom[mine];
@@ -1745,8 +1759,16 @@ void topk_merge(MergeArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(ap + (2 * j + half) * 16);
         f32x16 acc = {0};
+        if constexpr (QLDS) {
+          unsigned qoff = (unsigned)half * 16u;
+          asm volatile("" : "+v"(qoff));   // (born in the loop body: the reads below stay in it)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[j], acc, 0, 0, 0);
+          for (int j = 0; j < 8; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], *(const f16x8*)(s_qrow + qoff + 32 * j), acc, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], qf[j], acc, 0, 0, 0);
+        }
         if (li == 0) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s_sc[w][(r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
@@ -1865,7 +1887,7 @@ void topk_merge(MergeArgs a) {
   } else if (total <= 4u * T) {
     unsigned long long v[4];
     finish(v);
-  } else if (total <= 8u * T) {
+  } else if (CAP >= 8 * T && total <= 8u * T) {   // (CAP is a compile-time constant: a 4 T merge carries no 8-key network)
     unsigned long long v[8];
     finish(v);
   } else if constexpr (CAP > 8 * T) {
@@ -2633,7 +2655,13 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   const bool big = a.sort_cap > kMaxSortKeys;
   if (a.xb16) {   // records of the int8 nomination scan
     if (big || a.xq32 || a.compact || a.inclusive || a.bound_keys) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    // k <= 128 (every nominating search): the merge that holds 1024 keys -- EIGHT workgroups per CU, i.e. the 2032 merges of a
+    // round resident at once instead of 1792 + a second wave of 240 (PROQA_MERGE_NOM_CAP=2048: the seven-per-CU form, A/B)
+    static const bool kSmallNom = !(getenv("PROQA_MERGE_NOM_CAP") && atoi(getenv("PROQA_MERGE_NOM_CAP")) == 2048);
+    if (kSmallNom && a.k <= 128)
+      hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kNominatedSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
   } else if (a.xq32) {
     if (big)
       hipLaunchKernelGGL((topk_merge<kMergeExactF32, kBigSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
