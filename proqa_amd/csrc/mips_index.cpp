@@ -474,8 +474,11 @@ const double kBudget = getenv("PROQA_CAND_BUDGET") ? atof(getenv("PROQA_CAND_BUD
 // nominates ~1.9 x the rows that pass, so the time of a search follows the nominations more steeply than an fp16 search
 // follows its candidates; two or three more rounds (each ~35 us of launch + merge latency) are cheaper than the rows
 // they save (scripts/dev_schedule_sweep.py, 1 .. 2032 queries x 2.25M .. 18M rows: ABLATIONS R5.8).
+// Small batches (qw == 1) on the int8 copy: 4 -- their merges are few workgroups on an idle chip, what they save is the ~9 us
+// every launch costs before it streams (re-swept in round 6, 32 queries: 0.558 against 0.566 ms at 18M rows, 0.200 against
+// 0.207 at 2.25M; 2032 queries stay at 2: 4.271 against 4.299 / 4.329 ms for 3 / 4: ABLATIONS R6.10).
 double growth_for(int k, int configured, int qw, bool nominating = false) {
-  const int g = configured > 0 ? configured : nominating ? 2 : (qw == 1 ? 8 : 4);
+  const int g = configured > 0 ? configured : nominating ? (qw == 1 ? 4 : 2) : (qw == 1 ? 8 : 4);
   // big pages: 60 % of the free keys of the big merge (the rest is headroom for the spread of the candidate count)
   const double budget = k <= kPageK ? kBudget : 0.6 * (kBigSortKeys - k);
   return std::min<double>(g, budget / k);
@@ -786,8 +789,8 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
   // Bootstrap: exact top-k of the first rows in two launches instead of the first three or four (dense) rounds.
   // Not for pages after the first (bounded), exact-float32 mode (its scores are re-computed from float32 rows),
   // k beyond the select kernel's bound, or an index too small to need it.
-  // (rounds on the int8 copy nominate ~3 x the candidates of an fp16 round: never the growth 8 of the small batches)
-  const int gqw = idx->q8_active ? 2 : qw;
+  // (rounds on the int8 copy nominate ~2 x the candidates of an fp16 round: growth_for gives them their own, smaller growth)
+  const int gqw = qw;
   long long boot = 0;
   if (use_bootstrap && idx->bootstrap_rows > 0 && !bounded && !idx->exact && page_k <= kBootstrapMaxK &&
       page_k <= idx->bootstrap_rows / 4 && idx->n >= 4ll * idx->bootstrap_rows) {
