@@ -116,6 +116,7 @@ struct proqa_index {
   int nominate_mode = 1;                   // 0 off, 1 automatic, 2 always (no profitability check); proqa_index_configure_nomination
   bool q8_active = false;                  // the search being enqueued runs its rounds on the int8 copy
   int64_t pending_nq = 0;                  // queries of the search being enqueued (the row-split launch of small batches reads it)
+  double page_growth = 2.0;                // growth cap of the rounds being enqueued (the nominating merge's size follows it)
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
   proqa::NominateParams* qparams = nullptr;   // workspace [ws_nq_pad]
   unsigned long long* stat_nom = nullptr;  // workspace [ws_nq_pad] rows re-scored per query
@@ -669,6 +670,9 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     ma.xq16 = idx->xq_pad;
     ma.xb16 = idx->xb;
     ma.stat_nominated = idx->stat_nom;
+    // a round nominates ~2 k x growth rows per query (N(0,1) data; a query's count varies by +-30 % around that): the
+    // 1024-key merge (eight workgroups per CU) where that leaves a factor ~4 of headroom, else the 2048-key one
+    ma.nom_keys = (double)k * idx->page_growth <= 200.0 ? 1024 : 2048;
 #ifdef PROQA_MERGE_STAMPS
     if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -740,6 +744,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.xq16 = nullptr;
   ma.xb16 = nullptr;
   ma.stat_nominated = nullptr;
+  ma.nom_keys = 0;
 #ifdef PROQA_MERGE_STAMPS
   if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -812,6 +817,7 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
   const int first_cap = (sort_capacity(page_k) - page_k) / kStageRows * kStageRows;
   const int first = page_k > kPageK ? first_cap : std::min<int>(idx->first_slab_rows, first_cap);
   const double page_growth = growth_for(page_k, idx->growth, gqw, idx->q8_active);
+  idx->page_growth = page_growth;
   plan->slabs = boot && kEqualGrowth && kGrowthList.empty() ? plan_slabs_equal(idx->n, boot, page_growth)
                                                           : plan_slabs(idx->n, first, page_growth, boot);
   plan->boot = boot;

@@ -111,6 +111,7 @@ struct MergeArgs {
   int compact;                   // the launch logged compact lists (FilterArgs::compact)
   // int8 nomination rounds (all NULL otherwise): the records hold int32 scores and the integer threshold they were tested
   // against; every score above it names a row that is re-scored from xb16 against xq16 on the filter's MFMA sequence
+  int nom_keys;                  // keys the merge of this nominating round may hold: 1024 (rounds that nominate few rows) or 2048
   const void* xq16;              // fp16 [nq_pad,128] padded queries
   const char* xb16;              // fp16 corpus rows of this shard
   unsigned long long* stat_nominated;  // [nq_pad] rows re-scored per query (statistics)

@@ -1397,7 +1397,7 @@ constexpr int kMergeF16 = 0, kMergeExactF32 = 1, kMergeNominatedI8 = 2;
 // ~1.6 k of them), 1024 nominated rows; 8.6 KiB of LDS and <= 64 VGPRs: eight workgroups per CU
 constexpr int kNominatedSortKeys = 1024;
 template <int MODE, int CAP, int T = kMergeThreads>
-__global__ __launch_bounds__(T, CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE == 1 ? 4 : (MODE == 2 && CAP > kNominatedSortKeys ? 7 : 8))))
+__global__ __launch_bounds__(T, T > 512 || CAP > kBigSortKeys ? 1 : (CAP > kMidSortKeys ? (MODE ? 1 : 2) : (CAP > kMaxSortKeys || MODE == 1 ? 4 : (MODE == 2 && CAP > kNominatedSortKeys ? 7 : 8))))
 void topk_merge(MergeArgs a) {
   constexpr bool EXACT = MODE == kMergeExactF32;   // nominated rows are re-scored from the float32 rows in double
   constexpr bool NOM = MODE == kMergeNominatedI8;  // ... from the fp16 rows on the fp16 filter's MFMA sequence
@@ -2655,10 +2655,19 @@ hipError_t launch_merge(const MergeArgs& a, unsigned nq_pad, hipStream_t st) {
   const bool big = a.sort_cap > kMaxSortKeys;
   if (a.xb16) {   // records of the int8 nomination scan
     if (big || a.xq32 || a.compact || a.inclusive || a.bound_keys) return hipErrorInvalidValue;
-    // k <= 128 (every nominating search): the merge that holds 1024 keys -- EIGHT workgroups per CU, i.e. the 2032 merges of a
-    // round resident at once instead of 1792 + a second wave of 240 (PROQA_MERGE_NOM_CAP=2048: the seven-per-CU form, A/B)
+    // Which merge: (a) at most 256 queries -- the chip is empty during their merges, whose time is a chain of dependent round
+    // trips: a 1024-thread workgroup per query re-scores a round's nominated rows in ONE trip of 16 waves instead of three
+    // of four (PROQA_MERGE_NOM_WIDE=0: the 256-thread form, A/B); (b) rounds that nominate few rows (a.nom_keys == 1024: k x
+    // growth <= 200, e.g. the k = 80 search of thousands of queries) -- the merge that holds 1024 keys, EIGHT workgroups per CU,
+    // i.e. the 2032 merges of a round resident at once instead of 1792 + a second wave of 240 (PROQA_MERGE_NOM_CAP=2048: the
+    // seven-per-CU form, A/B); (c) 2048 keys, seven per CU.  A round that nominates more rows than its merge holds is re-scanned
+    // on the overflow-safe path AND suspends the int8 rounds: (b) is only taken with a factor ~4 of headroom.
     static const bool kSmallNom = !(getenv("PROQA_MERGE_NOM_CAP") && atoi(getenv("PROQA_MERGE_NOM_CAP")) == 2048);
-    if (kSmallNom && a.k <= 128)
+    static const bool kWideNom = !(getenv("PROQA_MERGE_NOM_WIDE") && atoi(getenv("PROQA_MERGE_NOM_WIDE")) == 0);
+    if (kWideNom && nq_pad <= 256)
+      hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys, kOnePassMergeThreads>), dim3(nq_pad), dim3(kOnePassMergeThreads), 0,
+                         st, a);
+    else if (kSmallNom && a.nom_keys == kNominatedSortKeys)
       hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kNominatedSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
     else
       hipLaunchKernelGGL((topk_merge<kMergeNominatedI8, kMaxSortKeys>), dim3(nq_pad), dim3(kMergeThreads), 0, st, a);
