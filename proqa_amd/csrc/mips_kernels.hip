@@ -602,7 +602,8 @@ __device__ __forceinline__ unsigned nominee_mask(const i32x16& acc, float thr) {
   const int ti = thr < -2147483000.f ? (int)0x80000000 : (int)__builtin_floorf(thr);
   // mask = 2 mask + (acc[i] > ti), i = 15 .. 0: a compare into VCC and an add-with-carry per accumulator, no temporaries
   // (the plain C++ form costs ten more registers than the kernel's 128 allow).  The accumulators were read by the
-  // column maximum before this point: no MFMA result is in flight.
+  // column maximum before this point: no MFMA result is in flight.  (Two interleaved chains -- VCC and an SGPR pair -- and
+  // v_cvt_flr_i32_f32 for the threshold: measured within noise of this form, ABLATIONS R6.8.)
   unsigned mask = 0u;
 #define PROQA_BIT(n) "v_cmp_gt_i32 vcc, %" #n ", %17\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
   asm volatile(PROQA_BIT(16) PROQA_BIT(15) PROQA_BIT(14) PROQA_BIT(13) PROQA_BIT(12) PROQA_BIT(11) PROQA_BIT(10) PROQA_BIT(9)
