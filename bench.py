@@ -888,6 +888,7 @@ def main():
     xq = gen_queries(nq, device)
     sharded = ShardedIndexFlatIP(n, preallocate=False, transport=args.transport)
     sharded.adopt_local(xb)
+    sharded.prepare()      # the int8 copy of this rank's rows now (otherwise the first enqueued step's finish builds it)
     result = {}
 
     def step():
