@@ -475,11 +475,12 @@ const double kBudget = getenv("PROQA_CAND_BUDGET") ? atof(getenv("PROQA_CAND_BUD
 // nominates ~1.9 x the rows that pass, so the time of a search follows the nominations more steeply than an fp16 search
 // follows its candidates; two or three more rounds (each ~35 us of launch + merge latency) are cheaper than the rows
 // they save (scripts/dev_schedule_sweep.py, 1 .. 2032 queries x 2.25M .. 18M rows: ABLATIONS R5.8).
-// Small batches (qw == 1) on the int8 copy: 4 -- their merges are few workgroups on an idle chip, what they save is the ~9 us
-// every launch costs before it streams (re-swept in round 6, 32 queries: 0.558 against 0.566 ms at 18M rows, 0.200 against
-// 0.207 at 2.25M; 2032 queries stay at 2: 4.271 against 4.299 / 4.329 ms for 3 / 4: ABLATIONS R6.10).
+// Small batches (qw == 1) on the int8 copy: 6 -- their merges are few workgroups on an idle chip, what they save is the ~9 us
+// every launch costs before it streams (re-swept in round 6 with the 1024-thread merges, stream time for growth 4 / 6 / 8:
+// one question 0.502 / 0.488 / 0.499 ms at 18M rows, 32 queries 0.522 / 0.516 / 0.517, 128 queries 0.585 / 0.581 / 0.589; 2032
+// queries stay at 2: 4.271 against 4.299 / 4.329 ms for 3 / 4: ABLATIONS R6.10).
 double growth_for(int k, int configured, int qw, bool nominating = false) {
-  const int g = configured > 0 ? configured : nominating ? (qw == 1 ? 4 : 2) : (qw == 1 ? 8 : 4);
+  const int g = configured > 0 ? configured : nominating ? (qw == 1 ? 6 : 2) : (qw == 1 ? 8 : 4);
   // big pages: 60 % of the free keys of the big merge (the rest is headroom for the spread of the candidate count)
   const double budget = k <= kPageK ? kBudget : 0.6 * (kBigSortKeys - k);
   return std::min<double>(g, budget / k);
