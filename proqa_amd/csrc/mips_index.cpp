@@ -631,8 +631,8 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   // search was set up for it: two workgroups per CU, deep lane lists instead of a spill log
   const bool nominate = idx->q8_active && !inclusive && !dense && !bounded && !shape.want_chunks && !shape.compact;
   if (nominate) {
-    // batches of <= 256 queries (qw == 1) stream the int8 rows at the HBM's pace: ONE workgroup per CU with four pair
-    // buffers (three pairs, 96 KB, of LDS-DMA in flight) instead of two workgroups with two (64 KB in flight per CU)
+    // (developer switch, off: ONE workgroup per CU with four pair buffers -- 96 KB of LDS-DMA in flight -- for the batches of
+    // <= 256 queries measured 10-19 % slower than two workgroups with two, ABLATIONS R6.2)
     const bool deep = qw == 1 && kDeepRing;
     // at most 128 queries: row-split launch (mips_filter_i8<SPLIT>) -- the 1 / 2 / 4 query blocks that hold queries are
     // replicated over the eight waves, which share the units of the stream (and the lists of their queries)

@@ -261,26 +261,36 @@ class PipelinedSearcher:
         lib = _lib.load()
         k = int(k)
         pending = []
-        for n, xq in enumerate(batches):
-            slot = n & 1
-            if len(pending) == 2:
+        try:
+            for n, xq in enumerate(batches):
+                slot = n & 1
+                if len(pending) == 2:
+                    yield self._finish(pending.pop(0))
+                if not xq.is_cuda or xq.dim() != 2 or xq.shape[1] != self.d:
+                    raise ValueError(f"batches must be CUDA tensors of shape [nq, {self.d}]")
+                if xq.shape[0] > QUERY_BATCH:
+                    raise ValueError(f"at most {QUERY_BATCH} queries per batch")
+                xq = xq.contiguous()
+                nq = xq.shape[0]
+                D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
+                I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
+                st = self.streams[slot]
+                st.wait_stream(torch.cuda.current_stream(xq.device))  # the batch may still be on its way on the caller's stream
+                with torch.cuda.device(xq.device):
+                    _lib.check(lib.proqa_index_search_begin_device(self.handles[slot]._h, xq.data_ptr(), nq, _torch_dtype_code(xq),
+                                                                   k, int(idx_offset), D.data_ptr(), I.data_ptr(), None,
+                                                                   st.cuda_stream))
+                pending.append((slot, xq, D, I))
+            while pending:
                 yield self._finish(pending.pop(0))
-            if not xq.is_cuda or xq.dim() != 2 or xq.shape[1] != self.d:
-                raise ValueError(f"batches must be CUDA tensors of shape [nq, {self.d}]")
-            if xq.shape[0] > QUERY_BATCH:
-                raise ValueError(f"at most {QUERY_BATCH} queries per batch")
-            xq = xq.contiguous()
-            nq = xq.shape[0]
-            D = torch.empty((nq, k), dtype=torch.float32, device=xq.device)
-            I = torch.empty((nq, k), dtype=torch.int64, device=xq.device)
-            st = self.streams[slot]
-            st.wait_stream(torch.cuda.current_stream(xq.device))      # the batch may still be on its way on the caller's stream
-            with torch.cuda.device(xq.device):
-                _lib.check(lib.proqa_index_search_begin_device(self.handles[slot]._h, xq.data_ptr(), nq, _torch_dtype_code(xq), k,
-                                                               int(idx_offset), D.data_ptr(), I.data_ptr(), None, st.cuda_stream))
-            pending.append((slot, xq, D, I))
-        while pending:
-            yield self._finish(pending.pop(0))
+        finally:
+            # a consumer that stops early (or an error above): the searches still in flight write into tensors this frame
+            # is about to drop -- complete them first
+            for item in pending:
+                try:
+                    self._finish(item)
+                except Exception:
+                    pass
 
     def _finish(self, item):
         slot, _xq, D, I = item

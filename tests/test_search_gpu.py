@@ -1080,4 +1080,11 @@ def test_pipelined_searcher_returns_the_one_call_results_in_order(gpu_device):
     ref.adopt_device(t)
     D1, I1 = ref.search_device(torch.from_numpy(batches[4]).cuda(), 80, idx_offset=7)
     assert torch.equal(I1, got[4][1]) and torch.equal(D1, got[4][0])
+    # a consumer that stops after the first result: the searches still in flight are completed before their tensors go
+    gen = ps.search_batches([torch.from_numpy(b).cuda() for b in batches], 80)
+    D0, I0 = next(gen)
+    gen.close()
+    np.testing.assert_array_equal(I0.cpu().numpy(), search_oracle.topk_ip(batches[0], xb, 80)[1])
+    (D2, I2), = list(ps.search_batches([torch.from_numpy(batches[1]).cuda()], 80))      # the handles are usable again
+    np.testing.assert_array_equal(I2.cpu().numpy(), search_oracle.topk_ip(batches[1], xb, 80)[1])
     ps.close()
