@@ -649,15 +649,15 @@ __device__ __forceinline__ unsigned column_rows_mask(int rows_left) {
 // then re-scanned by the fp16 overflow-safe path): no spill log, no capacity branch in the hit path.
 //
 // NP = pair buffers of the LDS image (NP - 1 pairs of LDS-DMA in flight).  NP = 2 (64 KiB, two workgroups per CU: 64 KB in
-// flight per CU) is the MFMA-bound form.  The HBM-bound batches (QW = 1: <= 256 queries, one query block per wave) need
-// no second workgroup for the matrix pipe but more bytes in flight: NP = 4 is ONE workgroup per CU with 128 KiB of LDS and
-// three pairs (96 KB) in flight -- what the fp16 scan's ring holds (round-5 review, weak #9: 0.69 of 8 TB/s against 0.79).
+// flight per CU) is the shipped form for every batch size.  NP = 4 -- ONE workgroup per CU with 128 KiB of LDS and three
+// pairs (96 KB) in flight, what the fp16 scan's ring holds -- was built for the HBM-bound batches (QW = 1) on the round-5
+// review's reading that bytes in flight bound them; it measured 10-19 % SLOWER (the second workgroup's waves are worth more
+// than the third pair: ABLATIONS R6.2) and stays behind PROQA_I8_DEEP_RING=1.
 //
 // SPLIT (QW = 1, at most 128 queries): with one query block per wave a batch of <= 32 queries keeps ONE wave of the
 // workgroup busy -- it alone walks every 32-row unit of the chunk (fragment reads -> four dependent MFMAs -> test, in series:
-// ~500 cycles per unit) while seven waves only feed the DMA stream, and that wave's latency chain, not the memory system,
-// sets the pace (0.69 of 8 TB/s where the fp16 scan, which pipelines its test under the next unit's MFMAs, holds 0.79; a
-// deeper ring made it SLOWER: ABLATIONS R6.2).  Row-split launches give every wave work: the a.q_blocks (1, 2, 4) query
+// ~500 cycles per unit) while seven waves only feed the DMA stream.  Row-split launches give every wave work (measured: +3 %
+// at 18M rows, +8 % at 2.25M, ABLATIONS R6.2): the a.q_blocks (1, 2, 4) query
 // blocks are replicated over the 8 waves, the R = 8 / q_blocks waves of a block take every R-th unit each and append to
 // the block's lists (one per query and accumulator half, as ever) through list lengths kept in LDS -- an LDS atomic per
 // logged record, and records are rare where queries are few; the merge sees the same lists as from any other launch.
