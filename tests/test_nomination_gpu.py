@@ -32,7 +32,10 @@ def _both(xb, xq, k, add=None, idx_offset=0):
 
 
 @pytest.mark.parametrize("n,nq,k,lo,hi", [(70000, 600, 80, -4, 4), (20000, 300, 80, -4, 4), (100000, 257, 5, -8, 8),
-                                          (40000, 512, 128, 0, 1), (9000, 40, 80, -4, 4), (70000, 1100, 1, -2, 2)])
+                                          (40000, 512, 128, 0, 1), (9000, 40, 80, -4, 4), (70000, 1100, 1, -2, 2),
+                                          # either side of the rule that picks the nominating merge (k x growth <= 200: the
+                                          # 1024-key, eight-per-CU form), and k = 128 on the 1024-thread merge of a small batch
+                                          (70000, 600, 100, -4, 4), (70000, 600, 101, -4, 4), (90000, 200, 128, -4, 4)])
 def test_integer_corpora_ids_and_scores_identical_to_the_oracle(gpu_device, n, nq, k, lo, hi):
     rng = np.random.default_rng(n + nq + k)
     xb, xq = _int_corpus(rng, n, lo, hi), _int_corpus(rng, nq, lo, hi)
