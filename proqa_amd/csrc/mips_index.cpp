@@ -117,6 +117,11 @@ struct proqa_index {
   bool q8_active = false;                  // the search being enqueued runs its rounds on the int8 copy
   int64_t pending_nq = 0;                  // queries of the search being enqueued (the row-split launch of small batches reads it)
   double page_growth = 2.0;                // growth cap of the rounds being enqueued (the nominating merge's size follows it)
+  // the 1024-key nominating merge (eight workgroups per CU) is sized for rows that nominate ~2 x their candidates; rows that
+  // nominate more overflow it although the 2048-key merge would hold them: the first such search switches this index to the
+  // larger merge instead of suspending the int8 rounds (until the rows change)
+  bool small_merge_ok = true;
+  bool used_small_merge = false;           // a round of the search being enqueued took the 1024-key merge
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
   proqa::NominateParams* qparams = nullptr;   // workspace [ws_nq_pad]
   unsigned long long* stat_nom = nullptr;  // workspace [ws_nq_pad] rows re-scored per query
@@ -161,6 +166,8 @@ const bool kDebugRounds = debug_flag("PROQA_DEBUG_ROUNDS");
 // (measured slower: off), and the row-split launch of <= 128 queries (on)
 const bool kDeepRing = getenv("PROQA_I8_DEEP_RING") && atoi(getenv("PROQA_I8_DEEP_RING")) != 0;
 const bool kRowSplit = !(getenv("PROQA_I8_ROW_SPLIT") && atoi(getenv("PROQA_I8_ROW_SPLIT")) == 0);
+// k x growth up to which a nominating round takes the 1024-key merge (developer / test override: PROQA_NOM_SMALL_MERGE_LIMIT)
+const double kSmallMergeLimit = getenv("PROQA_NOM_SMALL_MERGE_LIMIT") ? atof(getenv("PROQA_NOM_SMALL_MERGE_LIMIT")) : 200.0;
 
 // counters of the last float32 -> fp16 conversion: {values fp16 cannot hold exactly, values beyond its range}
 int read_inexact(proqa_index* idx, const char* what, hipStream_t st, unsigned* n_inexact) {
@@ -272,6 +279,7 @@ int ensure_q8(proqa_index* idx, hipStream_t st) {
   idx->q8_build_due = false;
   if (idx->q8_epoch != 0) idx->q8_short_lived_builds = idx->q8_searches_on_copy <= 1 ? idx->q8_short_lived_builds + 1 : 0;
   idx->q8_searches_on_copy = 0;
+  idx->small_merge_ok = true;
   if (!idx->col) {
     PROQA_HIP(hipMalloc((void**)&idx->col, 3 * kDim * sizeof(float)));
     PROQA_HIP(hipMalloc((void**)&idx->col_partial, (size_t)kColStatGroups * 3 * kDim * sizeof(float)));
@@ -673,7 +681,8 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     ma.stat_nominated = idx->stat_nom;
     // a round nominates ~2 k x growth rows per query (N(0,1) data; a query's count varies by +-30 % around that): the
     // 1024-key merge (eight workgroups per CU) where that leaves a factor ~4 of headroom, else the 2048-key one
-    ma.nom_keys = (double)k * idx->page_growth <= 200.0 ? 1024 : 2048;
+    ma.nom_keys = idx->small_merge_ok && (double)k * idx->page_growth <= kSmallMergeLimit ? 1024 : 2048;
+    if (ma.nom_keys == 1024) idx->used_small_merge = true;
 #ifdef PROQA_MERGE_STAMPS
     if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -1185,6 +1194,16 @@ void note_nomination(proqa_index* idx, int64_t nq) {
   const double per_query = (double)idx->stats.nominated / (double)std::max<int64_t>(nq, 1);
   const double limit = std::max(4096.0, (double)idx->n / 2048.0);
   const bool bad = per_query > limit || idx->stats.fallback_rounds > 0;
+  if (bad && per_query <= limit && idx->used_small_merge && idx->small_merge_ok) {
+    // the rounds overflowed with the 1024-key merge in use and the nominations are within the limit: these rows nominate
+    // more per round than that merge is sized for -- the 2048-key merge from now on, no suspension (if it overflows too,
+    // the next search suspends the rounds)
+    idx->small_merge_ok = false;
+    log_line("index %p: a round's nominations overflowed the 1024-key merge (%.0f rows re-scored per query, %d overflow-safe rounds): "
+             "2048-key merges from now on", (void*)idx, per_query, idx->stats.fallback_rounds);
+    idx->stats.nomination_state = nomination_state_of(idx);
+    return;
+  }
   if (bad) {
     // One such batch may be an outlier (an adversarial or degenerate set of queries) on rows that quantise well: the
     // suspension is lifted by a later search that passes.  First probe after 8 eligible searches, then 16, 32, 64, 64, ...
@@ -1242,6 +1261,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   idx->stats.nomination_state = nomination_state_of(idx);
   idx->q8_active = false;
   idx->pending_nq = nq;
+  idx->used_small_merge = false;
   if (nq == 0) return PROQA_OK;
   PROQA_ON_DEVICE(idx->device);
 

@@ -540,3 +540,42 @@ def test_rows_that_change_between_all_searches_stop_rebuilding_the_copy(gpu_devi
     ix.add(parts[1])
     ix.search_device(tq, k)
     assert ix.last_stats()["nomination"]
+
+
+def test_rows_that_overflow_the_small_merge_move_to_the_large_one_not_to_the_fp16_scan(gpu_device):
+    """The 1024-key nominating merge (eight workgroups per CU) is chosen where a round is expected to nominate a quarter of
+    what it holds.  Rows that nominate more overflow it -- the round is re-scanned exactly -- and the index then moves to the
+    2048-key merge instead of suspending the int8 rounds.  Forced here: the rule's limit raised so that rounds growing by 8
+    (~1100 nominations per query) take the small merge."""
+    import subprocess
+    import sys
+    import os
+    code = r"""
+import numpy as np, torch
+from oracle import search_oracle
+from proqa_amd.index import IndexFlatIP
+rng = np.random.default_rng(3)
+xb = rng.standard_normal((400000, 128)).astype(np.float16)
+xq = rng.standard_normal((600, 128)).astype(np.float16)
+ix = IndexFlatIP(128); ix.configure(256, 8); ix.add(xb)
+tq = torch.from_numpy(xq).cuda()
+Do, Io = search_oracle.topk_ip(xq, xb, 80)
+for i in range(3):
+    D, I = ix.search_device(tq, 80)
+    st = ix.last_stats()
+    ov = np.mean([len(set(a) & set(b)) / 80 for a, b in zip(I.cpu().numpy(), Io)])
+    print("RESULT", i, st["nomination"], st["nomination_state"], st["fallback_rounds"], float(ov) > 1 - 1e-4)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PROQA_LOG="1", PROQA_NOM_SMALL_MERGE_LIMIT="100000", PYTHONPATH=root)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rows = [ln.split()[1:] for ln in p.stdout.splitlines() if ln.startswith("RESULT")]
+    assert len(rows) == 3
+    # search 0: int8 rounds with the small merge, overflow -> exact by the overflow-safe path, NOT suspended
+    assert rows[0][1] == "True" and rows[0][2] == "on" and int(rows[0][3]) > 0 and rows[0][4] == "True", rows
+    # searches 1, 2: int8 rounds with the large merge, nothing overflows
+    for r in rows[1:]:
+        assert r[1] == "True" and r[2] == "on" and int(r[3]) == 0 and r[4] == "True", rows
+    assert sum("overflowed the 1024-key merge" in ln for ln in p.stderr.splitlines()) == 1, p.stderr[-1500:]
+    assert "suspended" not in p.stderr
