@@ -122,6 +122,7 @@ struct proqa_index {
   // larger merge instead of suspending the int8 rounds (until the rows change)
   bool small_merge_ok = true;
   bool used_small_merge = false;           // a round of the search being enqueued took the 1024-key merge
+  unsigned overflow_bits = 0;              // OR of the overflow words of the search's rounds (bit 1 alone: only a merge's capacity)
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
   proqa::NominateParams* qparams = nullptr;   // workspace [ws_nq_pad]
   unsigned long long* stat_nom = nullptr;  // workspace [ws_nq_pad] rows re-scored per query
@@ -885,6 +886,7 @@ int page_complete(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64
   unsigned* word = idx->overflow + kMaxRounds - 1;
   for (size_t r = 0; r < slabs.size(); ++r) {
     if (!idx->mirror->overflow[r]) continue;
+    idx->overflow_bits |= idx->mirror->overflow[r];
     std::vector<Slab> todo;
     auto push_quarters = [&](const Slab& sl) {   // pushed in reverse: the stack pops them in row order
       const long long q = round_up<long long>(ceil_div<long long>(sl.r1 - sl.r0, 4), kStageRows);
@@ -1194,10 +1196,10 @@ void note_nomination(proqa_index* idx, int64_t nq) {
   const double per_query = (double)idx->stats.nominated / (double)std::max<int64_t>(nq, 1);
   const double limit = std::max(4096.0, (double)idx->n / 2048.0);
   const bool bad = per_query > limit || idx->stats.fallback_rounds > 0;
-  if (bad && per_query <= limit && idx->used_small_merge && idx->small_merge_ok) {
-    // the rounds overflowed with the 1024-key merge in use and the nominations are within the limit: these rows nominate
-    // more per round than that merge is sized for -- the 2048-key merge from now on, no suspension (if it overflows too,
-    // the next search suspends the rounds)
+  if (bad && per_query <= limit && idx->used_small_merge && idx->small_merge_ok && idx->overflow_bits == 2u) {
+    // what overflowed was the capacity of the 1024-key merge alone (no lane list of the scan: bit 0), and the nominations
+    // are within the limit: these rows nominate more per round than that merge is sized for -- the 2048-key merge from now
+    // on, no suspension (if that overflows too, the next search suspends the rounds)
     idx->small_merge_ok = false;
     log_line("index %p: a round's nominations overflowed the 1024-key merge (%.0f rows re-scored per query, %d overflow-safe rounds): "
              "2048-key merges from now on", (void*)idx, per_query, idx->stats.fallback_rounds);
@@ -1262,6 +1264,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   idx->q8_active = false;
   idx->pending_nq = nq;
   idx->used_small_merge = false;
+  idx->overflow_bits = 0;
   if (nq == 0) return PROQA_OK;
   PROQA_ON_DEVICE(idx->device);
 

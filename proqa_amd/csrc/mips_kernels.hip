@@ -1733,9 +1733,12 @@ void topk_merge(MergeArgs a) {
     // scan gives it.  Lane (li, half) ends up with the scores of rows (r & 3) + 8 (r >> 2) + 4 half of the batch in every
     // column; column 0 hands them to lanes 0..31 through LDS, which test and append them.
     __shared__ float s_sc[T / 64][32];
+    // (overflow word of a nominating round: bit 0 = a lane list of the scan was full, bit 1 = this merge's capacity, bit 2 =
+    // more nominations than even the 2048-key merge holds -- the host moves an index from the 1024-key to the 2048-key merge
+    // on bit 1 alone, mips_index.cpp note_nomination)
     unsigned n_nom = *ex.n_nom;
     if (n_nom > (unsigned)CAP) {  // more nominations than the list holds: overflow-safe path
-      if (tid == 0) *a.overflow = 1u;
+      if (tid == 0) atomicOr(a.overflow, n_nom > (unsigned)kMaxSortKeys ? 6u : 2u);
       n_nom = CAP;
     }
     if (tid == 0) a.stat_nominated[q] += n_nom;
@@ -1785,7 +1788,7 @@ void topk_merge(MergeArgs a) {
     if (s_n_keys > (unsigned)CAP / 2) {   // workgroup-uniform: more passing rows than the lower half holds -- overflow-safe path
       __syncthreads();
       if (tid == 0) {
-        *a.overflow = 1u;
+        atomicOr(a.overflow, s_n_keys > (unsigned)kMaxSortKeys / 2 ? 6u : 2u);
         s_n_keys = CAP / 2;
       }
       __syncthreads();
@@ -1797,7 +1800,7 @@ void topk_merge(MergeArgs a) {
   if (n_seen == 0) return;  // nothing passed the threshold this round: list and threshold stand
   unsigned n_cand = n_seen;
   if (n_cand + nrun > (unsigned)CAP) {  // more survivors than one LDS pass holds
-    if (tid == 0) *a.overflow = 1u;
+    if (tid == 0) atomicOr(a.overflow, NOM ? 2u : 1u);
     n_cand = CAP - nrun;
   }
   if constexpr (CAP > kMaxSortKeys) {
