@@ -291,7 +291,11 @@ __global__ __launch_bounds__(NW * 64) void mips_filter_f16(FilterArgs a) {
 #pragma unroll
     for (int blk = 0; blk < QW; ++blk) {
       unsigned long long* list = (unsigned long long*)lane_list[blk];
-      if (!kCheckRows && !(a.flags & 128u)) {   // (flag 128, A/B: the per-register test everywhere)
+#ifdef PROQA_COMPACT_FLAG128   // developer A/B build: the run-time switch to the per-register test (round 5)
+      if (!kCheckRows && !(a.flags & 128u)) {
+#else
+      if (!kCheckRows) {
+#endif
         // Every unit but the chunk's last stage: ONE wave-wide branch per query block (the column maximum), then straight-line
         // code -- the 16-bit set of the lane's scores above its threshold (32 VALU operations, no branch); a lane with ONE such
         // score (almost every hit) appends (its maximum, the row of the set bit); lanes with several take the per-register
