@@ -474,6 +474,9 @@ int proqa_microbench_mfma_i8_shape(double ms_target, int zero_operands, int shap
  * v_mfma_i32_32x32x32_i8 + n_valu x v_xad_u32 per wave and trip, four waves per SIMD (the shape of mips_filter_i8's unit);
  * n_valu in {0, 8, 16, 24, 32, 48, 64} */
 int proqa_microbench_mfma_i8_valu(double ms_target, int n_valu, void* stream, double* tops);
+/* microseconds of ONE cooperative launch of `grid` 256-thread workgroups that meet at n_syncs grid-wide barriers
+ * (hipLaunchCooperativeKernel + cooperative_groups::grid_group::sync): what fusing dependent small kernels would pay */
+int proqa_microbench_grid_sync(int grid, int n_syncs, void* stream, double* us);
 
 #ifdef __cplusplus
 }

@@ -155,6 +155,7 @@ SIGNATURES = {
     "proqa_microbench_mfma_i8": (c_int, [ctypes.c_double, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "proqa_microbench_mfma_i8_shape": (c_int, [ctypes.c_double, c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
     "proqa_microbench_mfma_i8_valu": (c_int, [ctypes.c_double, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
+    "proqa_microbench_grid_sync": (c_int, [c_int, c_int, c_void_p, ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lock = threading.Lock()

@@ -2,6 +2,7 @@
 // register-resident MFMA loop.  They are what SURVEY.md section 8(d) asks to be recorded next to the spec peaks
 // (HBM3E 8 TB/s, 2.5 PFLOP/s dense fp16 MFMA) that the roofline fractions are priced against.
 #include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -152,6 +153,20 @@ __global__ __launch_bounds__(512, 2) void mfma_i8_valu_loop(int iters, int* __re
   if (m0 + m1 == 0x12345678) *sink = m0;
 }
 
+// What a grid-wide barrier costs: a cooperative launch of `grid` 256-thread workgroups that meet at n_syncs barriers
+// (cooperative_groups::grid_group::sync, i.e. device-scope release / acquire across the XCDs), touching one cache line each in
+// between -- the price list of a fused small-batch encoder (ABLATIONS R6.12).
+__global__ __launch_bounds__(256) void grid_sync_loop(int n_syncs, unsigned* __restrict__ buf) {
+  cooperative_groups::grid_group g = cooperative_groups::this_grid();
+  unsigned v = 0;
+  for (int i = 0; i < n_syncs; ++i) {
+    if (threadIdx.x == 0) buf[blockIdx.x * 16] = v + (unsigned)i;
+    g.sync();
+    if (threadIdx.x == 0) v += buf[((blockIdx.x + 1) % gridDim.x) * 16];
+  }
+  if (threadIdx.x == 0) buf[blockIdx.x * 16 + 1] = v;
+}
+
 }  // namespace
 }  // namespace proqa
 
@@ -261,6 +276,38 @@ int proqa_microbench_mfma_i8_shape(double ms_target, int zero_operands, int shap
 
 int proqa_microbench_mfma_i8(double ms_target, int zero_operands, void* stream, double* tops) {
   return proqa_microbench_mfma_i8_shape(ms_target, zero_operands, 0, stream, tops);
+}
+
+// microseconds of one cooperative launch of `grid` workgroups with n_syncs grid-wide barriers (best of 5 after a warm-up)
+int proqa_microbench_grid_sync(int grid, int n_syncs, void* stream, double* us) {
+  if (!us || grid <= 0 || grid > 4096 || n_syncs < 0) return fail(PROQA_EINVAL, "microbench_grid_sync: bad argument");
+  hipStream_t st = as_stream(stream);
+  hipEvent_t e0, e1;
+  PROQA_HIP(hipEventCreate(&e0));
+  PROQA_HIP(hipEventCreate(&e1));
+  unsigned* buf = nullptr;
+  PROQA_HIP(hipMalloc((void**)&buf, (size_t)grid * 64));
+  PROQA_HIP(hipMemsetAsync(buf, 0, (size_t)grid * 64, st));
+  float best = 1e30f;
+  void* args[] = {&n_syncs, &buf};
+  for (int r = 0; r < 6; ++r) {
+    PROQA_HIP(hipEventRecord(e0, st));
+    hipError_t e = hipLaunchCooperativeKernel((const void*)grid_sync_loop, dim3((unsigned)grid), dim3(256), args, 0, st);
+    if (e != hipSuccess) {
+      (void)hipFree(buf);
+      return hip_fail(e, "hipLaunchCooperativeKernel", __FILE__, __LINE__);
+    }
+    PROQA_HIP(hipEventRecord(e1, st));
+    PROQA_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    PROQA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  (void)hipFree(buf);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *us = best * 1e3;
+  return PROQA_OK;
 }
 
 // int8 MFMA rate (TOP/s, random operands) of a loop of 8 MFMAs + n_valu plain VALU instructions per wave, four waves per
