@@ -56,7 +56,7 @@ while time.time() < t_end:
     tq = torch.from_numpy(xq).to(dev)
     always_nominate = bool(rng.random() < 0.5)
     bounds = np.linspace(0, n, shards + 1).astype(int)
-    parts = []
+    handles = []
     for lo, hi in zip(bounds[:-1], bounds[1:]):
         ix = IndexFlatIP(128)
         if always_nominate:
@@ -66,17 +66,31 @@ while time.time() < t_end:
                 ix.add(xb[lo:hi])
             else:
                 ix.add(torch.from_numpy(xb[lo:hi]).to(dev))
-        parts.append(ix.search_device(tq, k, idx_offset=int(lo)))
-    if shards == 1:
-        D, I = parts[0]
-    else:
-        D, I = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
-    D, I = D.cpu().numpy(), I.cpu().numpy()
-    ok = (I == Io).all() and (D == Do).all()
-    n_cases += 1
-    if not ok:
-        bad = np.argwhere(I != Io)
-        print(f"MISMATCH n={n} nq={nq} k={k} kind={kind} shards={shards} seed={seed} case={n_cases}: first at {bad[:3].tolist()}")
-        print(I[bad[0][0]][:12], Io[bad[0][0]][:12], D[bad[0][0]][:6], Do[bad[0][0]][:6])
-        sys.exit(1)
+        handles.append((ix, int(lo)))
+
+    def search_all(tq_, xq_, Do_, Io_, what):
+        global n_cases
+        parts = [ix.search_device(tq_, k, idx_offset=lo) for ix, lo in handles]
+        if shards == 1:
+            D, I = parts[0]
+        else:
+            D, I = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+        D, I = D.cpu().numpy(), I.cpu().numpy()
+        n_cases += 1
+        if not ((I == Io_).all() and (D == Do_).all()):
+            bad = np.argwhere(I != Io_)
+            print(f"MISMATCH ({what}) n={n} nq={xq_.shape[0]} k={k} kind={kind} shards={shards} seed={seed} case={n_cases}: first at {bad[:3].tolist()}")
+            print(I[bad[0][0]][:12], Io_[bad[0][0]][:12], D[bad[0][0]][:6], Do_[bad[0][0]][:6])
+            sys.exit(1)
+
+    search_all(tq, xq, Do, Io, "first search")
+    # the same handles again: another batch size (another launch shape, merge and schedule), the state the first search left
+    # behind (an int8 copy that exists, a suspended scan, a merge size the index was moved to)
+    for _ in range(int(rng.choice([0, 0, 1, 2]))):
+        nq2 = int(rng.choice([1, 20, 32, 100, 256, 300]))
+        if exact and n * nq2 > 3e7:
+            break
+        xq2 = xq[rng.integers(0, xq.shape[0], nq2)] if rng.random() < 0.5 else np.ascontiguousarray(xb[rng.integers(0, n, nq2)]).astype(xq.dtype)
+        Do2, Io2 = oracle(xq2, xb, k)
+        search_all(torch.from_numpy(xq2).to(dev), xq2, Do2, Io2, "repeated search")
 print(f"fuzz ok: {n_cases} cases in {budget:.0f} s (seed {seed})")
