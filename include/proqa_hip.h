@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PROQA_ABI_VERSION 6
+#define PROQA_ABI_VERSION 7
 
 /* element types of embedding matrices (the .npy index is '<f2' under --fp16, else '<f4':
  * retrieval/get_embed.py:139) */
@@ -162,6 +162,10 @@ typedef struct proqa_search_stats {
   int32_t nomination_state;  /* of the index after this search: 0 off (mode 0 / exact-float32), 1 on (the copy is, or will
                                 be, scanned by the searches it applies to), 2 suspended (the rows do not quantise, or a
                                 search over-nominated: fp16 scan until a re-probe succeeds or the rows change) */
+  int32_t leap_rank;         /* > 0: the rounds of this search tested against the score at that rank (< k) of the running lists
+                                (leaping rounds, proqa_index_configure_leap); 0: against the k-th best, as ever */
+  int32_t leap_state;        /* of the index after this search: 0 off (mode 0 / exact-float32), 1 on, 2 paused (a leaping
+                                round fell short: ordinary rounds for the next 16, 32, ... 1024 eligible searches) */
 } proqa_search_stats;
 int proqa_index_last_stats(const proqa_index* idx, proqa_search_stats* out);
 /* bracket every mips_filter launch with HIP events on the search stream (bench.py roofline) */
@@ -184,6 +188,20 @@ int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
  * 2: always.  The copy (+128 B per row) is built by proqa_index_prepare, or by the first search that wants it.  Rows
  * adopted with proqa_index_adopt_device: see the immutability note there. */
 int proqa_index_configure_nomination(proqa_index* idx, int mode);
+/* Leaping rounds of the k <= 128 searches (fp16 indexes, default schedule, behind the bootstrap).  A round that tests against
+ * the k-th best score of the n0 rows seen so far logs ~k (rho - 1) candidates per query while the rows seen grow by rho --
+ * which is what keeps rho near 3 and an 18M-row search at eight rounds.  A LEAPING round tests against the score at rank
+ * j < k of the running list: it logs ~j (rho - 1) rows, so rho can be 5-16 and the rounds three or four.  Its result is exact
+ * iff at least k rows of everything seen so far beat that threshold (every one of them is then known); the round's merge
+ * checks exactly that, and a round that falls short is re-scanned against the k-th best scores on the overflow-safe path
+ * (proqa_search_stats.fallback_rounds) -- the result never depends on the leap.  j is the smallest rank for which the
+ * shortfall has probability <= 1e-8 per query and round when the first rows stand for the rest (rows in no particular
+ * order: the count of new rows above the rank-j score is negative-binomial (j, 1 / rho)).  Rows sorted by topic or norm make
+ * leaps fall short: such a search pauses them for the next 16 eligible searches of the index, a failed retry doubles the
+ * pause (up to 1024), a clean one clears it, changed rows start afresh; one stderr line per switch under PROQA_LOG.
+ * mode 0: never; 1 (default): automatic, as above.  An index configured with proqa_index_configure(growth) keeps its
+ * ordinary rounds. */
+int proqa_index_configure_leap(proqa_index* idx, int mode);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
  * (the layout an RCCL all-gather of per-rank [nq, k] produces); every list as a search reports it (scores descending,

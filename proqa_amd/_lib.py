@@ -34,7 +34,8 @@ class ProqaError(RuntimeError):
 class SearchStats(ctypes.Structure):
     _fields_ = [("rounds", ctypes.c_int32), ("fallback_rounds", ctypes.c_int32),
                 ("candidates", ctypes.c_int64), ("filter_ms", c_float), ("total_ms", c_float),
-                ("nominated", ctypes.c_int64), ("nomination", ctypes.c_int32), ("nomination_state", ctypes.c_int32)]
+                ("nominated", ctypes.c_int64), ("nomination", ctypes.c_int32), ("nomination_state", ctypes.c_int32),
+                ("leap_rank", ctypes.c_int32), ("leap_state", ctypes.c_int32)]
 
 
 class BertLayer(ctypes.Structure):
@@ -91,6 +92,7 @@ SIGNATURES = {
     "proqa_index_set_profiling": (c_int, [c_void_p, c_int]),
     "proqa_index_configure": (c_int, [c_void_p, c_int, c_int]),
     "proqa_index_configure_nomination": (c_int, [c_void_p, c_int]),
+    "proqa_index_configure_leap": (c_int, [c_void_p, c_int]),
     "proqa_index_configure_bootstrap": (c_int, [c_void_p, c_int]),
     "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p]),
@@ -216,7 +218,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI drifted
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.proqa_abi_version() != 6:
+        if lib.proqa_abi_version() != 7:
             raise RuntimeError("libproqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
         return lib

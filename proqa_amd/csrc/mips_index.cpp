@@ -123,6 +123,20 @@ struct proqa_index {
   bool small_merge_ok = true;
   bool used_small_merge = false;           // a round of the search being enqueued took the 1024-key merge
   unsigned overflow_bits = 0;              // OR of the overflow words of the search's rounds (bit 1 alone: only a merge's capacity)
+  // Leaping rounds (plan_leap below): thresholds taken at rank j < k of the running list, a quarter of the candidates per row
+  // scanned, so half the rounds or fewer; a round in which fewer than k rows reach its threshold is re-scanned by the
+  // overflow-safe path (rows in an order the first rows do not stand for).  Such a search pauses the leaps of this index for
+  // leap_pause searches (16, then doubling up to 1024; a search that leaps cleanly clears it)
+  int leap_mode = 1;                       // 0 never, 1 automatic (developer switch PROQA_LEAP)
+  int leap_pause = 0;                      // length of the current pause
+  int leap_skip = 0;                       // searches of that pause still to go
+  bool leap_active = false;                // the search being enqueued leaps
+  long long leap_key[6] = {0, 0, 0, 0, 0, 0};   // what the kept plan was made for
+  int leap_plan_rounds = 0, leap_plan_rank = 0;
+  double leap_plan_per_round = 0.0;
+  int leap_logged = 0;                     // the plan last reported under PROQA_LOG
+  uint64_t leap_epoch = 0;                 // rows_epoch the pause belongs to (changed rows start afresh)
+  int round_next_rank = 0, round_leap_check = 0;   // MergeArgs of the round being enqueued
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
   proqa::NominateParams* qparams = nullptr;   // workspace [ws_nq_pad]
   unsigned long long* stat_nom = nullptr;  // workspace [ws_nq_pad] rows re-scored per query
@@ -554,6 +568,81 @@ std::vector<Slab> plan_slabs(long long n, int first, double growth, long long st
   return out;
 }
 
+// ---- leaping rounds ------------------------------------------------------------------------------------------------
+// A round that tests against the k-th best score of the n0 rows seen so far logs ~k (rho - 1) rows of the next (rho - 1) n0,
+// which is what caps the growth of the ordinary schedule (a merge holds so many keys; every candidate is a gather).  The
+// rows that end up in the best k are far fewer: a round may test against the score at rank j < k instead -- it then logs
+// ~j (rho - 1) rows -- provided at least k rows of the rho n0 now seen reach that score, for then every row of the best k is
+// among them (the running list holds every earlier row that reaches it: j <= k).  The merge verifies exactly that (its
+// k-th key reaches the threshold it was given, topk_merge); a round that fails is flagged like an overflowed one and re-scanned
+// against the k-th best scores (page_complete).  For rows in an order the first n0 stand for (exchangeable: any corpus that
+// is not sorted by topic or norm), the count of new rows above the rank-j score is negative-binomial (j, 1 / rho): mean
+// j (rho - 1), and P(fewer than k - j) is a closed sum -- leap_rank takes the smallest j that keeps it below kLeapEps per query
+// and round (1e-8: one re-scan in ~10^4 searches of 2032 queries).  The result never depends on any of this.
+// (developer switches, read at every search so that one process can alternate them: PROQA_LEAP=0 never; PROQA_LEAP_ROUNDS /
+// PROQA_LEAP_RANK / PROQA_LEAP_EPS fix the rounds behind the bootstrap, the rank, the probability)
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+constexpr int kLeapMaxK = 128;
+constexpr double kLeapEps = 1e-8;
+
+// P(fewer than k rows beat the rank-j score after the rows seen grew by the factor rho): the negative-binomial sum
+double leap_fail_probability(int k, int j, double rho) {
+  const double p = 1.0 / rho;
+  double pmf = std::pow(p, j), sum = 0.0;   // P(X = 0)
+  for (int x = 0; x < k - j; ++x) {
+    sum += pmf;
+    pmf *= (double)(x + j) / (double)(x + 1) * (1.0 - p);
+  }
+  return sum;
+}
+int leap_rank(int k, double rho, double eps) {
+  for (int j = 1; j < k; ++j)
+    if (leap_fail_probability(k, j, rho) <= eps) return j;
+  return k;
+}
+struct LeapPlan {
+  int rounds = 0;   // 0: no leap
+  int rank = 0;
+  double per_round = 0.0;   // rows expected to beat the threshold per round and query: rank (rho - 1)
+};
+// The schedule: `rounds` rounds of equal growth behind the bootstrap, the one that minimises rounds x (c + rows per round),
+// c = what a round costs beside the rows it logs, in rows per query: ~50 for a batch that fills the chip, ~120 for the
+// batches of <= 256 queries, whose rounds are launch latencies (interleaved sweeps, scripts/dev_leap_sweep.py, ABLATIONS R6.13:
+// 2032 queries: 4-5 rounds at 18M rows, 3 at 2.25M; <= 256 queries: 3 and 2).  The rows per round are capped by what the
+// round's merge holds: their count varies by a relative 1 / sqrt(rank) around rank (rho - 1) (5 sigma are allowed for), and the
+// int8 scan nominates ~2-2.5 x the rows that pass (2048-key merge: 2048 nominated rows).
+LeapPlan plan_leap(long long n, long long boot, int k, int qw, bool nominating) {
+  LeapPlan best;
+  if (boot <= 0 || n <= boot || k > kLeapMaxK || k < 8) return best;
+  const int fixed_rounds = env_int("PROQA_LEAP_ROUNDS", 0), fixed_rank = env_int("PROQA_LEAP_RANK", 0);
+  const double eps = getenv("PROQA_LEAP_EPS") ? atof(getenv("PROQA_LEAP_EPS")) : kLeapEps;
+  const double ratio = (double)n / (double)boot;
+  const double round_cost = getenv("PROQA_LEAP_ROUND_COST") ? atof(getenv("PROQA_LEAP_ROUND_COST")) : (qw == 1 ? 120.0 : 50.0);
+  double best_cost = 0.0;
+  for (int r = 1; r <= 16; ++r) {
+    if (fixed_rounds > 0 && r != fixed_rounds) continue;
+    const double rho = std::pow(ratio, 1.0 / r);
+    if (rho < 1.5) break;
+    const int j = fixed_rank > 0 ? std::min(fixed_rank, k) : leap_rank(k, rho, eps);
+    if (j >= k) continue;
+    const double m = j * (rho - 1.0);
+    const double spread = 1.0 + 5.0 / std::sqrt((double)j);
+    const bool fits = nominating ? m * spread * 2.5 <= (double)kMaxSortKeys : m * spread <= (double)(kMaxSortKeys - k) && m <= kBudget;
+    if (!fits && fixed_rounds <= 0) continue;
+    const double cost = r * (round_cost + m);
+    if (!best.rounds || cost < best_cost) {
+      best.rounds = r;
+      best.rank = j;
+      best.per_round = m;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
 struct LaunchGeom {
   int rows_per_chunk;
   unsigned chunks;   // chunks that scan rows
@@ -684,6 +773,8 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     // 1024-key merge (eight workgroups per CU) where that leaves a factor ~4 of headroom, else the 2048-key one
     ma.nom_keys = idx->small_merge_ok && (double)k * idx->page_growth <= kSmallMergeLimit ? 1024 : 2048;
     if (ma.nom_keys == 1024) idx->used_small_merge = true;
+    ma.next_rank = idx->round_next_rank;
+    ma.leap_check = idx->round_leap_check;
 #ifdef PROQA_MERGE_STAMPS
     if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -756,6 +847,8 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.xb16 = nullptr;
   ma.stat_nominated = nullptr;
   ma.nom_keys = 0;
+  ma.next_rank = inclusive ? 0 : idx->round_next_rank;
+  ma.leap_check = inclusive ? 0 : idx->round_leap_check;
 #ifdef PROQA_MERGE_STAMPS
   if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -766,7 +859,7 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
 // Exact top-k of rows [0, rows) for every query in two launches (see bootstrap_scores / bootstrap_select): the state the
 // rounds would have after those rows.  Its overflow word is the last-but-one (the last belongs to the overflow-safe
 // re-scans).
-int run_bootstrap(proqa_index* idx, long long rows, unsigned nq_pad, int k, hipStream_t st, int run_stride = 0) {
+int run_bootstrap(proqa_index* idx, long long rows, unsigned nq_pad, int k, hipStream_t st, int run_stride = 0, int tau_rank = 0) {
   const size_t need = (size_t)idx->ws_nq_pad * round_up<long long>(rows, 32);
   if (need > idx->boot_floats) {
     PROQA_HIP(hipStreamSynchronize(st));
@@ -777,7 +870,7 @@ int run_bootstrap(proqa_index* idx, long long rows, unsigned nq_pad, int k, hipS
     idx->boot_floats = need;
   }
   PROQA_HIP(launch_bootstrap(idx->xb, idx->xq_pad, (int)rows, nq_pad, k, idx->boot_scores, idx->run_keys, idx->run_n, idx->tau,
-                             idx->stat_dev, idx->overflow + kMaxRounds - 2, st, run_stride));
+                             idx->stat_dev, idx->overflow + kMaxRounds - 2, st, run_stride, tau_rank));
   return PROQA_OK;
 }
 
@@ -797,6 +890,7 @@ struct PageOut {
 struct PagePlan {
   std::vector<Slab> slabs;
   long long boot = 0;
+  int leap_rank = 0;   // > 0: the rounds test against that rank of the running list (plan_leap)
 };
 
 int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int page_k, bool bounded,
@@ -827,23 +921,69 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
   // (big pages: as many rows as the merge holds -- their growth per round is small, so the rounds should start high)
   const int first_cap = (sort_capacity(page_k) - page_k) / kStageRows * kStageRows;
   const int first = page_k > kPageK ? first_cap : std::min<int>(idx->first_slab_rows, first_cap);
-  const double page_growth = growth_for(page_k, idx->growth, gqw, idx->q8_active);
+  double page_growth = growth_for(page_k, idx->growth, gqw, idx->q8_active);
+  // leaping rounds (plan_leap): behind a bootstrap, on the default schedule, unless this index is pausing them
+  LeapPlan leap;
+  if (boot && !bounded && !idx->exact && idx->leap_mode && env_int("PROQA_LEAP", 1) != 0 && idx->growth == 0 && kEqualGrowth && kGrowthList.empty() &&
+      page_k <= kLeapMaxK) {
+    if (idx->leap_epoch != idx->rows_epoch) {
+      idx->leap_epoch = idx->rows_epoch;
+      idx->leap_pause = idx->leap_skip = 0;
+    }
+    if (idx->leap_skip > 0)
+      --idx->leap_skip;
+    else {
+      // (the plan of the last search is kept: the same index, batch class and k ask again and again)
+      const long long key[6] = {idx->n, boot, page_k, qw, idx->q8_active ? 1 : 0,
+                                env_int("PROQA_LEAP_ROUNDS", 0) * 1000 + env_int("PROQA_LEAP_RANK", 0)};
+      if (std::memcmp(key, idx->leap_key, sizeof key) != 0 || getenv("PROQA_LEAP_EPS") || getenv("PROQA_LEAP_ROUND_COST")) {
+        std::memcpy(idx->leap_key, key, sizeof key);
+        const LeapPlan lp = plan_leap(idx->n, boot, page_k, qw, idx->q8_active);
+        idx->leap_plan_rounds = lp.rounds;
+        idx->leap_plan_rank = lp.rank;
+        idx->leap_plan_per_round = lp.per_round;
+      }
+      leap.rounds = idx->leap_plan_rounds;
+      leap.rank = idx->leap_plan_rank;
+      leap.per_round = idx->leap_plan_per_round;
+    }
+  }
+  if (leap.rounds) {
+    // (equal growth over exactly leap.rounds rounds; the nominating merge is sized by the rows expected per round)
+    const double rho = std::pow((double)idx->n / (double)boot, 1.0 / leap.rounds);
+    plan->slabs = plan_slabs_equal(idx->n, boot, rho - 1.0 + 1e-6);
+    page_growth = leap.per_round / page_k;
+    plan->leap_rank = leap.rank;
+    idx->leap_active = true;
+    idx->stats.leap_rank = leap.rank;
+    if (log_enabled() && idx->leap_logged != leap.rounds * 1000 + leap.rank) {
+      idx->leap_logged = leap.rounds * 1000 + leap.rank;
+      log_line("index %p: %d leaping rounds behind a bootstrap of %lld rows, thresholds at rank %d of %d (~%.0f rows per round and query "
+               "reach them)", (void*)idx, leap.rounds, boot, leap.rank, page_k, leap.per_round);
+    }
+  } else {
+    plan->slabs = boot && kEqualGrowth && kGrowthList.empty() ? plan_slabs_equal(idx->n, boot, page_growth)
+                                                            : plan_slabs(idx->n, first, page_growth, boot);
+  }
   idx->page_growth = page_growth;
-  plan->slabs = boot && kEqualGrowth && kGrowthList.empty() ? plan_slabs_equal(idx->n, boot, page_growth)
-                                                          : plan_slabs(idx->n, first, page_growth, boot);
   plan->boot = boot;
   const std::vector<Slab>& slabs = plan->slabs;
   if ((int)slabs.size() + 2 > kMaxRounds) return fail(PROQA_EINVAL, "search: too many rounds (%zu)", slabs.size());
   if (boot)
-    if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, page_k, st)) return rc;
+    if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, page_k, st, 0, plan->leap_rank)) return rc;
   const bool prof = idx->profile && !bounded;  // the per-round brackets describe the first page
   for (size_t r = 0; r < slabs.size(); ++r) {
     hipEvent_t f0 = prof ? idx->ev_filter[2 * r] : nullptr;
     hipEvent_t f1 = prof ? idx->ev_filter[2 * r + 1] : nullptr;
     // while fewer than page_k rows have been merged the threshold is still -inf: every row is logged
     const bool dense = slabs[r].r0 < page_k;
-    if (int rc = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, page_k, false, dense, bounded,
-                           idx->overflow + r, st, f0, f1))
+    // (a leaping round's merge verifies its threshold and leaves the next round's: the same rank, the k-th best after the last)
+    idx->round_leap_check = plan->leap_rank ? 1 : 0;
+    idx->round_next_rank = plan->leap_rank && r + 1 < slabs.size() ? plan->leap_rank : 0;
+    const int rc_round = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, page_k, false, dense, bounded,
+                                   idx->overflow + r, st, f0, f1);
+    idx->round_leap_check = idx->round_next_rank = 0;
+    if (int rc = rc_round)
       return rc;
     if (kDebugCand) {
       (void)hipStreamSynchronize(st);
@@ -1195,8 +1335,9 @@ void note_nomination(proqa_index* idx, int64_t nq) {
   idx->stats.nominated = (int64_t)idx->mirror->nominated;
   const double per_query = (double)idx->stats.nominated / (double)std::max<int64_t>(nq, 1);
   const double limit = std::max(4096.0, (double)idx->n / 2048.0);
-  const bool bad = per_query > limit || idx->stats.fallback_rounds > 0;
-  if (bad && per_query <= limit && idx->used_small_merge && idx->small_merge_ok && idx->overflow_bits == 2u) {
+  // (overflow bit 3 alone: a leaping round fell short -- note_leap's business, not a property of the int8 copy)
+  const bool bad = per_query > limit || (idx->stats.fallback_rounds > 0 && (idx->overflow_bits & ~8u) != 0);
+  if (bad && per_query <= limit && idx->used_small_merge && idx->small_merge_ok && (idx->overflow_bits & ~8u) == 2u) {
     // what overflowed was the capacity of the 1024-key merge alone (no lane list of the scan: bit 0), and the nominations
     // are within the limit: these rows nominate more per round than that merge is sized for -- the 2048-key merge from now
     // on, no suspension (if that overflows too, the next search suspends the rounds)
@@ -1223,6 +1364,27 @@ void note_nomination(proqa_index* idx, int64_t nq) {
     idx->q8_probe_after = 0;
   }
   idx->stats.nomination_state = nomination_state_of(idx);
+}
+
+// after the host sync of a search that leapt: a round that fell short pauses the leaps of this index
+int leap_state_of(const proqa_index* idx) {   // proqa_search_stats::leap_state
+  if (!idx->leap_mode || idx->exact) return 0;
+  return idx->leap_skip > 0 && idx->leap_epoch == idx->rows_epoch ? 2 : 1;
+}
+void note_leap(proqa_index* idx) {
+  idx->stats.leap_state = leap_state_of(idx);
+  if (!idx->leap_active) return;
+  idx->leap_active = false;
+  if (idx->overflow_bits) {   // bit 3: a round fell short; any other: scores that tie in numbers (the rows a leap logs tie with more) -- pause too
+    idx->leap_pause = idx->leap_pause ? std::min(2 * idx->leap_pause, 1024) : 16;
+    idx->leap_skip = idx->leap_pause;
+    log_line("index %p: a leaping round found fewer than k rows above its threshold or overflowed (%d overflow-safe rounds, overflow "
+             "bits %u): ordinary rounds for the next %d searches", (void*)idx, idx->stats.fallback_rounds, idx->overflow_bits, idx->leap_skip);
+  } else if (idx->leap_pause) {
+    log_line("index %p: leaping rounds resumed", (void*)idx);
+    idx->leap_pause = 0;
+  }
+  idx->stats.leap_state = leap_state_of(idx);
 }
 
 int finish_pending(proqa_index* idx, int* rewritten);
@@ -1261,10 +1423,12 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   if (idx->n >= (1ll << 32)) return fail(PROQA_EINVAL, "search: shard has >= 2^32 rows");
   idx->stats = {};
   idx->stats.nomination_state = nomination_state_of(idx);
+  idx->stats.leap_state = leap_state_of(idx);
   idx->q8_active = false;
   idx->pending_nq = nq;
   idx->used_small_merge = false;
   idx->overflow_bits = 0;
+  idx->leap_active = false;
   if (nq == 0) return PROQA_OK;
   PROQA_ON_DEVICE(idx->device);
 
@@ -1437,6 +1601,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
   idx->stats.candidates += (int64_t)idx->mirror->candidates;
   (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
   note_nomination(idx, nq);
+  note_leap(idx);
   return PROQA_OK;
 }
 
@@ -1467,6 +1632,7 @@ int finish_pending(proqa_index* idx, int* rewritten) {
   idx->stats.candidates += (int64_t)idx->mirror->candidates;
   (void)hipEventElapsedTime(&idx->stats.total_ms, idx->ev[0], idx->ev[1]);
   note_nomination(idx, pe.nq);
+  note_leap(idx);
   if (rewritten) *rewritten = fallback != 0;
   // the enqueued search found no current int8 copy of the rows and ran on the fp16 rows: build the copy now, behind the
   // host wait this call is anyway, so that the next search scans it
@@ -1591,6 +1757,14 @@ int proqa_index_configure_nomination(proqa_index* idx, int mode) {
   if (!idx) return fail(PROQA_EINVAL, "index_configure_nomination: NULL handle");
   if (mode < 0 || mode > 2) return fail(PROQA_EINVAL, "index_configure_nomination: mode=%d (0 off, 1 automatic, 2 always)", mode);
   idx->nominate_mode = mode;
+  return PROQA_OK;
+}
+
+int proqa_index_configure_leap(proqa_index* idx, int mode) {
+  if (!idx) return fail(PROQA_EINVAL, "index_configure_leap: NULL handle");
+  if (mode < 0 || mode > 1) return fail(PROQA_EINVAL, "index_configure_leap: mode=%d (0 off, 1 automatic)", mode);
+  idx->leap_mode = mode;
+  idx->leap_pause = idx->leap_skip = 0;
   return PROQA_OK;
 }
 

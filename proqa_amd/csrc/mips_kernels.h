@@ -115,6 +115,10 @@ struct MergeArgs {
   const void* xq16;              // fp16 [nq_pad,128] padded queries
   const char* xb16;              // fp16 corpus rows of this shard
   unsigned long long* stat_nominated;  // [nq_pad] rows re-scored per query (statistics)
+  // leaping rounds (see topk_merge): rank (1-based, < k) of the running list whose score becomes the next round's threshold, 0 =
+  // the k-th best; leap_check: this round's scan tested against such a rank -- verify that k keys reach it (else overflow bit 3)
+  int next_rank;
+  int leap_check;
 };
 
 // ---- int8 nomination scan (the k <= kPageK rounds of an fp16 index; see "int8 nomination" in mips_kernels.hip) ----------
@@ -186,7 +190,7 @@ hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned
 // run_stride (0 = k): keys per query in run_keys when the list that follows is longer than this k (search_one_pass)
 hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,
                             unsigned long long* run_keys, unsigned* run_n, float* tau, unsigned long long* stat,
-                            unsigned* overflow, hipStream_t st, int run_stride = 0);
+                            unsigned* overflow, hipStream_t st, int run_stride = 0, int tau_rank = 0);
 // overflow (optional): the kOverflowWords round words of the page that follows are zeroed
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,

@@ -1472,6 +1472,23 @@ void topk_merge(MergeArgs a) {
   // than T chunks).  The records themselves are the second, and last, dependent round trip.
   const unsigned nrun = a.run_n[q];
   unsigned long long run_pref = (unsigned)tid < (unsigned)a.k ? a.run_keys[(size_t)q * a.k + tid] : 0ull;
+  // Leaping rounds (mips_index.cpp plan_leap; forward rounds of a one-page search with k <= T): the scan that fed this merge
+  // tested against the score at rank j < k of the running list instead of rank k -- a.tau[q] on entry.  The merged list is the
+  // exact best k of the rows seen so far iff k of its keys BEAT that threshold (every row that does is in it; rows that tie
+  // with it were not logged, as ever); otherwise the round is flagged (bit 3 of its overflow word) and re-scanned by the
+  // overflow-safe path.  (Padding / exhausted queries -- threshold +inf, empty list -- have nothing to verify.)  What this merge leaves
+  // in a.tau[q] is the threshold of the NEXT round: rank a.next_rank, or the k-th best (0: the last round, every other search)
+  const float tau_in = a.leap_check ? a.tau[q] : 0.f;
+  auto note_rank = [&](unsigned i, unsigned long long key, unsigned keep) {   // key = the merged list's key of rank i
+    if (keep != (unsigned)a.k) return;
+    const unsigned rank = a.next_rank ? (unsigned)a.next_rank : (unsigned)a.k;
+    if (i + 1 == rank) {
+      const float t = float_from_ord((unsigned)(key >> 32));
+      a.tau[q] = t;
+      if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
+    }
+    if (a.leap_check && i + 1 == (unsigned)a.k && !(float_from_ord((unsigned)(key >> 32)) > tau_in)) atomicOr(a.overflow, 8u);
+  };
   unsigned cnt_first[2], n_spill_first;
   {
     const unsigned n_here = n_lists < 2u * T ? n_lists : 2u * T;
@@ -1801,7 +1818,13 @@ void topk_merge(MergeArgs a) {
   }
 
   const unsigned n_seen = s_n_keys;
-  if (n_seen == 0) return;  // nothing passed the threshold this round: list and threshold stand
+  if (n_seen == 0) {  // nothing passed the threshold this round: the list stands -- and the threshold, unless the rank changes
+    if (a.next_rank || a.leap_check) {   // (k <= T: run_pref is the whole list)
+      if ((unsigned)tid < nrun) note_rank((unsigned)tid, run_pref, nrun);
+      if (tid == 0 && a.leap_check && nrun < (unsigned)a.k && tau_in != __builtin_inff()) atomicOr(a.overflow, 8u);
+    }
+    return;
+  }
   unsigned n_cand = n_seen;
   if (n_cand + nrun > (unsigned)CAP) {  // more survivors than one LDS pass holds
     if (tid == 0) atomicOr(a.overflow, NOM ? 2u : 1u);
@@ -1867,16 +1890,15 @@ void topk_merge(MergeArgs a) {
 #pragma unroll
       for (int j = 0; j < NK; ++j) {
         const unsigned i = (unsigned)tid * NK + j;
-        if (i < keep) a.run_keys[(size_t)q * a.k + i] = v[j];
-        if (i + 1 == (unsigned)a.k && keep == (unsigned)a.k) {
-          const float t = float_from_ord((unsigned)(v[j] >> 32));
-          a.tau[q] = t;
-          if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
+        if (i < keep) {
+          a.run_keys[(size_t)q * a.k + i] = v[j];
+          note_rank(i, v[j], keep);
         }
       }
       if (tid == 0) {
         a.run_n[q] = keep;
         a.stat_candidates[q] += n_seen;
+        if (a.leap_check && keep < (unsigned)a.k && tau_in != __builtin_inff()) atomicOr(a.overflow, 8u);
       }
     } else {
 #pragma unroll
@@ -2002,7 +2024,7 @@ __global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* _
                                                                   int k, int run_stride, unsigned long long* __restrict__ run_keys,
                                                                   unsigned* __restrict__ run_n, float* __restrict__ tau,
                                                                   unsigned long long* __restrict__ stat_candidates,
-                                                                  unsigned* __restrict__ overflow) {
+                                                                  unsigned* __restrict__ overflow, int tau_rank) {
   __shared__ __attribute__((aligned(16))) unsigned long long keys[kMaxSortKeys];
   __shared__ unsigned long long s_bound;
   __shared__ unsigned s_n_keys;
@@ -2072,7 +2094,8 @@ __global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* _
     for (int j = 0; j < NK; ++j) {
       const unsigned i = (unsigned)tid * NK + j;
       if (i < keep) run_keys[(size_t)q * run_stride + i] = v[j];
-      if (i + 1 == (unsigned)k && keep == (unsigned)k) tau[q] = float_from_ord((unsigned)(v[j] >> 32));
+      // (tau_rank < k: the first round behind the bootstrap leaps -- see topk_merge)
+      if (i + 1 == (unsigned)tau_rank && keep == (unsigned)k) tau[q] = float_from_ord((unsigned)(v[j] >> 32));
     }
     if (tid == 0) {
       run_n[q] = keep;
@@ -2622,8 +2645,9 @@ hipError_t launch_query_margins(const void* xq, int dtype, long long nq, long lo
 
 hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsigned nq_pad, int k, float* scores,
                             unsigned long long* run_keys, unsigned* run_n, float* tau, unsigned long long* stat,
-                            unsigned* overflow, hipStream_t st, int run_stride) {
+                            unsigned* overflow, hipStream_t st, int run_stride, int tau_rank) {
   if (run_stride <= 0) run_stride = k;
+  if (tau_rank <= 0 || tau_rank > k) tau_rank = k;
   const int s_stride = (n_rows + 31) / 32 * 32;
   const unsigned row_tiles = (unsigned)(s_stride / 32);
   const unsigned per_wg = kBootWaves * kBootTilesPerWave;
@@ -2631,7 +2655,7 @@ hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsi
                      xb, xq_pad, n_rows, s_stride, scores);
 #define PROQA_SELECT_CASE(E)                                                                                            \
   hipLaunchKernelGGL(bootstrap_select<E>, dim3(nq_pad), dim3(kMergeThreads), 0, st, scores, n_rows, s_stride, k, run_stride, \
-                     run_keys, run_n, tau, stat, overflow)
+                     run_keys, run_n, tau, stat, overflow, tau_rank)
   if (n_rows <= 4 * kMergeThreads)
     PROQA_SELECT_CASE(4);
   else if (n_rows <= 8 * kMergeThreads)

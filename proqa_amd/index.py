@@ -181,7 +181,9 @@ class IndexFlatIP:
         return {"rounds": st.rounds, "fallback_rounds": st.fallback_rounds, "candidates": st.candidates,
                 "filter_ms": st.filter_ms, "total_ms": st.total_ms, "nominated": st.nominated,
                 "nomination": bool(st.nomination),
-                "nomination_state": ("off", "on", "suspended")[st.nomination_state] if 0 <= st.nomination_state <= 2 else None}
+                "nomination_state": ("off", "on", "suspended")[st.nomination_state] if 0 <= st.nomination_state <= 2 else None,
+                "leap_rank": st.leap_rank,
+                "leap_state": ("off", "on", "paused")[st.leap_state] if 0 <= st.leap_state <= 2 else None}
 
     def set_profiling(self, enable=True):
         _lib.check(self._lib.proqa_index_set_profiling(self._h, 1 if enable else 0))
@@ -215,6 +217,13 @@ class IndexFlatIP:
         scan's either way."""
         mode = {"off": 0, "auto": 1, "always": 2}.get(mode, mode)
         _lib.check(self._lib.proqa_index_configure_nomination(self._h, int(mode)))
+
+    def configure_leap(self, mode):
+        """Leaping rounds of the k <= 128 searches (see proqa_hip.h): thresholds at a rank j < k of the running lists, a
+        third to a half of the rounds; a round that falls short is re-scanned (the result never depends on it) and pauses
+        the leaps of this index (`last_stats()["leap_rank"]`, `["leap_state"]`).  0 / "off", 1 / "auto" (default)."""
+        mode = {"off": 0, "auto": 1}.get(mode, mode)
+        _lib.check(self._lib.proqa_index_configure_leap(self._h, int(mode)))
 
     def close(self):
         if getattr(self, "_h", None):

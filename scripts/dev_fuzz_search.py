@@ -1,5 +1,6 @@
 """Randomised parity fuzz of the HIP search against the NumPy oracles (dev; run on the MI355X).
 usage: python scripts/dev_fuzz_search.py [seconds] [seed]"""
+import os
 import sys, time
 import numpy as np
 import torch
@@ -55,10 +56,18 @@ while time.time() < t_end:
     Do, Io = oracle(xq, xb, k)
     tq = torch.from_numpy(xq).to(dev)
     always_nominate = bool(rng.random() < 0.5)
+    # leaping rounds (thresholds at a rank j < k): the planner's rank, a rank far too high (PROQA_LEAP_RANK is read at every
+    # search: most leaps fall short and are re-scanned), or none
+    leap = rng.choice(["auto", "auto", "rank", "off"])
+    os.environ.pop("PROQA_LEAP_RANK", None)
+    if leap == "rank":
+        os.environ["PROQA_LEAP_RANK"] = str(int(rng.integers(1, max(2, k))))
     bounds = np.linspace(0, n, shards + 1).astype(int)
     handles = []
     for lo, hi in zip(bounds[:-1], bounds[1:]):
         ix = IndexFlatIP(128)
+        if leap == "off":
+            ix.configure_leap("off")
         if always_nominate:
             ix.configure_nomination("always")       # the int8 nomination rounds on every shard of >= 512 rows (k <= 128)
         if hi > lo:

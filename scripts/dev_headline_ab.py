@@ -1,5 +1,5 @@
 """Wall and filter time of the headline search (2032 queries, k = 80, default schedule) over the first N rows of the bench
-corpus, for A/B by environment across processes (dev; MI355X).  usage: [ENV=...] python scripts/dev_headline_ab.py [rows ...]"""
+corpus, for A/B by environment across processes (dev; MI355X).  usage: [ENV=...] [AB_NQ=2032] [AB_K=80] python scripts/dev_headline_ab.py [rows ...]"""
 import hashlib
 import os
 import sys
@@ -12,7 +12,7 @@ sys.path.insert(0, ".")
 from proqa_amd.index import IndexFlatIP  # noqa: E402
 
 rows_list = [int(float(a)) for a in sys.argv[1:]] or [18_000_000, 2_250_000]
-nq, k = 2032, 80
+nq, k = int(os.environ.get("AB_NQ", 2032)), int(os.environ.get("AB_K", 80))
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev)
 g.manual_seed(0)

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in proqa_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == names
-    assert lib.proqa_abi_version() == 6
+    assert lib.proqa_abi_version() == 7
 
 
 def test_error_reporting_without_compute():
