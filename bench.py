@@ -937,6 +937,17 @@ def main():
                      "candidates_per_query": st16["candidates"] / max(nq, 1), "rounds": st16["rounds"],
                      "ids_equal": digest(result["DI"][1]) == ids_sha, "scores_equal": digest(result["DI"][0]) == scores_sha}
         step()   # (leave the nominated result in place for the legs below)
+    # the same search on ordinary rounds (thresholds at the k-th best) beside the leaping ones
+    ordinary = None
+    if st.get("leap_rank"):
+        local.configure_leap("off")
+        n_ord = max(3, args.steps // 2)
+        dt_ord = timed(step, n_ord, 1, world, device)
+        st_ord = local.last_stats()
+        local.configure_leap("auto")
+        ordinary = {"ms_per_step": dt_ord / n_ord * 1e3, "rounds": st_ord["rounds"],
+                    "ids_equal": digest(result["DI"][1]) == ids_sha, "scores_equal": digest(result["DI"][0]) == scores_sha}
+        step()
 
     # what ran where: every rank reports its process, GPU and shard (the record proves N ranks on N devices); the
     # digests of the merged result let two runs of the same workload (e.g. --gpus 1 and --gpus 2) be compared bit for bit
@@ -989,6 +1000,9 @@ def main():
                                 f"all-gather top-{k}, {args.transport}, "
                                 f"{dist.get_backend() if dist.is_initialized() else 'rccl (library communicator)'}"),
                    "rounds": st["rounds"], "fallback_rounds": st["fallback_rounds"],
+                   # leaping rounds (thresholds at rank leap_rank < k of the running lists, verified by the merges) and the
+                   # same search on ordinary rounds timed beside them
+                   "leap_rank": st.get("leap_rank"), "ordinary_rounds": ordinary,
                    "candidates_per_query": st["candidates"] / max(nq, 1),
                    "world_size": dist.get_world_size() if dist.is_initialized() else 1,
                    "backend": dist.get_backend() if dist.is_initialized() else None,
