@@ -136,7 +136,20 @@ struct proqa_index {
   double leap_plan_per_round = 0.0;
   int leap_logged = 0;                     // the plan last reported under PROQA_LOG
   uint64_t leap_epoch = 0;                 // rows_epoch the pause belongs to (changed rows start afresh)
-  int round_next_rank = 0, round_leap_check = 0;   // MergeArgs of the round being enqueued
+  int round_next_rank = 0, round_leap_check = 0, round_bit = 0;   // MergeArgs of the round being enqueued
+  // queries a leaping round left short (at most kRescueMax of them, nothing else overflowed) are searched again on ordinary
+  // rounds as a small batch of their own, instead of re-scanning the flagged slabs for every query (rescue_short_queries)
+  unsigned* short_rounds = nullptr;        // workspace [ws_nq_pad]: bit r = fell short in round r
+  struct Rescue {
+    std::vector<int> ids;                  // the short queries of the search that just completed (empty: nothing to do)
+    float* D = nullptr;
+    long long* I = nullptr;
+    int k = 0, out_stride = 0;
+    long long idx_offset = 0;
+    hipStream_t st = nullptr;
+  } rescue;
+  void* rescue_buf = nullptr;              // device: ids, fp16 query rows, D and I rows of the rescue batch
+  size_t rescue_bytes = 0;
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
   proqa::NominateParams* qparams = nullptr;   // workspace [ws_nq_pad]
   unsigned long long* stat_nom = nullptr;  // workspace [ws_nq_pad] rows re-scored per query
@@ -310,7 +323,8 @@ int ensure_q8(proqa_index* idx, hipStream_t st) {
     const int64_t cap = round_up<int64_t>(std::max(idx->n, idx->capacity), kStageRows);
     if (try_malloc((void**)&idx->xb8, (size_t)cap * kDim) != hipSuccess ||
         try_malloc((void**)&idx->blk8, (size_t)(cap / 32 + 16) * sizeof(float2)) != hipSuccess) {
-      if (idx->xb8) (void)hipFree(idx->xb8);
+      if (idx->rescue_buf) (void)hipFree(idx->rescue_buf);
+  if (idx->xb8) (void)hipFree(idx->xb8);
       idx->xb8 = nullptr;
       idx->q8_epoch = idx->rows_epoch;   // no room for the copy: this index is searched on its fp16 rows
       return PROQA_OK;
@@ -407,7 +421,8 @@ void free_store(proqa_index* idx) {
 
 void free_workspace(proqa_index* idx) {
   void* ptrs[] = {idx->xq_pad, idx->tau, idx->run_n, idx->run_keys, idx->stat_dev, idx->bound_keys, idx->ub, idx->done,
-                  idx->xq32, idx->margin, idx->tau_filter, idx->ub_filter, idx->xq8, idx->qparams, idx->stat_nom};
+                  idx->xq32, idx->margin, idx->tau_filter, idx->ub_filter, idx->xq8, idx->qparams, idx->stat_nom, idx->short_rounds};
+  idx->short_rounds = nullptr;
   idx->xq8 = nullptr;
   idx->qparams = nullptr;
   idx->stat_nom = nullptr;
@@ -450,6 +465,7 @@ int ensure_workspace(proqa_index* idx, int64_t nq_pad, int k) {
   PROQA_HIP(hipMalloc((void**)&idx->xq8, (size_t)q * kDim));
   PROQA_HIP(hipMalloc((void**)&idx->qparams, (size_t)q * sizeof(NominateParams)));
   PROQA_HIP(hipMalloc((void**)&idx->stat_nom, (size_t)q * sizeof(unsigned long long)));
+  PROQA_HIP(hipMalloc((void**)&idx->short_rounds, (size_t)q * sizeof(unsigned)));
   idx->ws_nq_pad = q;
   idx->ws_k = kk;
   return PROQA_OK;
@@ -587,6 +603,9 @@ int env_int(const char* name, int dflt) {
 }
 constexpr int kLeapMaxK = 128;
 constexpr double kLeapEps = 1e-8;
+// most queries of a search that are searched again by themselves when leaping rounds left them short (one small batch;
+// developer / test switch PROQA_LEAP_RESCUE_MAX, 0 = always the slab re-scan)
+const int kRescueMax = getenv("PROQA_LEAP_RESCUE_MAX") ? atoi(getenv("PROQA_LEAP_RESCUE_MAX")) : 256;
 
 // P(fewer than k rows beat the rank-j score after the rows seen grew by the factor rho): the negative-binomial sum
 double leap_fail_probability(int k, int j, double rho) {
@@ -775,6 +794,8 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
     if (ma.nom_keys == 1024) idx->used_small_merge = true;
     ma.next_rank = idx->round_next_rank;
     ma.leap_check = idx->round_leap_check;
+    ma.short_rounds = idx->short_rounds;
+    ma.round_bit = idx->round_bit;
 #ifdef PROQA_MERGE_STAMPS
     if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -849,6 +870,8 @@ int run_round(proqa_index* idx, const Slab& slab, int qw, unsigned n_qtiles, uns
   ma.nom_keys = 0;
   ma.next_rank = inclusive ? 0 : idx->round_next_rank;
   ma.leap_check = inclusive ? 0 : idx->round_leap_check;
+  ma.short_rounds = idx->short_rounds;
+  ma.round_bit = idx->round_bit;
 #ifdef PROQA_MERGE_STAMPS
   if (merge_stamps_dump(ma, nq_pad, st)) return PROQA_OK;
 #endif
@@ -980,6 +1003,7 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
     // (a leaping round's merge verifies its threshold and leaves the next round's: the same rank, the k-th best after the last)
     idx->round_leap_check = plan->leap_rank ? 1 : 0;
     idx->round_next_rank = plan->leap_rank && r + 1 < slabs.size() ? plan->leap_rank : 0;
+    idx->round_bit = (int)r;
     const int rc_round = run_round(idx, slabs[r], qw, n_qtiles, (unsigned)nq_pad, page_k, false, dense, bounded,
                                    idx->overflow + r, st, f0, f1);
     idx->round_leap_check = idx->round_next_rank = 0;
@@ -1024,7 +1048,35 @@ int page_complete(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64
   // only an adversarial row order reaches the dense leaves.
   const long long leaf_rows = (long long)((sort_capacity(page_k) - page_k) / kStageRows) * kStageRows;
   unsigned* word = idx->overflow + kMaxRounds - 1;
-  for (size_t r = 0; r < slabs.size(); ++r) {
+  // Leaping rounds that fell short and nothing else (no list, no merge overflowed): which queries?  A few -- the usual
+  // case on rows in a loose order -- are searched again as a batch of their own once this search is complete
+  // (rescue_short_queries: an HBM-bound small-batch search instead of an MFMA-bound pass over the flagged slabs for every
+  // query); many (rows sorted against the queries) take the slab re-scan below.
+  bool rescued = false;
+  if (idx->leap_active && !bounded && kRescueMax > 0) {
+    unsigned bits = 0;
+    for (size_t r = 0; r < slabs.size(); ++r) bits |= idx->mirror->overflow[r];
+    if (bits == 8u) {
+      std::vector<unsigned> flags((size_t)nq);
+      PROQA_HIP(hipMemcpyAsync(flags.data(), idx->short_rounds, (size_t)nq * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+      PROQA_HIP(hipStreamSynchronize(st));
+      std::vector<int> ids;
+      for (int64_t q = 0; q < nq && ids.size() <= (size_t)kRescueMax; ++q)
+        if (flags[(size_t)q]) ids.push_back((int)q);
+      if (!ids.empty() && ids.size() <= (size_t)kRescueMax) {
+        idx->overflow_bits |= 8u;
+        idx->rescue.ids.swap(ids);
+        idx->rescue.D = out.D + out.out_offset;
+        idx->rescue.I = out.I + out.out_offset;
+        idx->rescue.k = page_k;
+        idx->rescue.out_stride = out.out_stride;
+        idx->rescue.idx_offset = out.idx_offset;
+        idx->rescue.st = st;
+        rescued = true;
+      }
+    }
+  }
+  for (size_t r = 0; r < slabs.size() && !rescued; ++r) {
     if (!idx->mirror->overflow[r]) continue;
     idx->overflow_bits |= idx->mirror->overflow[r];
     std::vector<Slab> todo;
@@ -1391,6 +1443,53 @@ int finish_pending(proqa_index* idx, int* rewritten);
 int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset, float* D_dev,
                        int64_t* I_dev, hipStream_t st, bool defer, uint32_t* status_dev);
 
+// The queries page_complete listed in idx->rescue (leaping rounds left them short; every other query's result is verified):
+// their padded fp16 rows are gathered into a batch of their own, searched on ordinary rounds with this handle's workspace
+// (the search that owned it is complete), and their result rows written over the optimistic ones.  Waits for the stream.
+int rescue_short_queries(proqa_index* idx) {
+  proqa_index::Rescue rq;
+  std::swap(rq, idx->rescue);
+  const int s = (int)rq.ids.size(), k = rq.k;
+  if (s == 0) return PROQA_OK;
+  const size_t off_xq = round_up<size_t>((size_t)s * sizeof(int), 256), off_d = off_xq + (size_t)s * kDim * 2,
+               off_i = round_up<size_t>(off_d + (size_t)s * k * sizeof(float), 256), bytes = off_i + (size_t)s * k * sizeof(long long);
+  if (bytes > idx->rescue_bytes) {
+    if (idx->rescue_buf) (void)hipFree(idx->rescue_buf);
+    idx->rescue_buf = nullptr;
+    idx->rescue_bytes = 0;
+    PROQA_HIP(hipMalloc(&idx->rescue_buf, bytes));
+    idx->rescue_bytes = bytes;
+  }
+  char* base = (char*)idx->rescue_buf;
+  int* ids_dev = (int*)base;
+  float* D_tmp = (float*)(base + off_d);
+  long long* I_tmp = (long long*)(base + off_i);
+  PROQA_HIP(hipMemcpyAsync(ids_dev, rq.ids.data(), (size_t)s * sizeof(int), hipMemcpyHostToDevice, rq.st));
+  PROQA_HIP(launch_gather_query_rows(idx->xq_pad, ids_dev, s, base + off_xq, rq.st));
+  const proqa_search_stats outer = idx->stats;
+  const int mode = idx->leap_mode;
+  idx->leap_mode = 0;   // (ordinary rounds; the pause this search earned stays as note_leap left it)
+  const int rc = search_device_impl(idx, base + off_xq, s, PROQA_F16, k, rq.idx_offset, D_tmp, (int64_t*)I_tmp, rq.st, false, nullptr);
+  idx->leap_mode = mode;
+  if (rc) return rc;
+  PROQA_HIP(launch_scatter_result_rows(D_tmp, I_tmp, ids_dev, s, k, rq.D, rq.I, rq.out_stride, rq.st));
+  PROQA_HIP(hipStreamSynchronize(rq.st));
+  const proqa_search_stats inner = idx->stats;
+  idx->stats = outer;
+  idx->stats.fallback_rounds += inner.rounds + inner.fallback_rounds;   // rounds run again
+  idx->stats.candidates += inner.candidates;
+  idx->stats.nominated += inner.nominated;
+  idx->stats.total_ms += inner.total_ms;
+  idx->stats.nomination_state = inner.nomination_state;
+  idx->stats.leap_state = leap_state_of(idx);
+  log_line("index %p: %d quer%s a leaping round left short searched again on ordinary rounds (%d rounds, %.3f ms)", (void*)idx, s,
+           s == 1 ? "y" : "ies", inner.rounds, inner.total_ms);
+  return PROQA_OK;
+}
+
+int search_device_impl_body(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset, float* D_dev,
+                            int64_t* I_dev, hipStream_t st, bool defer, uint32_t* status_dev);
+
 // `defer`: a search of the one-page kind is only ENQUEUED (idx->pending describes it; finish_pending completes it);
 // every other kind runs to completion here.  `status_dev` (optional device word, written on the stream): 1 if the
 // completion will rewrite the result, else 0.
@@ -1416,6 +1515,13 @@ int search_device(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, i
 
 int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
                        float* D_dev, int64_t* I_dev, hipStream_t st, bool defer, uint32_t* status_dev) {
+  idx->rescue.ids.clear();
+  if (int rc = search_device_impl_body(idx, xq_dev, nq, dtype, k, idx_offset, D_dev, I_dev, st, defer, status_dev)) return rc;
+  return idx->rescue.ids.empty() ? PROQA_OK : rescue_short_queries(idx);
+}
+
+int search_device_impl_body(proqa_index* idx, const void* xq_dev, int64_t nq, int dtype, int k, int64_t idx_offset,
+                            float* D_dev, int64_t* I_dev, hipStream_t st, bool defer, uint32_t* status_dev) {
   if (idx->pending.active)   // a begun search nobody finished (an error path of the caller): complete it, drop its result
     if (int rc = finish_pending(idx, nullptr)) return rc;
   if (nq < 0 || k <= 0) return fail(PROQA_EINVAL, "search: nq=%lld k=%d", (long long)nq, k);
@@ -1470,7 +1576,7 @@ int search_device_impl(proqa_index* idx, const void* xq_dev, int64_t nq, int dty
     const bool check_q = dtype == PROQA_F32;
     if (check_q) PROQA_HIP(hipMemsetAsync(idx->inexact, 0, 2 * sizeof(unsigned), st));
     PROQA_HIP(launch_prep_queries(xq_dev, dtype, nq, idx->ws_nq_pad, idx->xq_pad, idx->tau, idx->run_n, idx->stat_dev,
-                                  nullptr, true, check_q ? idx->inexact : nullptr, idx->overflow, st));
+                                  nullptr, true, check_q ? idx->inexact : nullptr, idx->overflow, st, idx->short_rounds));
     if (check_q) {
       unsigned bad = 0;
       if (int rc = read_inexact(idx, "index_search (queries)", st, &bad)) return rc;
@@ -1634,6 +1740,10 @@ int finish_pending(proqa_index* idx, int* rewritten) {
   note_nomination(idx, pe.nq);
   note_leap(idx);
   if (rewritten) *rewritten = fallback != 0;
+  if (!idx->rescue.ids.empty()) {   // (queries a leaping round left short: searched again, their rows rewritten)
+    if (int rc = rescue_short_queries(idx)) return rc;
+    if (rewritten) *rewritten = 1;
+  }
   // the enqueued search found no current int8 copy of the rows and ran on the fp16 rows: build the copy now, behind the
   // host wait this call is anyway, so that the next search scans it
   if (idx->q8_build_due) {

@@ -119,6 +119,8 @@ struct MergeArgs {
   // the k-th best; leap_check: this round's scan tested against such a rank -- verify that k keys reach it (else overflow bit 3)
   int next_rank;
   int leap_check;
+  unsigned* short_rounds;        // [nq_pad] bit round_bit set: the query ended that leaping round with fewer than k rows above its threshold
+  int round_bit;
 };
 
 // ---- int8 nomination scan (the k <= kPageK rounds of an fp16 index; see "int8 nomination" in mips_kernels.hip) ----------
@@ -194,7 +196,12 @@ hipError_t launch_bootstrap(const char* xb, const void* xq_pad, int n_rows, unsi
 // overflow (optional): the kOverflowWords round words of the page that follows are zeroed
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                               bool reset_stat, unsigned* inexact, unsigned* overflow, hipStream_t st);
+                               bool reset_stat, unsigned* inexact, unsigned* overflow, hipStream_t st,
+                               unsigned* short_rounds = nullptr);
+// rows ids[0..n) of the padded fp16 queries -> out [n,128]; result rows [n,k] -> rows ids[i] of D / I (row stride out_stride)
+hipError_t launch_gather_query_rows(const void* xq_pad, const int* ids, int n, void* out, hipStream_t st);
+hipError_t launch_scatter_result_rows(const float* D_src, const long long* I_src, const int* ids, int n, int k, float* D, long long* I,
+                                      int out_stride, hipStream_t st);
 // What a search's one host synchronisation reads, written by the finalize kernel straight into pinned host memory (no
 // copy command on the stream): the overflow words of the rounds and the candidates summed over the queries.
 constexpr int kOverflowWords = 96;   // = kMaxRounds of mips_index.cpp

@@ -1479,6 +1479,10 @@ void topk_merge(MergeArgs a) {
   // overflow-safe path.  (Padding / exhausted queries -- threshold +inf, empty list -- have nothing to verify.)  What this merge leaves
   // in a.tau[q] is the threshold of the NEXT round: rank a.next_rank, or the k-th best (0: the last round, every other search)
   const float tau_in = a.leap_check ? a.tau[q] : 0.f;
+  auto fell_short = [&]() {   // (one thread per query and round)
+    atomicOr(a.overflow, 8u);
+    if (a.short_rounds) a.short_rounds[q] |= 1u << (a.round_bit & 31);
+  };
   auto note_rank = [&](unsigned i, unsigned long long key, unsigned keep) {   // key = the merged list's key of rank i
     if (keep != (unsigned)a.k) return;
     const unsigned rank = a.next_rank ? (unsigned)a.next_rank : (unsigned)a.k;
@@ -1487,7 +1491,7 @@ void topk_merge(MergeArgs a) {
       a.tau[q] = t;
       if (a.tau_filter) a.tau_filter[q] = filter_threshold(t, a.margin[q]);
     }
-    if (a.leap_check && i + 1 == (unsigned)a.k && !(float_from_ord((unsigned)(key >> 32)) > tau_in)) atomicOr(a.overflow, 8u);
+    if (a.leap_check && i + 1 == (unsigned)a.k && !(float_from_ord((unsigned)(key >> 32)) > tau_in)) fell_short();
   };
   unsigned cnt_first[2], n_spill_first;
   {
@@ -1821,7 +1825,7 @@ void topk_merge(MergeArgs a) {
   if (n_seen == 0) {  // nothing passed the threshold this round: the list stands -- and the threshold, unless the rank changes
     if (a.next_rank || a.leap_check) {   // (k <= T: run_pref is the whole list)
       if ((unsigned)tid < nrun) note_rank((unsigned)tid, run_pref, nrun);
-      if (tid == 0 && a.leap_check && nrun < (unsigned)a.k && tau_in != __builtin_inff()) atomicOr(a.overflow, 8u);
+      if (tid == 0 && a.leap_check && nrun < (unsigned)a.k && tau_in != __builtin_inff()) fell_short();
     }
     return;
   }
@@ -1898,7 +1902,7 @@ void topk_merge(MergeArgs a) {
       if (tid == 0) {
         a.run_n[q] = keep;
         a.stat_candidates[q] += n_seen;
-        if (a.leap_check && keep < (unsigned)a.k && tau_in != __builtin_inff()) atomicOr(a.overflow, 8u);
+        if (a.leap_check && keep < (unsigned)a.k && tau_in != __builtin_inff()) fell_short();
       }
     } else {
 #pragma unroll
@@ -2123,9 +2127,10 @@ __global__ __launch_bounds__(kMergeThreads) void bootstrap_select(const float* _
 // pad + convert queries to the fp16 [Qpad,128] operand layout, reset per-query state
 __global__ void prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, _Float16* xq_pad,
                              float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                             int reset_stat, unsigned* inexact, int debug_nohit, unsigned* overflow) {
+                             int reset_stat, unsigned* inexact, int debug_nohit, unsigned* overflow, unsigned* short_rounds) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (overflow && i < kOverflowWords) overflow[i] = 0u;   // the round words of the page that follows (no memset command)
+  if (short_rounds && i < nq_pad) short_rounds[i] = 0u;   // leaping rounds in which the query fell short (topk_merge)
   const long long n = nq_pad * kDim;
   if (i < n) {
     const long long q = i / kDim;
@@ -2237,6 +2242,23 @@ __global__ void gather_index_rows(const _Float16* __restrict__ xb16, const float
 }
 
 // one-pass search of a large k: a query that collected fewer than `want` rows above its estimated threshold
+// the queries a leaping round left short are searched again on ordinary rounds as a batch of their own (mips_index.cpp
+// rescue_short_queries): their padded fp16 rows out, their result rows back in
+__global__ void gather_query_rows(const uint4* __restrict__ xq_pad, const int* __restrict__ ids, int n, uint4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // one 16-byte piece per thread, kRowBytes / 16 pieces per row
+  constexpr int kPieces = kRowBytes / 16;
+  if (i < n * kPieces) out[i] = xq_pad[(size_t)ids[i / kPieces] * kPieces + i % kPieces];
+}
+__global__ void scatter_result_rows(const float* __restrict__ D_src, const long long* __restrict__ I_src, const int* __restrict__ ids,
+                                    int n, int k, float* __restrict__ D, long long* __restrict__ I, int out_stride) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * k) {
+    const size_t dst = (size_t)ids[i / k] * out_stride + i % k;
+    D[dst] = D_src[i];
+    I[dst] = I_src[i];
+  }
+}
+
 __global__ void flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag) {
   const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < nq && run_n[q] < want) *flag = 1u;
@@ -2678,6 +2700,19 @@ hipError_t launch_gather_index_rows(const void* xb16, const float* xb32, long lo
   return hipGetLastError();
 }
 
+hipError_t launch_gather_query_rows(const void* xq_pad, const int* ids, int n, void* out, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_query_rows, dim3((unsigned)((n * (kRowBytes / 16) + 255) / 256)), dim3(256), 0, st, (const uint4*)xq_pad, ids, n,
+                     (uint4*)out);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_result_rows(const float* D_src, const long long* I_src, const int* ids, int n, int k, float* D, long long* I,
+                                      int out_stride, hipStream_t st) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_result_rows, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, D_src, I_src, ids, n, k, D, I, out_stride);
+  return hipGetLastError();
+}
+
 hipError_t launch_flag_short_lists(const unsigned* run_n, long long nq, unsigned want, unsigned* flag, hipStream_t st) {
   hipLaunchKernelGGL(flag_short_lists, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, run_n, nq, want, flag);
   return hipGetLastError();
@@ -2727,11 +2762,11 @@ static const bool kDebugNoHit = getenv("PROQA_DEBUG_NOHIT") != nullptr;
 
 hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long long nq_pad, void* xq_pad,
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
-                               bool reset_stat, unsigned* inexact, unsigned* overflow, hipStream_t st) {
+                               bool reset_stat, unsigned* inexact, unsigned* overflow, hipStream_t st, unsigned* short_rounds) {
   const long long n = nq_pad * kDim;
   hipLaunchKernelGGL(prep_queries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xq, dtype, nq, nq_pad,
                      (_Float16*)xq_pad, tau, run_n, stat, done, reset_stat ? 1 : 0, inexact,
-                     kDebugNoHit ? 1 : 0, overflow);
+                     kDebugNoHit ? 1 : 0, overflow, short_rounds);
   return hipGetLastError();
 }
 

@@ -96,6 +96,50 @@ def test_a_leap_that_falls_short_is_rescanned_and_pauses_the_leaps(gpu_device, n
     np.testing.assert_array_equal(D.cpu().numpy().view(np.uint32), D2.view(np.uint32))
 
 
+def _planted(rng, n, nq, k, which):
+    """random rows; for the queries `which`, k rows among the first few hundred score far above everything else: their
+    running lists are final after the bootstrap, no later row beats the score at rank j -- those queries end every leaping round
+    short, all others are verified"""
+    xb = rng.standard_normal((n, 128)).astype(np.float32)
+    xq = rng.standard_normal((nq, 128)).astype(np.float32)
+    for i, q in enumerate(which):
+        r0 = 50 + 100 * i
+        xb[r0:r0 + k] = 4.0 * xq[q] + 0.05 * rng.standard_normal((k, 128))
+    return xb.astype(np.float16), xq.astype(np.float16)
+
+
+@pytest.mark.parametrize("nq,nomination,which", [(600, "always", (3, 17, 599)), (40, "always", (0,)), (600, "off", (5, 300)),
+                                                 (2000, "auto", tuple(range(0, 2000, 50)))])
+def test_a_few_short_queries_are_searched_again_by_themselves(gpu_device, nq, nomination, which):
+    rng = np.random.default_rng(nq)
+    n, k = 300000, 80
+    xb, xq = _planted(rng, n, nq, k, which)
+    D0, I0, st0, _ = _search(xb, xq, k, "off", nomination)
+    D1, I1, st1, ix = _search(xb, xq, k, "auto", nomination)
+    assert st1["leap_rank"] > 0 and st1["fallback_rounds"] > 0 and st1["leap_state"] == "paused", st1
+    # (the short queries alone ran again -- a small batch on ordinary rounds -- not the flagged slabs for all: far fewer rounds
+    # than the four quarters per flagged round of the slab re-scan)
+    assert st1["fallback_rounds"] <= 8, st1
+    np.testing.assert_array_equal(I1, I0)
+    np.testing.assert_array_equal(D1.view(np.uint32), D0.view(np.uint32))
+    for q in which:
+        assert set(I1[q]) == set(range(50 + 100 * which.index(q), 50 + 100 * which.index(q) + k))
+
+
+def test_the_deferred_search_searches_its_short_queries_again(gpu_device):
+    import torch
+    from proqa_amd.index import PipelinedSearcher
+    rng = np.random.default_rng(8)
+    xb, xq = _planted(rng, 300000, 512, 80, (1, 100, 257, 511))
+    D0, I0, _, _ = _search(xb, xq, 80, "off")
+    ps = PipelinedSearcher(torch.from_numpy(xb).cuda())
+    outs = list(ps.search_batches([torch.from_numpy(xq[:256]).cuda(), torch.from_numpy(xq[256:]).cuda()], 80))
+    np.testing.assert_array_equal(np.concatenate([o[1].cpu().numpy() for o in outs]), I0)
+    np.testing.assert_array_equal(np.concatenate([o[0].cpu().numpy() for o in outs]).view(np.uint32), D0.view(np.uint32))
+    assert all(st["fallback_rounds"] > 0 for st in ps.last_stats())
+    ps.close()
+
+
 @pytest.mark.parametrize("nq,k,rank,nomination", [(600, 80, 2, "always"), (40, 80, 3, "always"), (300, 128, 1, "off"), (600, 16, 2, "auto"),
                                                   (1, 80, 2, "always")])
 def test_thresholds_at_a_rank_far_too_high_are_caught_by_the_merge(gpu_device, monkeypatch, nq, k, rank, nomination):
@@ -171,3 +215,9 @@ print(ix.last_stats())
                        text=True, timeout=600)
     assert p.returncode == 0, p.stderr
     assert "leaping rounds behind a bootstrap" in p.stderr and "a leaping round found fewer than k rows" in p.stderr, p.stderr
+    # 64 short queries of 64: searched again by themselves; with PROQA_LEAP_RESCUE_MAX=0 the flagged slabs are re-scanned
+    assert "searched again on ordinary rounds" in p.stderr, p.stderr
+    q = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PROQA_LOG="1", PROQA_LEAP_RESCUE_MAX="0", PYTHONPATH=root),
+                       capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr
+    assert "a leaping round found fewer than k rows" in q.stderr and "searched again" not in q.stderr, q.stderr
