@@ -164,8 +164,8 @@ typedef struct proqa_search_stats {
                                 search over-nominated: fp16 scan until a re-probe succeeds or the rows change) */
   int32_t leap_rank;         /* > 0: the rounds of this search tested against the score at that rank (< k) of the running lists
                                 (leaping rounds, proqa_index_configure_leap); 0: against the k-th best, as ever */
-  int32_t leap_state;        /* of the index after this search: 0 off (mode 0 / exact-float32), 1 on, 2 paused (a leaping
-                                round fell short: ordinary rounds for the next 16, 32, ... 1024 eligible searches) */
+  int32_t leap_state;        /* of the index after this search: 0 off (mode 0 / exact-float32), 1 on, 2 paused (leaping
+                                rounds fell short: ordinary rounds for the next 16, 32, ... 1024 eligible searches) */
 } proqa_search_stats;
 int proqa_index_last_stats(const proqa_index* idx, proqa_search_stats* out);
 /* bracket every mips_filter launch with HIP events on the search stream (bench.py roofline) */
@@ -196,11 +196,14 @@ int proqa_index_configure_nomination(proqa_index* idx, int mode);
  * checks exactly that, and a round that falls short is re-scanned against the k-th best scores on the overflow-safe path
  * (proqa_search_stats.fallback_rounds) -- the result never depends on the leap.  j is the smallest rank for which the
  * shortfall has probability <= 1e-8 per query and round when the first rows stand for the rest (rows in no particular
- * order: the count of new rows above the rank-j score is negative-binomial (j, 1 / rho)).  Rows sorted by topic or norm make
- * leaps fall short: such a search pauses them for the next 16 eligible searches of the index, a failed retry doubles the
- * pause (up to 1024), a clean one clears it, changed rows start afresh; one stderr line per switch under PROQA_LOG.
- * mode 0: never; 1 (default): automatic, as above.  An index configured with proqa_index_configure(growth) keeps its
- * ordinary rounds. */
+ * order: the count of new rows above the rank-j score is negative-binomial (j, 1 / rho)).  What a shortfall costs: when at
+ * most 256 queries of the batch are short and nothing overflowed, THOSE queries are searched again as a small batch on
+ * ordinary rounds (~ +10 % of the search; every other query's result is verified); otherwise the flagged slabs are
+ * re-scanned for all queries (~2.7 x).  Rows sorted by topic or norm make leaps fall short: cheap shortfalls count three
+ * strikes each (a clean leap takes one back), the slab re-scan eight; at eight strikes the leaps of the index pause for 16
+ * eligible searches, a failed retry doubles the pause (up to 1024), a clean one clears it, changed rows start afresh; one
+ * stderr line per event under PROQA_LOG.  mode 0: never; 1 (default): automatic, as above.  An index configured with
+ * proqa_index_configure(growth) keeps its ordinary rounds. */
 int proqa_index_configure_leap(proqa_index* idx, int mode);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]

@@ -130,6 +130,7 @@ struct proqa_index {
   int leap_mode = 1;                       // 0 never, 1 automatic (developer switch PROQA_LEAP)
   int leap_pause = 0;                      // length of the current pause
   int leap_skip = 0;                       // searches of that pause still to go
+  int leap_strikes = 0;                    // what the recent shortfalls cost (note_leap): a pause at eight
   bool leap_active = false;                // the search being enqueued leaps
   long long leap_key[6] = {0, 0, 0, 0, 0, 0};   // what the kept plan was made for
   int leap_plan_rounds = 0, leap_plan_rank = 0;
@@ -951,7 +952,7 @@ int page_enqueue(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64_
       page_k <= kLeapMaxK) {
     if (idx->leap_epoch != idx->rows_epoch) {
       idx->leap_epoch = idx->rows_epoch;
-      idx->leap_pause = idx->leap_skip = 0;
+      idx->leap_pause = idx->leap_skip = idx->leap_strikes = 0;
     }
     if (idx->leap_skip > 0)
       --idx->leap_skip;
@@ -1427,14 +1428,30 @@ void note_leap(proqa_index* idx) {
   idx->stats.leap_state = leap_state_of(idx);
   if (!idx->leap_active) return;
   idx->leap_active = false;
-  if (idx->overflow_bits) {   // bit 3: a round fell short; any other: scores that tie in numbers (the rows a leap logs tie with more) -- pause too
-    idx->leap_pause = idx->leap_pause ? std::min(2 * idx->leap_pause, 1024) : 16;
-    idx->leap_skip = idx->leap_pause;
-    log_line("index %p: a leaping round found fewer than k rows above its threshold or overflowed (%d overflow-safe rounds, overflow "
-             "bits %u): ordinary rounds for the next %d searches", (void*)idx, idx->stats.fallback_rounds, idx->overflow_bits, idx->leap_skip);
-  } else if (idx->leap_pause) {
-    log_line("index %p: leaping rounds resumed", (void*)idx);
-    idx->leap_pause = 0;
+  if (idx->overflow_bits) {
+    // bit 3: a round fell short; any other: scores that tie in numbers (the rows a leap logs tie with more).  What it cost
+    // decides how soon the leaps pause: a few short queries searched again by themselves (idx->rescue is set) are ~10 % of a
+    // search -- three strikes each, one taken back by every clean leap, a pause at eight: leaps go on while fewer than a
+    // quarter of the searches fall short (they pay up to a half); the slab re-scan for every query is ~2.7 x a search -- eight
+    // strikes, a pause at once
+    idx->leap_strikes = std::min(idx->leap_strikes + (idx->rescue.ids.empty() ? 8 : 3), 16);
+    if (idx->leap_strikes >= 8) {
+      idx->leap_pause = idx->leap_pause ? std::min(2 * idx->leap_pause, 1024) : 16;
+      idx->leap_skip = idx->leap_pause;
+      idx->leap_strikes = 4;
+      log_line("index %p: a leaping round found fewer than k rows above its threshold or overflowed (%d overflow-safe rounds, overflow "
+               "bits %u): ordinary rounds for the next %d searches", (void*)idx, idx->stats.fallback_rounds, idx->overflow_bits,
+               idx->leap_skip);
+    } else {
+      log_line("index %p: a leaping round found fewer than k rows above its threshold for %zu quer%s: leaps go on (%d strikes of 8)",
+               (void*)idx, idx->rescue.ids.size(), idx->rescue.ids.size() == 1 ? "y" : "ies", idx->leap_strikes);
+    }
+  } else {
+    if (idx->leap_strikes > 0) --idx->leap_strikes;
+    if (idx->leap_pause) {
+      log_line("index %p: leaping rounds resumed", (void*)idx);
+      idx->leap_pause = 0;
+    }
   }
   idx->stats.leap_state = leap_state_of(idx);
 }
@@ -1874,7 +1891,7 @@ int proqa_index_configure_leap(proqa_index* idx, int mode) {
   if (!idx) return fail(PROQA_EINVAL, "index_configure_leap: NULL handle");
   if (mode < 0 || mode > 1) return fail(PROQA_EINVAL, "index_configure_leap: mode=%d (0 off, 1 automatic)", mode);
   idx->leap_mode = mode;
-  idx->leap_pause = idx->leap_skip = 0;
+  idx->leap_pause = idx->leap_skip = idx->leap_strikes = 0;
   return PROQA_OK;
 }
 

@@ -32,7 +32,7 @@ for s in shorts:
     for i, q in enumerate(qs.tolist()):
         r = torch.arange(k, device=dev) * max(s, 1) + i
         r = r[r < 4096]
-        xb[r] = (4.0 * xq[q].float() + 0.05 * torch.randn((r.numel(), 128), generator=g, device=dev)).to(torch.float16)
+        xb[r] = (1.2 * xq[q].float() + 0.02 * torch.randn((r.numel(), 128), generator=g, device=dev)).to(torch.float16)
     ix = IndexFlatIP(128)
     ix.adopt_device(xb)
     ix.prepare()

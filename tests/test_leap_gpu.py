@@ -55,7 +55,7 @@ def _sorted_rows(rng, n, nq):
     return xb, xq
 
 
-@pytest.mark.parametrize("nq,nomination", [(300, "always"), (40, "always"), (600, "off")])
+@pytest.mark.parametrize("nq,nomination", [(300, "always"), (2000, "auto"), (600, "off")])
 def test_a_leap_that_falls_short_is_rescanned_and_pauses_the_leaps(gpu_device, nq, nomination):
     import torch
     rng = np.random.default_rng(11)
@@ -104,26 +104,38 @@ def _planted(rng, n, nq, k, which):
     xq = rng.standard_normal((nq, 128)).astype(np.float32)
     for i, q in enumerate(which):
         r0 = 50 + 100 * i
-        xb[r0:r0 + k] = 4.0 * xq[q] + 0.05 * rng.standard_normal((k, 128))
+        # (1.2 x the query: ~150 against a best ordinary score of ~40, and few OTHER queries score high on these rows)
+        xb[r0:r0 + k] = 1.2 * xq[q] + 0.02 * rng.standard_normal((k, 128))
     return xb.astype(np.float16), xq.astype(np.float16)
 
 
 @pytest.mark.parametrize("nq,nomination,which", [(600, "always", (3, 17, 599)), (40, "always", (0,)), (600, "off", (5, 300)),
-                                                 (2000, "auto", tuple(range(0, 2000, 50)))])
+                                                 (2000, "auto", tuple(range(0, 2000, 250)))])
 def test_a_few_short_queries_are_searched_again_by_themselves(gpu_device, nq, nomination, which):
     rng = np.random.default_rng(nq)
     n, k = 300000, 80
     xb, xq = _planted(rng, n, nq, k, which)
     D0, I0, st0, _ = _search(xb, xq, k, "off", nomination)
     D1, I1, st1, ix = _search(xb, xq, k, "auto", nomination)
-    assert st1["leap_rank"] > 0 and st1["fallback_rounds"] > 0 and st1["leap_state"] == "paused", st1
-    # (the short queries alone ran again -- a small batch on ordinary rounds -- not the flagged slabs for all: far fewer rounds
-    # than the four quarters per flagged round of the slab re-scan)
-    assert st1["fallback_rounds"] <= 8, st1
+    # (a shortfall this cheap does not pause the leaps at once: three strikes each, a pause at eight)
+    assert st1["leap_rank"] > 0 and st1["fallback_rounds"] > 0 and st1["leap_state"] == "on", st1
+    # (the short queries alone ran again -- a small batch on ordinary rounds -- not the flagged slabs for all queries, which is
+    # four quarters per flagged round)
+    assert st1["fallback_rounds"] < 4 * st1["rounds"], st1
     np.testing.assert_array_equal(I1, I0)
     np.testing.assert_array_equal(D1.view(np.uint32), D0.view(np.uint32))
     for q in which:
         assert set(I1[q]) == set(range(50 + 100 * which.index(q), 50 + 100 * which.index(q) + k))
+    import torch
+    tq = torch.from_numpy(xq).cuda()
+    states = []
+    for _ in range(3):
+        D, I = ix.search_device(tq, k)
+        st = ix.last_stats()
+        states.append((st["leap_rank"] > 0, st["leap_state"]))
+        np.testing.assert_array_equal(I.cpu().numpy(), I0)
+    # strikes 3, 6, 9 -> the third shortfall pauses; the search after it takes ordinary rounds
+    assert states == [(True, "on"), (True, "paused"), (False, "paused")], states
 
 
 def test_the_deferred_search_searches_its_short_queries_again(gpu_device):
@@ -153,7 +165,8 @@ def test_thresholds_at_a_rank_far_too_high_are_caught_by_the_merge(gpu_device, m
     monkeypatch.setenv("PROQA_LEAP_RANK", str(rank))
     monkeypatch.setenv("PROQA_LEAP_ROUNDS", "3")
     D1, I1, st1, _ = _search(xb, xq, k, "auto", nomination)
-    assert st1["leap_rank"] == rank and st1["fallback_rounds"] > 0 and st1["leap_state"] == "paused", st1
+    assert st1["leap_rank"] == rank and st1["fallback_rounds"] > 0, st1
+    assert st1["leap_state"] == ("paused" if nq > 256 else "on")   # (<= 256 short queries: searched again by themselves, a cheap shortfall)
     np.testing.assert_array_equal(I1, I0)
     np.testing.assert_array_equal(D1.view(np.uint32), D0.view(np.uint32))
 
@@ -216,8 +229,8 @@ print(ix.last_stats())
     assert p.returncode == 0, p.stderr
     assert "leaping rounds behind a bootstrap" in p.stderr and "a leaping round found fewer than k rows" in p.stderr, p.stderr
     # 64 short queries of 64: searched again by themselves; with PROQA_LEAP_RESCUE_MAX=0 the flagged slabs are re-scanned
-    assert "searched again on ordinary rounds" in p.stderr, p.stderr
+    assert "searched again on ordinary rounds" in p.stderr and "leaps go on (3 strikes of 8)" in p.stderr, p.stderr
     q = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PROQA_LOG="1", PROQA_LEAP_RESCUE_MAX="0", PYTHONPATH=root),
                        capture_output=True, text=True, timeout=600)
     assert q.returncode == 0, q.stderr
-    assert "a leaping round found fewer than k rows" in q.stderr and "searched again" not in q.stderr, q.stderr
+    assert "ordinary rounds for the next 16 searches" in q.stderr and "searched again" not in q.stderr, q.stderr
