@@ -938,8 +938,9 @@ def main():
                      "ids_equal": digest(result["DI"][1]) == ids_sha, "scores_equal": digest(result["DI"][0]) == scores_sha}
         step()   # (leave the nominated result in place for the legs below)
     # the same search on ordinary rounds (thresholds at the k-th best) beside the leaping ones
+    # (not under --skip-extras: the profile passes of scripts/collect_profiles.sh count launches per search)
     ordinary = None
-    if st.get("leap_rank"):
+    if st.get("leap_rank") and not args.skip_extras:
         local.configure_leap("off")
         n_ord = max(3, args.steps // 2)
         dt_ord = timed(step, n_ord, 1, world, device)
