@@ -20,6 +20,10 @@ five significant digits, no prose.  What the keys mean:
                            (profiles/pmc_traffic.json, stamped with its commit), null when that pass measured the other scan;
                            .rescore_gather_bytes = fp16 rows the merges gather for the exact re-scoring
   fp16_scan                the same search with the nomination switched off (mips_filter_f16), digests compared
+  config.leap_rank /       leaping rounds: the rank (< k) of the running lists the rounds tested against, and the same search on
+  config.ordinary_rounds   ordinary rounds (thresholds at the k-th best) timed beside it, digests compared
+  query_shards             N > 1 only: the same job with the rows REPLICATED on every rank and the queries sharded (one all-gather
+                           of the result rows, no rank merge); `value` stays the row-sharded figure of BASELINE configs[3]
   scan_small_batch         32 queries over the same rows: the HBM-bound regime (algorithmic bytes = rows x 256 B)
   shard_sweep              N=1 timing of the per-rank search of a G-rank job (first N/G rows, no collective); .pipelined_ms_per_search:
                            the same searches as a stream of batches on two handles / two streams (PipelinedSearcher)
@@ -858,6 +862,56 @@ def online_leg(args, device, index, n_rows):
     return out
 
 
+def query_shards_leg(args, n, nq, k, world, rank, device, xq, ids_sha, scores_sha, digest):
+    """rows replicated, queries sharded: queries [rank * per, (rank + 1) * per) over all n rows on every rank, then one
+    all-gather of the [per, k] result rows (timed with it).  Collective-safe: the ranks agree that every one of them built
+    its replica before the first collective of the timed loop."""
+    from proqa_amd.index import IndexFlatIP
+    per = (nq + world - 1) // world
+    ok, err, ix = 1, None, None
+    try:
+        rows = gen_rows(0, n, device)
+        ix = IndexFlatIP(128)
+        ix.adopt_device(rows)
+        ix.prepare()
+        q0, q1 = min(rank * per, nq), min((rank + 1) * per, nq)
+        xq_mine = xq[q0:q1].contiguous()
+        Dp = torch.full((per, k), float("-inf"), dtype=torch.float32, device=device)
+        Ip = torch.full((per, k), -1, dtype=torch.int64, device=device)
+    except Exception as e:   # (e.g. no room for the replica beside the row shard on a shared GPU)
+        ok, err = 0, repr(e)[:200]
+    flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"error": err or "another rank could not build its replica"}
+    gathered = {}
+
+    def gather(t):
+        if dist.get_backend() == "gloo":
+            tc = t.cpu()
+            parts = [torch.empty_like(tc) for _ in range(world)]
+            dist.all_gather(parts, tc)
+            return torch.cat(parts).to(device)
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=device)
+        dist.all_gather_into_tensor(out, t)
+        return out
+
+    def step():
+        if q1 > q0:
+            ix.search_device(xq_mine, k, out=(Dp[:q1 - q0], Ip[:q1 - q0]))
+        gathered["D"], gathered["I"] = gather(Dp)[:nq], gather(Ip)[:nq]
+
+    steps = max(5, args.steps // 2)
+    dt = timed(step, steps, 2, world, device)
+    out = {"value": nq * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "queries_per_rank": per,
+           "rows_per_rank": n, "exchange": "all-gather of the result rows, no rank merge",
+           "ids_equal": digest(gathered["I"]) == ids_sha, "scores_equal": digest(gathered["D"]) == scores_sha}
+    ix.close()
+    del rows
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1013,6 +1067,13 @@ def main():
     }
     if fp16_scan:
         line["fp16_scan"] = fp16_scan
+
+    # N > 1: the SAME job with the rows replicated and the QUERIES sharded -- every rank holds all N rows (+ their int8 copy:
+    # 6.9 GB of 288 at 18M rows) and searches its nq / world queries; one all-gather of the result rows, no rank merge.
+    # `value` above stays the row-sharded figure BASELINE configs[3] prescribes; this is what the machine's memory allows
+    # (DESIGN.md section 7).  Any failure here is reported in the object and never costs the line.
+    if world > 1 and dist.is_initialized() and not args.skip_extras:
+        line["query_shards"] = query_shards_leg(args, n, nq, k, world, rank, device, xq, ids_sha, scores_sha, digest)
 
     if dist.is_initialized():
         # where a sharded step goes: the rank-local search alone (max over ranks) vs the whole step with the exchange

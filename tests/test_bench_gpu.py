@@ -41,6 +41,25 @@ def test_bench_starts_its_own_ranks(gpu_device):
     assert two["result"] == one["result"]
 
 
+def test_two_ranks_also_time_query_shards_over_replicated_rows(gpu_device):
+    """N > 1 without --skip-extras: beside the row-sharded `value` the line carries the same job with the rows replicated and
+    the queries sharded (65 queries on 2 ranks: 33 + 32, the second slice padded), its result equal to the row-sharded one."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "400000", "--queries", "65", "--steps", "2",
+           "--warmup", "1", "--skip-encode", "--skip-float32", "--skip-cpu"]
+    env = dict(os.environ, PROQA_DIST_BACKEND="gloo")
+    for v in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 6000
+    line = json.loads(lines[0])
+    qs = line["query_shards"]
+    assert "error" not in qs, qs
+    assert qs["queries_per_rank"] == 33 and qs["rows_per_rank"] == 400000 and qs["value"] > 0
+    assert qs["ids_equal"] and qs["scores_equal"]
+
+
 def test_the_full_line_fits_the_drivers_tail(gpu_device):
     """The default N = 1 run with every leg (shrunk: 1M rows, 3 steps, 20 k passages) prints one line of <= 6000 bytes that
     still carries the headline, the roofline object, the fp16 scan beside the nomination scan, and the secondary legs."""
