@@ -196,11 +196,13 @@ int proqa_index_configure_nomination(proqa_index* idx, int mode);
  * checks exactly that, and a round that falls short is re-scanned against the k-th best scores on the overflow-safe path
  * (proqa_search_stats.fallback_rounds) -- the result never depends on the leap.  j is the smallest rank for which the
  * shortfall has probability <= 1e-8 per query and round when the first rows stand for the rest (rows in no particular
- * order: the count of new rows above the rank-j score is negative-binomial (j, 1 / rho)).  What a shortfall costs: when at
- * most 256 queries of the batch are short and nothing overflowed, THOSE queries are searched again as a small batch on
- * ordinary rounds (~ +10 % of the search; every other query's result is verified); otherwise the flagged slabs are
- * re-scanned for all queries (~2.7 x).  Rows sorted by topic or norm make leaps fall short: cheap shortfalls count three
- * strikes each (a clean leap takes one back), the slab re-scan eight; at eight strikes the leaps of the index pause for 16
+ * order: the count of new rows above the rank-j score is negative-binomial (j, 1 / rho)).  What a shortfall costs: the
+ * queries that fell short are searched again as a batch of their own on ordinary rounds and their result rows rewritten
+ * (every other query's result is verified): ~ +10 % of the search for a handful, at most one more search for all of them
+ * (the flagged slabs are re-scanned for all queries only when a list or a merge overflowed as well).  Rows sorted by topic
+ * or norm -- or long runs of near-duplicates: ~k/2 rows that score alike next to each other -- make leaps fall short:
+ * up to 256 short queries count three strikes (a clean leap takes one back), more eight; at eight strikes the leaps of the
+ * index pause for 16
  * eligible searches, a failed retry doubles the pause (up to 1024), a clean one clears it, changed rows start afresh; one
  * stderr line per event under PROQA_LOG.  mode 0: never; 1 (default): automatic, as above.  An index configured with
  * proqa_index_configure(growth) keeps its ordinary rounds. */

@@ -604,9 +604,12 @@ int env_int(const char* name, int dflt) {
 }
 constexpr int kLeapMaxK = 128;
 constexpr double kLeapEps = 1e-8;
-// most queries of a search that are searched again by themselves when leaping rounds left them short (one small batch;
-// developer / test switch PROQA_LEAP_RESCUE_MAX, 0 = always the slab re-scan)
-const int kRescueMax = getenv("PROQA_LEAP_RESCUE_MAX") ? atoi(getenv("PROQA_LEAP_RESCUE_MAX")) : 256;
+// Queries that leaping rounds left short are searched again by themselves -- all of them, however many: a second search of s <= nq
+// queries on ordinary rounds never costs more than the first one did, the overflow-safe re-scan of the flagged slabs for
+// every query ~1.7 x (developer / test switch PROQA_LEAP_RESCUE_MAX: at most that many, 0 = always the slab re-scan).  Up to
+// kRescueCheap of them count as a cheap shortfall (note_leap).
+constexpr int kRescueCheap = 256;
+const int kRescueMax = getenv("PROQA_LEAP_RESCUE_MAX") ? atoi(getenv("PROQA_LEAP_RESCUE_MAX")) : (1 << 30);
 
 // P(fewer than k rows beat the rank-j score after the rows seen grew by the factor rho): the negative-binomial sum
 double leap_fail_probability(int k, int j, double rho) {
@@ -1049,10 +1052,10 @@ int page_complete(proqa_index* idx, int qw, unsigned n_qtiles, int64_t nq, int64
   // only an adversarial row order reaches the dense leaves.
   const long long leaf_rows = (long long)((sort_capacity(page_k) - page_k) / kStageRows) * kStageRows;
   unsigned* word = idx->overflow + kMaxRounds - 1;
-  // Leaping rounds that fell short and nothing else (no list, no merge overflowed): which queries?  A few -- the usual
-  // case on rows in a loose order -- are searched again as a batch of their own once this search is complete
-  // (rescue_short_queries: an HBM-bound small-batch search instead of an MFMA-bound pass over the flagged slabs for every
-  // query); many (rows sorted against the queries) take the slab re-scan below.
+  // Leaping rounds that fell short and nothing else (no list, no merge overflowed): which queries?  They are searched
+  // again as a batch of their own once this search is complete (rescue_short_queries: a few -- the usual case on rows in a
+  // loose order -- are an HBM-bound small-batch search; all of them, on rows sorted against the queries, one more search on
+  // ordinary rounds) instead of an fp16 pass over the flagged slabs for every query.
   bool rescued = false;
   if (idx->leap_active && !bounded && kRescueMax > 0) {
     unsigned bits = 0;
@@ -1430,11 +1433,12 @@ void note_leap(proqa_index* idx) {
   idx->leap_active = false;
   if (idx->overflow_bits) {
     // bit 3: a round fell short; any other: scores that tie in numbers (the rows a leap logs tie with more).  What it cost
-    // decides how soon the leaps pause: a few short queries searched again by themselves (idx->rescue is set) are ~10 % of a
+    // decides how soon the leaps pause: up to 256 short queries searched again by themselves (idx->rescue) are ~10 % of a
     // search -- three strikes each, one taken back by every clean leap, a pause at eight: leaps go on while fewer than a
-    // quarter of the searches fall short (they pay up to a half); the slab re-scan for every query is ~2.7 x a search -- eight
-    // strikes, a pause at once
-    idx->leap_strikes = std::min(idx->leap_strikes + (idx->rescue.ids.empty() ? 8 : 3), 16);
+    // quarter of the searches fall short (they pay up to a half); more short queries (up to a whole second search) or the
+    // slab re-scan for every query -- eight strikes, a pause at once
+    const bool cheap = !idx->rescue.ids.empty() && idx->rescue.ids.size() <= (size_t)kRescueCheap;
+    idx->leap_strikes = std::min(idx->leap_strikes + (cheap ? 3 : 8), 16);
     if (idx->leap_strikes >= 8) {
       idx->leap_pause = idx->leap_pause ? std::min(2 * idx->leap_pause, 1024) : 16;
       idx->leap_skip = idx->leap_pause;
