@@ -863,49 +863,32 @@ def online_leg(args, device, index, n_rows):
 
 
 def query_shards_leg(args, n, nq, k, world, rank, device, xq, ids_sha, scores_sha, digest):
-    """rows replicated, queries sharded: queries [rank * per, (rank + 1) * per) over all n rows on every rank, then one
-    all-gather of the [per, k] result rows (timed with it).  Collective-safe: the ranks agree that every one of them built
-    its replica before the first collective of the timed loop."""
-    from proqa_amd.index import IndexFlatIP
-    per = (nq + world - 1) // world
-    ok, err, ix = 1, None, None
+    """rows replicated, queries sharded (proqa_amd.index.QueryShardedIndexFlatIP): every rank searches its nq / world queries
+    over all n rows, one all-gather of the result rows (timed with it).  Collective-safe: the ranks agree that every one of
+    them built its replica before the first collective of the timed loop."""
+    from proqa_amd.index import QueryShardedIndexFlatIP
+    ok, err, ix, rows = 1, None, None, None
     try:
         rows = gen_rows(0, n, device)
-        ix = IndexFlatIP(128)
-        ix.adopt_device(rows)
+        ix = QueryShardedIndexFlatIP()
+        ix.adopt(rows)
         ix.prepare()
-        q0, q1 = min(rank * per, nq), min((rank + 1) * per, nq)
-        xq_mine = xq[q0:q1].contiguous()
-        Dp = torch.full((per, k), float("-inf"), dtype=torch.float32, device=device)
-        Ip = torch.full((per, k), -1, dtype=torch.int64, device=device)
     except Exception as e:   # (e.g. no room for the replica beside the row shard on a shared GPU)
         ok, err = 0, repr(e)[:200]
     flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend() != "gloo" else "cpu")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         return {"error": err or "another rank could not build its replica"}
-    gathered = {}
-
-    def gather(t):
-        if dist.get_backend() == "gloo":
-            tc = t.cpu()
-            parts = [torch.empty_like(tc) for _ in range(world)]
-            dist.all_gather(parts, tc)
-            return torch.cat(parts).to(device)
-        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=device)
-        dist.all_gather_into_tensor(out, t)
-        return out
+    got = {}
 
     def step():
-        if q1 > q0:
-            ix.search_device(xq_mine, k, out=(Dp[:q1 - q0], Ip[:q1 - q0]))
-        gathered["D"], gathered["I"] = gather(Dp)[:nq], gather(Ip)[:nq]
+        got["DI"] = ix.search(xq, k)
 
     steps = max(5, args.steps // 2)
     dt = timed(step, steps, 2, world, device)
-    out = {"value": nq * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "queries_per_rank": per,
+    out = {"value": nq * steps / dt, "unit": "queries/s", "ms_per_step": dt / steps * 1e3, "queries_per_rank": (nq + world - 1) // world,
            "rows_per_rank": n, "exchange": "all-gather of the result rows, no rank merge",
-           "ids_equal": digest(gathered["I"]) == ids_sha, "scores_equal": digest(gathered["D"]) == scores_sha}
+           "ids_equal": digest(got["DI"][1]) == ids_sha, "scores_equal": digest(got["DI"][0]) == scores_sha}
     ix.close()
     del rows
     torch.cuda.empty_cache()

@@ -56,6 +56,41 @@ def test_two_ranks_one_gpu_sharded_search(gpu_device, tmp_path):
         np.testing.assert_array_equal(np.load(tmp_path / f"D{r}.npy"), D)
 
 
+def _query_shard_worker(rank, world, port, n, nq, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from proqa_amd.index import QueryShardedIndexFlatIP
+        dev = torch.device("cuda:0")
+        rng = np.random.default_rng(8)
+        xb = rng.integers(-4, 5, (n, 128)).astype(np.float16)
+        xq = rng.integers(-4, 5, (nq, 128)).astype(np.float16)
+        index = QueryShardedIndexFlatIP()
+        index.add(xb)                       # every rank holds all rows
+        index.prepare()
+        D, I = index.search(torch.from_numpy(xq).to(dev), k)
+        assert D.is_cuda and tuple(D.shape) == (nq, k)
+        np.save(os.path.join(out_dir, f"qD{rank}.npy"), D.cpu().numpy())
+        np.save(os.path.join(out_dir, f"qI{rank}.npy"), I.cpu().numpy())
+        index.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_query_sharded_search(gpu_device, tmp_path):
+    """rows replicated, queries sharded (QueryShardedIndexFlatIP): 301 queries = 151 + 150, the HIP search on both ranks"""
+    from oracle import search_oracle
+    n, nq, k = 70001, 301, 80
+    mp.spawn(_query_shard_worker, args=(2, _free_port(), n, nq, k, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(8)
+    xb = rng.integers(-4, 5, (n, 128)).astype(np.float16)
+    xq = rng.integers(-4, 5, (nq, 128)).astype(np.float16)
+    D, I = search_oracle.topk_ip(xq, xb, k)
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"qI{r}.npy"), I)
+        np.testing.assert_array_equal(np.load(tmp_path / f"qD{r}.npy"), D)
+
+
 def test_two_ranks_one_gpu_sharded_encode(gpu_device, tmp_path):
     """torchrun-style launch of get_embed.py (WORLD_SIZE=2): each rank encodes a contiguous row
     range and writes its slice of one pre-sized .npy; result == the single-process file."""

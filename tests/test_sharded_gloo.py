@@ -62,6 +62,46 @@ def test_two_rank_sharded_search_equals_unsharded(tmp_path, n, nq, k):
         np.testing.assert_array_equal(np.load(tmp_path / f"D{r}.npy"), D)
 
 
+def _query_worker(rank, world, port, n, nq, k, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from proqa_amd.index import QueryShardedIndexFlatIP
+        rng = np.random.default_rng(43)
+        xb = rng.integers(-3, 4, (n, 128)).astype(np.float16)
+        xq = rng.integers(-3, 4, (nq, 128)).astype(np.float16)
+        seen = []
+
+        def local_search(q, kk):
+            seen.append(q.shape[0])
+            D, I = search_oracle.topk_ip(q.numpy(), xb, kk)
+            return torch.from_numpy(D), torch.from_numpy(I)
+
+        index = QueryShardedIndexFlatIP(local_search=local_search)
+        D, I = index.search(torch.from_numpy(xq), k)
+        per = (nq + world - 1) // world
+        assert seen == ([min(per, max(nq - rank * per, 0))] if nq > rank * per else [])
+        np.save(os.path.join(out_dir, f"qD{rank}.npy"), D.numpy())
+        np.save(os.path.join(out_dir, f"qI{rank}.npy"), I.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,nq,k", [(1001, 9, 80), (50, 4, 80), (300, 1, 10)])
+def test_two_rank_query_sharded_search_equals_unsharded(tmp_path, n, nq, k):
+    """rows replicated, queries sharded (QueryShardedIndexFlatIP): 9 queries = 5 + 4 (a padded slice), 1 query = 1 + 0 (an
+    empty slice); every rank ends with the whole result"""
+    port = _free_port()
+    mp.spawn(_query_worker, args=(2, port, n, nq, k, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(43)
+    xb = rng.integers(-3, 4, (n, 128)).astype(np.float16)
+    xq = rng.integers(-3, 4, (nq, 128)).astype(np.float16)
+    D, I = search_oracle.topk_ip(xq, xb, k)
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"qI{r}.npy"), I)
+        np.testing.assert_array_equal(np.load(tmp_path / f"qD{r}.npy"), D)
+
+
 def test_shard_bounds_cover_without_overlap():
     from proqa_amd.index import shard_bounds
     for n in (0, 1, 7, 18_000_000):
