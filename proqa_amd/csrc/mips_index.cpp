@@ -1490,8 +1490,17 @@ int rescue_short_queries(proqa_index* idx) {
   const proqa_search_stats outer = idx->stats;
   const int mode = idx->leap_mode;
   idx->leap_mode = 0;   // (ordinary rounds; the pause this search earned stays as note_leap left it)
+  // the second search is part of the caller's ONE search: it does not count towards the automatic mode of the int8 scan
+  // (a suspended scan's probe distance, the copy's searches), whose state is put back as the caller's search left it
+  const bool unprofitable = idx->q8_unprofitable, small_ok = idx->small_merge_ok;
+  const int suspended = idx->q8_suspended_searches, probe_after = idx->q8_probe_after, on_copy = idx->q8_searches_on_copy;
   const int rc = search_device_impl(idx, base + off_xq, s, PROQA_F16, k, rq.idx_offset, D_tmp, (int64_t*)I_tmp, rq.st, false, nullptr);
   idx->leap_mode = mode;
+  idx->q8_unprofitable = unprofitable;
+  idx->small_merge_ok = small_ok;
+  idx->q8_suspended_searches = suspended;
+  idx->q8_probe_after = probe_after;
+  idx->q8_searches_on_copy = on_copy;
   if (rc) return rc;
   PROQA_HIP(launch_scatter_result_rows(D_tmp, I_tmp, ids_dev, s, k, rq.D, rq.I, rq.out_stride, rq.st));
   PROQA_HIP(hipStreamSynchronize(rq.st));
@@ -1501,7 +1510,7 @@ int rescue_short_queries(proqa_index* idx) {
   idx->stats.candidates += inner.candidates;
   idx->stats.nominated += inner.nominated;
   idx->stats.total_ms += inner.total_ms;
-  idx->stats.nomination_state = inner.nomination_state;
+  idx->stats.nomination_state = nomination_state_of(idx);
   idx->stats.leap_state = leap_state_of(idx);
   log_line("index %p: %d quer%s a leaping round left short searched again on ordinary rounds (%d rounds, %.3f ms)", (void*)idx, s,
            s == 1 ? "y" : "ies", inner.rounds, inner.total_ms);
