@@ -149,6 +149,10 @@ struct proqa_index {
     long long idx_offset = 0;
     hipStream_t st = nullptr;
   } rescue;
+  // compact lists the re-scoring of an int8 one-pass launch writes for its merge (one_pass_big_launch_i8)
+  proqa::WaveRecord* emit_log = nullptr;
+  unsigned* emit_cnt = nullptr;
+  size_t emit_records = 0, emit_counts = 0;
   void* rescue_buf = nullptr;              // device: ids, fp16 query rows, D and I rows of the rescue batch
   size_t rescue_bytes = 0;
   signed char* xq8 = nullptr;              // workspace [ws_nq_pad,128]
@@ -325,6 +329,8 @@ int ensure_q8(proqa_index* idx, hipStream_t st) {
     if (try_malloc((void**)&idx->xb8, (size_t)cap * kDim) != hipSuccess ||
         try_malloc((void**)&idx->blk8, (size_t)(cap / 32 + 16) * sizeof(float2)) != hipSuccess) {
       if (idx->rescue_buf) (void)hipFree(idx->rescue_buf);
+  if (idx->emit_log) (void)hipFree(idx->emit_log);
+  if (idx->emit_cnt) (void)hipFree(idx->emit_cnt);
   if (idx->xb8) (void)hipFree(idx->xb8);
       idx->xb8 = nullptr;
       idx->q8_epoch = idx->rows_epoch;   // no room for the copy: this index is searched on its fp16 rows
@@ -1162,6 +1168,7 @@ struct OnePassPlan {
   unsigned lane_cap = 0;       // records per lane list of the big launch
   bool compact = false;        // the big launch logs 8-byte keys (mips_filter_f16<COMPACT>)
   long long max_queries = 0;   // per launch, within kOnePassMaxStoreBytes of candidate store
+  double expected = 0.0;       // rows expected to beat the sampled threshold, per query
 };
 
 const bool kOnePass = !(getenv("PROQA_ONE_PASS") && atoi(getenv("PROQA_ONE_PASS")) == 0);   // developer A/B switch
@@ -1212,6 +1219,7 @@ OnePassPlan plan_one_pass(const proqa_index* idx, int64_t nq_pad, int k, bool la
   if (const char* v = getenv("PROQA_ONE_PASS_STORE_MB")) budget = (size_t)atoll(v) << 20;   // tests: force the grouping
   p.max_queries = (long long)(budget / per_query) / 512 * 512;
   if (p.max_queries < 512 && nq_pad > p.max_queries) return p;
+  p.expected = expected;
   p.use = true;
   return p;
 }
@@ -1236,6 +1244,122 @@ int one_pass_big_launch(proqa_index* idx, const OnePassPlan& pl, const RoundShap
   return PROQA_OK;
 }
 
+// The big launch of a one-pass search for a FEW queries (one question with k = 5000, online_sampler.py:113) on the
+// int8 copy: such a launch is an HBM stream, and the int8 rows are half the bytes (18M rows: 0.68 -> ~0.37 ms).  The scan
+// logs {row0, nominee bits} records exactly as a nominating round does; rescore_nominated_lists re-scores the nominated rows
+// (~2.5 x the rows that pass: ~19 k x 256 B for k = 5000, nothing for a few queries -- for thousands it would be tens of GB,
+// which is why the batched large-k search stays on the fp16 scan) and writes the keys that beat the sampled threshold as
+// compact lists; the compact merge and everything behind it are the fp16 launch's.  *handled = false: not taken (no usable
+// copy, a shape the lists do not fit) -- the caller runs the fp16 launch.
+const bool kOnePassI8 = !(getenv("PROQA_ONE_PASS_I8") && atoi(getenv("PROQA_ONE_PASS_I8")) == 0);   // developer A/B switch
+// When it pays: the launch saves 128 B per row of the shard and costs a 256-byte gather (plus a share of an MFMA and of a merge)
+// per nominated row, ~3 x expected per query -- measured break-even near rows = 12 x queries x expected (18M rows, k = 5000:
+// -32 % for one question, -26 % for 64, -19 % for 128, -7 % for 256; 2.25M rows: -15 % for one, 0 for 32); taken from 16 x.
+// (developer override PROQA_ONE_PASS_I8_MAX_QUERIES: up to that many queries whatever the shard)
+const int kOnePassI8MaxQueries = getenv("PROQA_ONE_PASS_I8_MAX_QUERIES") ? atoi(getenv("PROQA_ONE_PASS_I8_MAX_QUERIES")) : 0;
+int one_pass_big_launch_i8(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int k,
+                           const PageOut& out, hipStream_t st, int sample_rounds, bool* done, bool* handled) {
+  *handled = false;
+  if (!kOnePassI8 || qw != 1 || idx->exact || idx->nominate_mode == 0 || idx->n < kNominateMinRows) return PROQA_OK;
+  if (kOnePassI8MaxQueries > 0 ? nq > kOnePassI8MaxQueries : 16.0 * (double)nq * pl.expected > (double)idx->n) return PROQA_OK;
+  if (idx->q8_epoch != idx->rows_epoch) {
+    if (idx->nominate_mode == 1 && idx->q8_short_lived_builds >= 2) return PROQA_OK;   // rows that keep changing: see setup_nominate
+    if (int rc = ensure_q8(idx, st)) return rc;
+  }
+  if (!idx->q8_usable || (idx->q8_unprofitable && idx->nominate_mode != 2)) return PROQA_OK;
+  // lists: ~8 records (of kNominateLaneCap = 32) per lane list of the scan at 3 nominated rows per passing row; ~24 keys (of
+  // kCompactKeys = 64) per compact list
+  const unsigned want = round_up<unsigned>((unsigned)std::ceil(3.0 * pl.expected / 16.0), 8);
+  const LaunchGeom g = geometry(idx->n, n_qtiles, false, k, want);
+  const unsigned in_lists = 2 * g.chunks;
+  unsigned groups = std::max(2u, round_up<unsigned>((unsigned)std::ceil(pl.expected / 24.0), 2));
+  const unsigned per_group = ceil_div<unsigned>(in_lists, groups);
+  if (per_group == 0 || per_group > 64) return PROQA_OK;
+  groups = round_up<unsigned>(ceil_div<unsigned>(in_lists, per_group), 2);
+  const unsigned out_chunks = groups / 2, out_stride = round_up<unsigned>(out_chunks, 8);
+  if (int rc = ensure_store(idx, round_up<unsigned>(g.chunks, 8), n_qtiles, nq_pad, kNominateLaneCap))
+    return rc == PROQA_ENOMEM ? PROQA_OK : rc;
+  {
+    const size_t records = (size_t)out_chunks * nq_pad * 2 * kCompactLaneCap, counts = (size_t)nq_pad * out_stride * 2;
+    if (records > idx->emit_records || counts > idx->emit_counts) {
+      PROQA_HIP(hipStreamSynchronize(st));
+      if (idx->emit_log) (void)hipFree(idx->emit_log);
+      if (idx->emit_cnt) (void)hipFree(idx->emit_cnt);
+      idx->emit_log = nullptr;
+      idx->emit_cnt = nullptr;
+      idx->emit_records = idx->emit_counts = 0;
+      PROQA_HIP(hipMalloc((void**)&idx->emit_log, records * sizeof(WaveRecord)));
+      PROQA_HIP(hipMalloc((void**)&idx->emit_cnt, counts * sizeof(unsigned)));
+      idx->emit_records = records;
+      idx->emit_counts = counts;
+    }
+  }
+  *handled = true;
+  // (the merge reads the list lengths of every padded query; the re-scoring writes those of the real ones)
+  PROQA_HIP(hipMemsetAsync(idx->emit_cnt, 0, (size_t)nq_pad * out_stride * 2 * sizeof(unsigned), st));
+  PROQA_HIP(launch_prep_queries_i8(idx->xq_pad, idx->ws_nq_pad, idx->col, idx->qstats, idx->xq8, idx->qparams, idx->stat_nom, st));
+  PROQA_HIP(hipMemsetAsync(idx->run_n, 0, (size_t)idx->ws_nq_pad * sizeof(unsigned), st));
+  unsigned* word = idx->overflow + 1;   // [1]: the pass overflowed, [2]: a query came back short
+  FilterArgsI8 fa;
+  fa.xq8 = idx->xq8;
+  fa.xb8 = idx->xb8;
+  fa.slab_row0 = 0;
+  fa.slab_row1 = idx->n;
+  fa.rows_per_chunk = g.rows_per_chunk;
+  fa.tau = idx->tau;
+  fa.qp = idx->qparams;
+  fa.blk = idx->blk8;
+  fa.store = store_of(idx, (unsigned)nq_pad, n_qtiles, kNominateLaneCap, round_up<unsigned>(g.chunks, 8));
+  fa.overflow = word;
+  fa.flags = kFilterFlags;
+  // (row-split launch as in run_round: the 1 / 2 / 4 query blocks that hold queries, the eight waves share the units of the stream)
+  fa.q_blocks = kRowSplit && nq <= 128 ? (nq <= 32 ? 1u : (nq <= 64 ? 2u : 4u)) : 0u;
+  PROQA_HIP(launch_filter_i8(fa, qw, g.grid, st, false));
+  CandidateStore emitted;
+  emitted.lane_log = idx->emit_log;
+  emitted.lane_cnt = idx->emit_cnt;
+  emitted.spill_log = idx->spill_log;   // (the merge reads a spill counter per chunk up front whatever the lists hold; compact
+  emitted.spill_cnt = idx->spill_cnt;   //  lists have no spill log and the value is not used: any valid counters do)
+  emitted.nq_pad = (unsigned)nq_pad;
+  emitted.n_qtiles = n_qtiles;
+  emitted.lane_cap = (unsigned)kCompactLaneCap;
+  emitted.n_chunks = out_stride;
+  RescoreArgs ra;
+  ra.in = fa.store;
+  ra.in_lists = in_lists;
+  ra.lists_per_group = per_group;
+  ra.out = emitted;
+  ra.xq16 = idx->xq_pad;
+  ra.xb16 = idx->xb;
+  ra.tau = idx->tau;
+  ra.overflow = word;
+  ra.stat_nominated = idx->stat_nom;
+  PROQA_HIP(launch_rescore_nominated_lists(ra, groups, (unsigned)nq, st));
+  MergeArgs ma = {};
+  ma.store = emitted;
+  ma.n_chunks = out_chunks;
+  ma.qw = (unsigned)qw;
+  ma.run_keys = idx->run_keys;
+  ma.run_n = idx->run_n;
+  ma.tau = idx->tau;
+  ma.k = k;
+  ma.sort_cap = pl.sort_cap;
+  ma.stat_candidates = idx->stat_dev;
+  ma.overflow = word;
+  ma.compact = 1;
+  PROQA_HIP(launch_merge(ma, (unsigned)nq_pad, st));
+  PROQA_HIP(launch_flag_short_lists(idx->run_n, nq, (unsigned)k, word + 1, st));
+  PROQA_HIP(launch_finalize(idx->run_keys, idx->run_n, nq, k, out.idx_offset, out.D, out.I, out.out_stride, 0, idx->overflow, nullptr,
+                            idx->mirror, idx->stat_dev, st, idx->stat_nom));
+  PROQA_HIP(hipEventRecord(idx->ev[1], st));
+  PROQA_HIP(hipStreamSynchronize(st));
+  idx->stats.rounds += sample_rounds + 1;
+  idx->stats.nomination = 1;
+  idx->stats.nominated = (int64_t)idx->mirror->nominated;
+  *done = !idx->mirror->overflow[1] && !idx->mirror->overflow[2];
+  return PROQA_OK;
+}
+
 // returns PROQA_OK with *done = false when the estimate failed (the caller searches page by page)
 int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_qtiles, int64_t nq, int64_t nq_pad, int k,
                     const PageOut& out, hipStream_t st, bool* done) {
@@ -1252,6 +1376,11 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   // (several times slower) the launch is repeated ONCE over four times the chunks -- against the thresholds the first
   // attempt's merge left, which are still lower bounds of the k-th best scores and usually tighter.
   auto big_launch_with_retry = [&](int sample_rounds) -> int {
+    {   // a few queries: the launch over the shard on the int8 copy (a void attempt -- its lists overflowed -- goes to pages)
+      bool handled = false;
+      if (int rc8 = one_pass_big_launch_i8(idx, pl, qw, n_qtiles, nq, nq_pad, k, out, st, sample_rounds, done, &handled)) return rc8;
+      if (handled) return PROQA_OK;
+    }
     int rc = one_pass_big_launch(idx, pl, shape, qw, n_qtiles, nq, nq_pad, k, out, st, sample_rounds, done);
     if (rc || *done || !shape.compact || !idx->mirror->overflow[1]) return rc;
     RoundShape wide = shape;
@@ -1476,6 +1605,8 @@ int rescue_short_queries(proqa_index* idx) {
                off_i = round_up<size_t>(off_d + (size_t)s * k * sizeof(float), 256), bytes = off_i + (size_t)s * k * sizeof(long long);
   if (bytes > idx->rescue_bytes) {
     if (idx->rescue_buf) (void)hipFree(idx->rescue_buf);
+  if (idx->emit_log) (void)hipFree(idx->emit_log);
+  if (idx->emit_cnt) (void)hipFree(idx->emit_cnt);
     idx->rescue_buf = nullptr;
     idx->rescue_bytes = 0;
     PROQA_HIP(hipMalloc(&idx->rescue_buf, bytes));

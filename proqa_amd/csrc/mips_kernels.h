@@ -198,6 +198,22 @@ hipError_t launch_prep_queries(const void* xq, int dtype, long long nq, long lon
                                float* tau, unsigned* run_n, unsigned long long* stat, const unsigned char* done,
                                bool reset_stat, unsigned* inexact, unsigned* overflow, hipStream_t st,
                                unsigned* short_rounds = nullptr);
+// One-pass search of a large k for a FEW queries (mips_index.cpp one_pass_big_launch_i8): the launch over the shard scans the
+// int8 copy (half the bytes of an HBM-bound pass) and logs {row0, nominee bits} records; this kernel re-scores the nominated
+// rows of `lists_per_group` lane lists per workgroup from the fp16 rows (the fp16 scan's MFMA sequence: its bits) and writes
+// the keys that beat tau as ONE compact list per group -- the lists the compact merge (MergeArgs::compact) sorts.
+struct RescoreArgs {
+  CandidateStore in;          // records of the int8 launch (8 bytes each, in.lane_cap per list)
+  unsigned in_lists;          // 2 x its chunks
+  unsigned lists_per_group;   // <= 64
+  CandidateStore out;         // group g -> list (chunk g >> 1, half g & 1): kCompactKeys keys each, lengths in out.lane_cnt
+  const void* xq16;           // fp16 [nq_pad,128]
+  const char* xb16;           // fp16 rows of the shard
+  const float* tau;
+  unsigned* overflow;         // a group nominated more rows than it holds, or more keys passed than a compact list holds
+  unsigned long long* stat_nominated;
+};
+hipError_t launch_rescore_nominated_lists(const RescoreArgs& a, unsigned groups, unsigned nq, hipStream_t st);
 // rows ids[0..n) of the padded fp16 queries -> out [n,128]; result rows [n,k] -> rows ids[i] of D / I (row stride out_stride)
 hipError_t launch_gather_query_rows(const void* xq_pad, const int* ids, int n, void* out, hipStream_t st);
 hipError_t launch_scatter_result_rows(const float* D_src, const long long* I_src, const int* ids, int n, int k, float* D, long long* I,

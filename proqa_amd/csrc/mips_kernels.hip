@@ -1963,6 +1963,91 @@ void topk_merge(MergeArgs a) {
   for (unsigned i = tid; i < keep; i += T) a.run_keys[(size_t)q * a.k + i] = keys[i];
 }
 
+
+// see RescoreArgs (mips_kernels.h)
+constexpr unsigned kRescoreNominees = 1024;
+__global__ __launch_bounds__(256) void rescore_nominated_lists(RescoreArgs a) {
+  __shared__ __attribute__((aligned(16))) char s_qrow[kRowBytes];
+  __shared__ unsigned s_nom[kRescoreNominees];
+  __shared__ unsigned long long s_keys[kCompactKeys];
+  __shared__ unsigned s_n_nom, s_n_keys, s_cnt[64], s_off[65];
+  __shared__ float s_sc[4][32];
+  const unsigned g = blockIdx.x, q = blockIdx.y;
+  const int tid = threadIdx.x;
+  const unsigned L = a.lists_per_group;
+  const unsigned l0 = g * L;
+  if (tid == 0) {
+    s_n_nom = 0;
+    s_n_keys = 0;
+  }
+  if (tid < kRowBytes / 16) ((uint4*)s_qrow)[tid] = ((const uint4*)((const char*)a.xq16 + (size_t)q * kRowBytes))[tid];
+  if ((unsigned)tid < L) {
+    const unsigned l = l0 + (unsigned)tid;
+    unsigned c = l < a.in_lists ? a.in.lane_cnt[lane_cnt_index(a.in, l >> 1, q, (int)(l & 1))] : 0u;
+    s_cnt[tid] = c < a.in.lane_cap ? c : a.in.lane_cap;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned o = 0;
+    for (unsigned i = 0; i < L; ++i) {
+      s_off[i] = o;
+      o += s_cnt[i];
+    }
+    s_off[L] = o;
+  }
+  __syncthreads();
+  const unsigned n_rec = s_off[L];
+  ExactCtx ex = {s_nom, &s_n_nom};
+  for (unsigned w = tid; w < n_rec; w += 256) {
+    unsigned i = 0;
+    while (w >= s_off[i + 1]) ++i;
+    const unsigned l = l0 + i;
+    keep_nominees(((const uint2*)a.in.lane_log)[lane_list_index(a.in, l >> 1, q, (int)(l & 1)) * a.in.lane_cap + (w - s_off[i])], ex,
+                  kRescoreNominees);
+  }
+  __syncthreads();
+  unsigned n_nom = s_n_nom;
+  if (n_nom > kRescoreNominees) {
+    if (tid == 0) *a.overflow = 1u;
+    n_nom = kRescoreNominees;
+  }
+  const float tau = a.tau[q];
+  const int lane = tid & 63, w = tid >> 6, li = lane & 31, half = lane >> 5;
+  for (unsigned c0 = (unsigned)w * 32; c0 < n_nom; c0 += 4 * 32) {   // wave-uniform trip count (as in topk_merge<NOMINATED>)
+    const unsigned mine = c0 + (unsigned)li < n_nom ? c0 + (unsigned)li : c0;
+    const unsigned row = s_nom[mine];
+    const char* ap = a.xb16 + (size_t)row * kRowBytes;
+    f16x8 af[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[j] = *(const f16x8*)(ap + (2 * j + half) * 16);
+    f32x16 acc = {0};
+    unsigned qoff = (unsigned)half * 16u;
+    asm volatile("" : "+v"(qoff));
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[j], *(const f16x8*)(s_qrow + qoff + 32 * j), acc, 0, 0, 0);
+    if (li == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_sc[w][(r & 3) + 8 * (r >> 2) + 4 * half] = acc[r];
+    }
+    const float score = s_sc[w][li];
+    const bool keep = half == 0 && c0 + (unsigned)li < n_nom && score > tau;
+    wave_append(keep, pack_key(score, row), s_keys, &s_n_keys, kCompactKeys);
+  }
+  __syncthreads();
+  unsigned n = s_n_keys;
+  if (n > kCompactKeys) {
+    if (tid == 0) *a.overflow = 1u;
+    n = kCompactKeys;
+  }
+  unsigned long long* dst = (unsigned long long*)(a.out.lane_log + lane_list_index(a.out, g >> 1, q, (int)(g & 1)) * a.out.lane_cap);
+  if ((unsigned)tid < n) dst[tid] = s_keys[tid];
+  if (tid == 0) {
+    a.out.lane_cnt[lane_cnt_index(a.out, g >> 1, q, (int)(g & 1))] = n;
+    if (a.stat_nominated) atomicAdd(a.stat_nominated + q, (unsigned long long)n_nom);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // bootstrap: exact top-k of the first R0 corpus rows in two launches
 // ---------------------------------------------------------------------------------------
@@ -2697,6 +2782,13 @@ hipError_t launch_gather_index_rows(const void* xb16, const float* xb32, long lo
   const long long pieces = n * (out_f32 ? kDim / 4 : kDim / 8);
   hipLaunchKernelGGL(gather_index_rows, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const _Float16*)xb16, xb32,
                      n_index, ids, n, idx_offset, out, out_f32 ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t launch_rescore_nominated_lists(const RescoreArgs& a, unsigned groups, unsigned nq, hipStream_t st) {
+  if (groups == 0 || nq == 0) return hipSuccess;
+  if (a.lists_per_group == 0 || a.lists_per_group > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rescore_nominated_lists, dim3(groups, nq), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -579,3 +579,31 @@ for i in range(3):
         assert r[1] == "True" and r[2] == "on" and int(r[3]) == 0 and r[4] == "True", rows
     assert sum("overflowed the 1024-key merge" in ln for ln in p.stderr.splitlines()) == 1, p.stderr[-1500:]
     assert "suspended" not in p.stderr
+
+
+@pytest.mark.parametrize("n,nq,k", [(400000, 1, 5000), (2000000, 32, 2000), (1000000, 7, 5000), (200000, 5, 700)])
+def test_one_pass_large_k_for_a_few_queries_scans_the_int8_copy(gpu_device, n, nq, k):
+    """k in the thousands for <= 32 queries (online_sampler.py:113: one question, k = 5000): the one launch over the shard is an
+    HBM stream -- it runs on the int8 copy (half the bytes), the nominated rows are re-scored by rescore_nominated_lists and
+    the compact merge sorts what beats the sampled threshold (taken while rows >= 16 x queries x the rows expected above the
+    threshold: the gather of the nominated rows must stay small beside the bytes saved).  Ids and score bits are the fp16
+    launch's."""
+    import torch
+    from proqa_amd.index import IndexFlatIP
+    rng = np.random.default_rng(n + nq + k)
+    xb = rng.standard_normal((n, 128)).astype(np.float16)
+    xq = rng.standard_normal((nq, 128)).astype(np.float16)
+    tq = torch.from_numpy(xq).cuda()
+    out = []
+    for mode in ("off", "auto"):
+        ix = IndexFlatIP(128)
+        ix.configure_nomination(mode)
+        ix.add(xb)
+        D, I = ix.search_device(tq, k)
+        out.append((D.cpu().numpy(), I.cpu().numpy(), ix.last_stats()))
+        ix.close()
+    (D0, I0, st0), (D1, I1, st1) = out
+    assert not st0["nomination"] and st1["nomination"] and st1["nominated"] >= nq * k, (st0, st1)
+    assert st0["fallback_rounds"] == 0 and st1["fallback_rounds"] == 0
+    np.testing.assert_array_equal(I1, I0)
+    np.testing.assert_array_equal(D1.view(np.uint32), D0.view(np.uint32))
