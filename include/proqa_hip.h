@@ -185,7 +185,9 @@ int proqa_index_configure_bootstrap(proqa_index* idx, int rows);
  * overflow-safe path SUSPENDS the int8 rounds (fp16 scan); the 8th eligible search after that probes them again, a
  * failed probe doubles the distance (16, 32, 64, 64, ...), a successful one resumes; a change of the rows starts afresh;
  * every switch is one line on stderr when PROQA_LOG is set, and proqa_search_stats.nomination_state reports the state;
- * 2: always.  The copy (+128 B per row) is built by proqa_index_prepare, or by the first search that wants it.  Rows
+ * 2: always.  A search with k in the thousands for a FEW queries (one question, k = 5000: rows >= 16 x queries x ~1.5 k) scans
+ * the copy as well, in its one launch over the shard (same result; mode 0 keeps the fp16 rows).  The copy (+128 B per row) is
+ * built by proqa_index_prepare, or by the first search that wants it.  Rows
  * adopted with proqa_index_adopt_device: see the immutability note there. */
 int proqa_index_configure_nomination(proqa_index* idx, int mode);
 /* Leaping rounds of the k <= 128 searches (fp16 indexes, default schedule, behind the bootstrap).  A round that tests against
