@@ -135,6 +135,8 @@ struct proqa_index {
   long long leap_key[6] = {0, 0, 0, 0, 0, 0};   // what the kept plan was made for
   int leap_plan_rounds = 0, leap_plan_rank = 0;
   double leap_plan_per_round = 0.0;
+  long long leap_sample_key[4] = {0, 0, 0, 0};   // the same for the sample rounds of the one-pass search of a large k
+  int leap_sample_rounds = 0, leap_sample_rank = 0;
   int leap_logged = 0;                     // the plan last reported under PROQA_LOG
   uint64_t leap_epoch = 0;                 // rows_epoch the pause belongs to (changed rows start afresh)
   int round_next_rank = 0, round_leap_check = 0, round_bit = 0;   // MergeArgs of the round being enqueued
@@ -643,9 +645,9 @@ struct LeapPlan {
 // 2032 queries: 4-5 rounds at 18M rows, 3 at 2.25M; <= 256 queries: 3 and 2).  The rows per round are capped by what the
 // round's merge holds: their count varies by a relative 1 / sqrt(rank) around rank (rho - 1) (5 sigma are allowed for), and the
 // int8 scan nominates ~2-2.5 x the rows that pass (2048-key merge: 2048 nominated rows).
-LeapPlan plan_leap(long long n, long long boot, int k, int qw, bool nominating) {
+LeapPlan plan_leap(long long n, long long boot, int k, int qw, bool nominating, int max_k = kLeapMaxK) {
   LeapPlan best;
-  if (boot <= 0 || n <= boot || k > kLeapMaxK || k < 8) return best;
+  if (boot <= 0 || n <= boot || k > max_k || k < 8) return best;
   const int fixed_rounds = env_int("PROQA_LEAP_ROUNDS", 0), fixed_rank = env_int("PROQA_LEAP_RANK", 0);
   const double eps = getenv("PROQA_LEAP_EPS") ? atof(getenv("PROQA_LEAP_EPS")) : kLeapEps;
   const double ratio = (double)n / (double)boot;
@@ -1462,9 +1464,32 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   const double g_cap = idx->growth > 0 ? idx->growth : (qw == 1 ? 8 : 4);
   const double growth = std::min(g_cap, 0.85 * (sort_capacity(r) - r) / r);
   std::vector<Slab> slabs = plan_slabs(pl.n_sample, std::min<int>(idx->first_slab_rows, first_cap), growth, boot);
+  // Leaping sample rounds (plan_leap; r <= 256: the merge's early exit reads the whole running list from one key per thread):
+  // thresholds at a rank j < r, two rounds instead of three for one question with k = 5000.  Nothing verifies them and nothing
+  // needs to: a round that falls short leaves the sample's r-th best too LOW, i.e. a looser threshold for the launch over
+  // the shard, whose result is checked as ever (>= k rows per query, no overflow).
+  int leap_rank_sample = 0;
+  if (boot && r <= 256 && idx->leap_mode && env_int("PROQA_LEAP", 1) != 0 && idx->growth == 0 && kGrowthList.empty()) {
+    // (the plan is kept: the negative-binomial sums for r = 256 are ~0.2 ms of host time)
+    const long long key[4] = {pl.n_sample, boot, r, qw};
+    if (std::memcmp(key, idx->leap_sample_key, sizeof key) != 0) {
+      std::memcpy(idx->leap_sample_key, key, sizeof key);
+      const LeapPlan fresh = plan_leap(pl.n_sample, boot, r, qw, false, 256);
+      idx->leap_sample_rounds = fresh.rounds;
+      idx->leap_sample_rank = fresh.rank;
+    }
+    LeapPlan lp;
+    lp.rounds = idx->leap_sample_rounds;
+    lp.rank = idx->leap_sample_rank;
+    if (lp.rounds && lp.rounds < (int)slabs.size()) {
+      const double rho = std::pow((double)pl.n_sample / (double)boot, 1.0 / lp.rounds);
+      slabs = plan_slabs_equal(pl.n_sample, boot, rho - 1.0 + 1e-6);
+      leap_rank_sample = lp.rank;
+    }
+  }
   if ((int)slabs.size() + 4 > kMaxRounds) return PROQA_OK;
   if (boot)
-    if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, r, st)) return rc;
+    if (int rc = run_bootstrap(idx, boot, (unsigned)nq_pad, r, st, 0, leap_rank_sample)) return rc;
   // spread the slabs over [boot, n): slab i keeps its length and starts i/m of the way through
   {
     const size_t m = slabs.size();
@@ -1484,8 +1509,11 @@ int search_one_pass(proqa_index* idx, const OnePassPlan& pl, int qw, unsigned n_
   long long seen = boot;
   for (size_t i = 0; i < slabs.size(); ++i) {
     // while fewer than r rows have been merged the threshold is still -inf: every row is logged
-    if (int rc = run_round(idx, slabs[i], qw, n_qtiles, (unsigned)nq_pad, r, false, seen < r, false, idx->overflow, st, nullptr,
-                           nullptr))
+    idx->round_next_rank = leap_rank_sample && i + 1 < slabs.size() ? leap_rank_sample : 0;
+    const int rc_round = run_round(idx, slabs[i], qw, n_qtiles, (unsigned)nq_pad, r, false, seen < r, false, idx->overflow, st, nullptr,
+                                   nullptr);
+    idx->round_next_rank = 0;
+    if (int rc = rc_round)
       return rc;
     seen += slabs[i].r1 - slabs[i].r0;
     if (kDebugCand) {
