@@ -152,7 +152,8 @@ int proqa_index_reconstruct_batch_device(proqa_index* idx, const int64_t* ids_de
 /* statistics of the last search on this handle (for tests and the benchmark) */
 typedef struct proqa_search_stats {
   int32_t rounds;            /* filter+merge rounds launched */
-  int32_t fallback_rounds;   /* rounds re-run on the overflow-safe path */
+  int32_t fallback_rounds;   /* rounds run again: slabs re-scanned on the overflow-safe path, and the rounds of the second
+                                search that the queries a leaping round left short are given (proqa_index_configure_leap) */
   int64_t candidates;        /* (score,id) pairs that passed the running threshold */
   float filter_ms;           /* HIP-event time of the mips_filter launches, summed over the
                                 rounds (0 unless profiling is enabled on the handle) */
