@@ -210,6 +210,14 @@ int proqa_index_configure_nomination(proqa_index* idx, int mode);
  * stderr line per event under PROQA_LOG.  mode 0: never; 1 (default): automatic, as above.  An index configured with
  * proqa_index_configure(growth) keeps its ordinary rounds. */
 int proqa_index_configure_leap(proqa_index* idx, int mode);
+/* The schedule proqa_index_configure_leap's automatic mode takes for a search of `queries` queries for the best k of `rows`
+ * rows behind a bootstrap of `bootstrap_rows` (host arithmetic only, no GPU): rounds behind the bootstrap (0: no leap --
+ * k > 128 or k < 8, or nothing fits the merges), the rank j < k its thresholds sit at, the rows expected above a threshold
+ * per round and query (j (rho - 1), rho = (rows / bootstrap_rows)^(1 / rounds)) and the probability that fewer than k - j rows
+ * beat it -- the negative-binomial (j, 1 / rho) sum -- per query and round.  nominating: the rounds scan the int8 copy (their
+ * merges hold 2048 nominated rows).  rows_per_round / shortfall_probability may be NULL. */
+int proqa_leap_plan(int64_t rows, int64_t bootstrap_rows, int k, int64_t queries, int nominating, int* rounds, int* rank,
+                    double* rows_per_round, double* shortfall_probability);
 
 /* Merge n_parts per-shard result lists into one: D_parts/I_parts are [n_parts, nq, k]
  * (the layout an RCCL all-gather of per-rank [nq, k] produces); every list as a search reports it (scores descending,

@@ -93,6 +93,8 @@ SIGNATURES = {
     "proqa_index_configure": (c_int, [c_void_p, c_int, c_int]),
     "proqa_index_configure_nomination": (c_int, [c_void_p, c_int]),
     "proqa_index_configure_leap": (c_int, [c_void_p, c_int]),
+    "proqa_leap_plan": (c_int, [c_int64, c_int64, c_int, c_int64, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "proqa_index_configure_bootstrap": (c_int, [c_void_p, c_int]),
     "proqa_topk_merge_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p,
                                         c_void_p, c_void_p]),

@@ -2067,6 +2067,19 @@ int proqa_index_configure_leap(proqa_index* idx, int mode) {
   return PROQA_OK;
 }
 
+int proqa_leap_plan(int64_t rows, int64_t bootstrap_rows, int k, int64_t queries, int nominating, int* rounds, int* rank,
+                    double* rows_per_round, double* shortfall_probability) {
+  if (!rounds || !rank) return fail(PROQA_EINVAL, "leap_plan: NULL output");
+  if (rows <= 0 || bootstrap_rows <= 0 || k <= 0 || queries <= 0) return fail(PROQA_EINVAL, "leap_plan: non-positive argument");
+  const LeapPlan lp = plan_leap(rows, bootstrap_rows, k, queries > 256 ? 2 : 1, nominating != 0);
+  *rounds = lp.rounds;
+  *rank = lp.rank;
+  if (rows_per_round) *rows_per_round = lp.per_round;
+  if (shortfall_probability)
+    *shortfall_probability = lp.rounds ? leap_fail_probability(k, lp.rank, std::pow((double)rows / (double)bootstrap_rows, 1.0 / lp.rounds)) : 0.0;
+  return PROQA_OK;
+}
+
 int proqa_index_prepare(proqa_index* idx, void* stream) {
   if (!idx) return fail(PROQA_EINVAL, "index_prepare: NULL handle");
   if (idx->pending.active) return fail(PROQA_EINVAL, "index_prepare: a search begun on this handle has not been finished");
