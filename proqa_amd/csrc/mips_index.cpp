@@ -597,13 +597,15 @@ std::vector<Slab> plan_slabs(long long n, int first, double growth, long long st
 // A round that tests against the k-th best score of the n0 rows seen so far logs ~k (rho - 1) rows of the next (rho - 1) n0,
 // which is what caps the growth of the ordinary schedule (a merge holds so many keys; every candidate is a gather).  The
 // rows that end up in the best k are far fewer: a round may test against the score at rank j < k instead -- it then logs
-// ~j (rho - 1) rows -- provided at least k rows of the rho n0 now seen reach that score, for then every row of the best k is
-// among them (the running list holds every earlier row that reaches it: j <= k).  The merge verifies exactly that (its
-// k-th key reaches the threshold it was given, topk_merge); a round that fails is flagged like an overflowed one and re-scanned
-// against the k-th best scores (page_complete).  For rows in an order the first n0 stand for (exchangeable: any corpus that
-// is not sorted by topic or norm), the count of new rows above the rank-j score is negative-binomial (j, 1 / rho): mean
-// j (rho - 1), and P(fewer than k - j) is a closed sum -- leap_rank takes the smallest j that keeps it below kLeapEps per query
-// and round (1e-8: one re-scan in ~10^4 searches of 2032 queries).  The result never depends on any of this.
+// ~j (rho - 1) rows -- provided at least k rows of the rho n0 now seen BEAT that score, for then every row of the best k
+// does, and each of them is in the running list (an earlier row: the list holds the best k of those) or was logged.  The
+// merge verifies exactly that (its k-th key beats the threshold it was handed, topk_merge: note_rank) and marks the queries
+// for which it does not hold; those are searched again on ordinary rounds (page_complete -> rescue_short_queries), or, when a
+// list or a merge overflowed as well, the flagged slabs are re-scanned against the k-th best scores like any overflowed
+// round.  For rows in an order the first n0 stand for (exchangeable: no sorting by topic or norm, no long runs of rows that
+// score alike), the count of new rows above the rank-j score is negative-binomial (j, 1 / rho): mean j (rho - 1), and
+// P(fewer than k - j) is a closed sum -- leap_rank takes the smallest j that keeps it below kLeapEps per query and round
+// (1e-8: one second search in ~10^4 searches of 2032 queries).  The result never depends on any of this.
 // (developer switches, read at every search so that one process can alternate them: PROQA_LEAP=0 never; PROQA_LEAP_ROUNDS /
 // PROQA_LEAP_RANK / PROQA_LEAP_EPS fix the rounds behind the bootstrap, the rank, the probability)
 int env_int(const char* name, int dflt) {
