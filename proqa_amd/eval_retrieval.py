@@ -130,7 +130,7 @@ def dist_env():
 LAST_RUN_STATS = {}     # filled by search() / main(): seconds per stage of the last run (bench.py's search.cli_eval reads it)
 
 
-def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
+def search(indexpath, query_embed, topk, allow_rounding=False, readers=0, shard="rows"):
     """np.load + IndexFlatIP.add + search of the reference (:98-104), on the GPU.
 
     The index file goes from disk to HBM inside the library (proqa_index_add_npy: reader threads -> pinned ring -> PCIe,
@@ -140,7 +140,9 @@ def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
 
     Under torchrun (WORLD_SIZE > 1) the corpus is row-sharded: every rank loads ONLY rows [r*N/G, (r+1)*N/G) of the file
     into its GPU, all ranks search all queries, one all-gather of the per-shard lists (RCCL over xGMI) and a merge give
-    every rank the result of the single-GPU search, bit for bit (ShardedIndexFlatIP)."""
+    every rank the result of the single-GPU search, bit for bit (ShardedIndexFlatIP).
+    shard="queries": every rank loads ALL rows and searches its slice of the queries -- one all-gather of result rows, no
+    merge (QueryShardedIndexFlatIP: what 288 GB per GPU allow)."""
     import time
     from . import npy
     xq = npy.load(query_embed)
@@ -162,21 +164,27 @@ def search(indexpath, query_embed, topk, allow_rounding=False, readers=0):
     else:
         import torch
         import torch.distributed as dist
-        from .index import ShardedIndexFlatIP
+        from .index import QueryShardedIndexFlatIP, ShardedIndexFlatIP
         torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
         if not dist.is_initialized():
             # RCCL ("nccl") on ROCm.  PROQA_DIST_BACKEND=gloo lets two ranks share one GPU (RCCL refuses that), which is
             # how the GPU test exercises this path.
             dist.init_process_group(backend=os.environ.get("PROQA_DIST_BACKEND", "nccl"))
-        index = ShardedIndexFlatIP(info["rows"])
+        if shard == "queries":
+            index = QueryShardedIndexFlatIP()
+        else:
+            index = ShardedIndexFlatIP(info["rows"])
         if allow_rounding:
             index.local_index.allow_rounding(True)
         t0b = time.perf_counter()
-        index.add_local_npy(indexpath, readers)
+        if shard == "queries":
+            index.add_npy(indexpath, readers)
+        else:
+            index.add_local_npy(indexpath, readers)
         t1 = time.perf_counter()
         D, I = index.search(torch.from_numpy(np.ascontiguousarray(xq)).cuda(), topk)
         D, I = D.cpu().numpy(), I.cpu().numpy()
-        rows_here = index.hi - index.lo
+        rows_here = info["rows"] if shard == "queries" else index.hi - index.lo
     t2 = time.perf_counter()
     row_bytes = 128 * (2 if info["dtype"] == np.float16 else 4)
     LAST_RUN_STATS.update(world=world, rows=int(info["rows"]), rows_this_rank=int(rows_here), queries=int(xq.shape[0]),
@@ -215,6 +223,9 @@ def build_parser():
     parser.add_argument("--no-text-sidecar", action="store_true",
                         help="fetch the passage texts from the sqlite DB by document id even if a text sidecar (<stem>.txt, "
                              "gen_index_id_map --texts) sits next to the id map")
+    parser.add_argument("--shard", choices=("rows", "queries"), default="rows",
+                        help="under torchrun: row shards + all-gather + merge (default), or every rank loads all rows and "
+                             "searches its slice of the queries (no merge; 6.9 GB per GPU at 18M rows)")
     parser.add_argument("--dump-results", type=str, default=None,
                         help="also write the search result (D float32 [Q,k], I int64 [Q,k]) to this .npz (not in the reference)")
     return parser
@@ -228,7 +239,7 @@ def main(argv=None):
     t_start = time.perf_counter()
     if rank != 0:
         # a shard of the corpus and the collective; rank 0 maps ids, scores and prints
-        search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding)
+        search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding, shard=args.shard)
         finish_distributed()
         return []
     with open(args.raw_data) as f:
@@ -243,7 +254,7 @@ def main(argv=None):
     processes = ProcessPool(processes=args.num_workers, initializer=init, initargs=[args.db, text_sidecar])
     try:
         t0 = time.perf_counter()
-        D, I = search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding)
+        D, I = search(args.indexpath, args.query_embed, args.topk, allow_rounding=args.allow_fp16_rounding, shard=args.shard)
         finish_distributed()
         if args.dump_results:
             np.savez(args.dump_results, D=D, I=I)

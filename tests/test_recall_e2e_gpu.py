@@ -121,3 +121,15 @@ def test_cli_under_two_ranks_prints_the_same_lines(gpu_device, corpus, tmp_path)
     a, b = np.load(tmp_path / "single.npz"), np.load(tmp_path / "sharded.npz")
     np.testing.assert_array_equal(a["I"], b["I"])
     np.testing.assert_array_equal(a["D"], b["D"])
+    # --shard queries: every rank loads the whole file and searches its half of the questions; the same lines, the same result
+    env["MASTER_PORT"] = str(_free_port())
+    procs = [subprocess.Popen(cmd + ["--shard", "queries", "--dump-results", str(tmp_path / "qsharded.npz")],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    printed = ["".join(ln for ln in o[0].splitlines(True) if not ln.startswith("[Gloo]")) for o in outs]
+    assert printed[0] == single.stdout and printed[1] == ""
+    c = np.load(tmp_path / "qsharded.npz")
+    np.testing.assert_array_equal(a["I"], c["I"])
+    np.testing.assert_array_equal(a["D"], c["D"])
